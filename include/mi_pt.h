@@ -1,0 +1,278 @@
+/*
+ * mi_pt.h -- C ABI of the MI355X spectral path-tracing hot path.
+ *
+ * This is the one boundary the build introduces: host C++ (scene front end,
+ * Integrator-shaped class) -> C ABI -> hand-written HIP kernels (gfx950).
+ * It replaces, for `Integrator "path"`, the body of the reference's
+ *     SamplerIntegrator::Render(const Scene&)       src/core/integrator.cpp:228-342
+ *     PathIntegrator::Li(...)                       src/integrators/path.cpp:64-188
+ * The reference has no FFI: its integrator contract is the C++ virtual
+ *     class Integrator { virtual void Render(const Scene &scene) = 0; }
+ *                                                   src/core/integrator.h:53-58
+ * and Scene / BVHAccel keep their data private (src/core/scene.h:76-79,
+ * src/accelerators/bvh.h:91-94), so the drop-in is at the `.pbrt` file +
+ * `Integrator "path"` level: the host front end flattens the scene into the POD
+ * description below and calls mi_pt_*.
+ *
+ * Conventions: plain pointers + counts, host memory unless a flag says device;
+ * inputs are copied at mi_pt_create (caller keeps ownership); every entry point
+ * returns 0 on success or a negative mi_status, never aborts, never throws;
+ * one handle per GPU, calls on one handle are serialised by the caller.
+ * Spectrum = float[MI_NSPEC] (31 bins over 395..705 nm, src/core/spectrum.h:48-50).
+ */
+#ifndef MI_PT_H
+#define MI_PT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_NSPEC 31
+#define MI_ABI_VERSION 1
+#define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_INVALID = -1,   /* bad argument / malformed description */
+    MI_ERR_NO_DEVICE = -2, /* no HIP device / ordinal out of range */
+    MI_ERR_HIP = -3,       /* a HIP runtime call failed (see mi_pt_last_error) */
+    MI_ERR_UNSUPPORTED = -4,
+    MI_ERR_NOMEM = -5
+} mi_status;
+
+/* ---- acceleration structure: same 32-byte node as LinearBVHNode
+ *      (src/accelerators/bvh.cpp:95-104), depth-first, first child = idx+1. */
+typedef struct mi_bvh_node {
+    float bmin[3];
+    float bmax[3];
+    int32_t offset;    /* leaf: first primitive; interior: second child */
+    uint16_t n_prims;  /* 0 -> interior */
+    uint8_t axis;
+    uint8_t pad;
+} mi_bvh_node;
+
+/* One GeometricPrimitive (src/core/primitive.h:70-95) in BVH leaf order. */
+typedef struct mi_prim {
+    int32_t shape;      /* >=0: triangle index; <0: ~sphere index */
+    int32_t material;   /* index into materials, -1 = none (interface only) */
+    int32_t area_light; /* index into lights, -1 = not emissive */
+    int32_t pad;
+} mi_prim;
+
+/* Per TriangleMesh flags (src/shapes/triangle.cpp:54-92). */
+#define MI_MESH_HAS_N 1u
+#define MI_MESH_HAS_UV 2u
+#define MI_MESH_FLIP 4u /* reverseOrientation ^ transformSwapsHandedness */
+typedef struct mi_mesh {
+    uint32_t flags;
+    uint32_t first_vertex, n_vertices;
+    uint32_t first_tri, n_tris;
+} mi_mesh;
+
+/* Sphere (src/shapes/sphere.h:49-66). Matrices row-major, m[r*4+c]. */
+typedef struct mi_sphere {
+    float o2w[16], w2o[16];
+    float radius, z_min, z_max, theta_min, theta_max, phi_max;
+    int32_t reverse_orientation, swaps_handedness;
+} mi_sphere;
+
+/* ---- materials: textures are constants (src/textures/constant.h:49-58), so a
+ * Material::ComputeScatteringFunctions result is a fixed BxDF list. */
+typedef enum mi_bxdf_type {
+    MI_BXDF_LAMBERTIAN_REFLECTION = 0, /* R */
+    MI_BXDF_OREN_NAYAR,                /* R, p[0]=A, p[1]=B */
+    MI_BXDF_SPECULAR_REFLECTION,       /* R, fresnel */
+    MI_BXDF_SPECULAR_TRANSMISSION,     /* R(=T), p[0]=etaA, p[1]=etaB */
+    MI_BXDF_FRESNEL_SPECULAR,          /* R, S(=T), p[0]=etaA, p[1]=etaB */
+    MI_BXDF_MICROFACET_REFLECTION,     /* R, p[0]=alphax, p[1]=alphay, fresnel, p[5]=separableG */
+    MI_BXDF_MICROFACET_TRANSMISSION,   /* R(=T), p[0]=alphax, p[1]=alphay, p[2]=etaA, p[3]=etaB, p[5]=separableG */
+    MI_BXDF_LAMBERTIAN_TRANSMISSION,   /* R(=T) */
+    MI_BXDF_DISNEY_DIFFUSE,            /* R */
+    MI_BXDF_DISNEY_FAKE_SS,            /* R, p[0]=roughness */
+    MI_BXDF_DISNEY_RETRO,              /* R, p[0]=roughness */
+    MI_BXDF_DISNEY_SHEEN,              /* R */
+    MI_BXDF_DISNEY_CLEARCOAT           /* p[0]=weight, p[1]=gloss */
+} mi_bxdf_type;
+
+typedef enum mi_fresnel_type {
+    MI_FRESNEL_NOOP = 0,
+    MI_FRESNEL_DIELECTRIC, /* p[2]=etaI, p[3]=etaT */
+    MI_FRESNEL_DISNEY      /* S=R0, p[2]=metallic, p[3]=eta */
+} mi_fresnel_type;
+
+/* BxDFType bits, src/core/reflection.h:153-161 */
+#define MI_BSDF_REFLECTION 1
+#define MI_BSDF_TRANSMISSION 2
+#define MI_BSDF_DIFFUSE 4
+#define MI_BSDF_GLOSSY 8
+#define MI_BSDF_SPECULAR 16
+#define MI_BSDF_ALL 31
+
+typedef struct mi_bxdf {
+    int32_t type;    /* mi_bxdf_type */
+    int32_t flags;   /* BxDFType bits */
+    int32_t fresnel; /* mi_fresnel_type (reflection lobes) */
+    int32_t pad;
+    float p[8];
+    float R[MI_NSPEC];
+    float S[MI_NSPEC];
+} mi_bxdf;
+
+typedef struct mi_material {
+    int32_t n_bxdfs;
+    float eta; /* BSDF::eta, src/core/reflection.h:189 */
+    int32_t kind; /* informational: 0 matte 1 plastic 2 glass 3 uber 4 disney */
+    int32_t pad;
+    mi_bxdf bxdf[MI_MAX_BXDFS];
+} mi_material;
+
+/* ---- lights */
+typedef enum mi_light_type {
+    MI_LIGHT_DIFFUSE_AREA = 0, /* src/lights/diffuse.cpp */
+    MI_LIGHT_POINT,            /* src/lights/point.cpp */
+    MI_LIGHT_DISTANT           /* src/lights/distant.cpp */
+} mi_light_type;
+
+typedef struct mi_light {
+    int32_t type;
+    int32_t shape;     /* area: >=0 triangle index, <0 ~sphere index */
+    int32_t two_sided;
+    float area;        /* Shape::Area() */
+    float L[MI_NSPEC]; /* Lemit / I / L */
+    float pos[3];      /* point: pLight */
+    float dir[3];      /* distant: wLight (normalised, world) */
+    float world_radius;
+    float world_center[3];
+} mi_light;
+
+/* Light-selection pmf (src/core/lightdistrib.cpp). For UNIFORM / POWER there is
+ * one Distribution1D; for SPATIAL one per voxel, all voxels precomputed by the
+ * host with the reference's 128-point Halton estimator (lightdistrib.cpp:232-300).
+ * Distribution d lives at func[d*n_lights .. ], cdf[d*(n_lights+1) .. ], func_int[d]. */
+typedef enum mi_lightdistrib_type { MI_LD_UNIFORM = 0, MI_LD_POWER, MI_LD_SPATIAL } mi_lightdistrib_type;
+typedef struct mi_lightdistrib {
+    int32_t type;
+    int32_t n_voxels[3]; /* SPATIAL only */
+    uint32_t n_distributions;
+    const float *func;
+    const float *cdf;
+    const float *func_int;
+} mi_lightdistrib;
+
+/* ---- camera (perspective only, src/cameras/perspective.cpp:45-146) */
+typedef struct mi_camera {
+    float raster_to_camera[16];
+    float camera_to_world[16];
+    float lens_radius, focal_distance;
+    float shutter_open, shutter_close;
+} mi_camera;
+
+/* ---- film + reconstruction filter (src/core/film.cpp:50-112, film.h:123-163) */
+typedef struct mi_film {
+    int32_t full_res[2];
+    int32_t cropped_bounds[4]; /* x0,y0,x1,y1 (max exclusive) */
+    int32_t sample_bounds[4];  /* Film::GetSampleBounds() */
+    float filter_radius[2];
+    float filter_table[256];   /* 16x16, Film ctor */
+    float scale;
+    float max_sample_luminance;
+} mi_film;
+
+/* ---- Halton sampler (src/samplers/halton.cpp:65-127) */
+typedef struct mi_sampler {
+    int64_t samples_per_pixel;
+    int32_t base_scales[2], base_exponents[2];
+    int32_t sample_stride;
+    int32_t mult_inverse[2];
+    int32_t sample_at_pixel_center;
+    int32_t n_dims;            /* dimensions with tables below */
+    const int32_t *primes;     /* [n_dims] */
+    const int32_t *prime_sums; /* [n_dims] offset of each base's permutation */
+    const uint16_t *perms;     /* [n_perms] ComputeRadicalInversePermutations prefix */
+    uint32_t n_perms;
+} mi_sampler;
+
+typedef struct mi_integrator {
+    int32_t max_depth;        /* CreatePathIntegrator, src/integrators/path.cpp:193 */
+    float rr_threshold;
+    int32_t pixel_bounds[4];  /* x0,y0,x1,y1 */
+} mi_integrator;
+
+typedef struct mi_scene_desc {
+    uint32_t abi_version; /* MI_ABI_VERSION */
+    uint32_t n_nodes;  const mi_bvh_node *nodes;
+    uint32_t n_prims;  const mi_prim *prims;
+    uint32_t n_tris;   const int32_t *tri_indices; /* 3 per triangle, global vertex ids */
+                       const uint32_t *tri_mesh;   /* mesh id per triangle */
+    uint32_t n_verts;  const float *P;  /* 3 per vertex, world space */
+                       const float *N;  /* 3 per vertex, world space (0 when mesh has none) */
+                       const float *UV; /* 2 per vertex */
+    uint32_t n_meshes; const mi_mesh *meshes;
+    uint32_t n_spheres; const mi_sphere *spheres;
+    uint32_t n_materials; const mi_material *materials;
+    uint32_t n_lights; const mi_light *lights;
+    mi_lightdistrib light_distrib;
+    mi_camera camera;
+    mi_film film;
+    mi_sampler sampler;
+    mi_integrator integrator;
+    float cie_y[MI_NSPEC]; /* SampledSpectrum::Y, for y() guards */
+} mi_scene_desc;
+
+/* Counters with the reference's STAT names (src/core/integrator.cpp:48,
+ * src/core/scene.cpp:40-42, src/integrators/path.cpp:45-46). */
+typedef struct mi_counters {
+    uint64_t camera_rays;
+    uint64_t regular_rays; /* Scene::Intersect calls */
+    uint64_t shadow_rays;  /* Scene::IntersectP calls */
+    uint64_t total_paths;  /* direct-lighting estimates */
+    uint64_t zero_radiance_paths;
+    uint64_t path_length_sum;
+    uint64_t bvh_nodes_visited; /* build's own traversal, for B_ray */
+    uint64_t tri_tests;
+    uint64_t bad_samples;  /* NaN / negative / inf guards, integrator.cpp:295-316 */
+    uint64_t reserved[7];
+} mi_counters;
+
+#define MI_RENDER_FILM_ON_DEVICE 1u /* film_sum / weight_sum are device pointers */
+#define MI_RENDER_ACCUMULATE 2u     /* do not clear the device film first */
+typedef struct mi_render_params {
+    int32_t shard_index, shard_count; /* 16x16 tiles with (tile_id % shard_count == shard_index) */
+    uint32_t flags;
+    uint32_t path_pool;   /* resident path slots; 0 = default */
+    int64_t spp_override; /* 0 = use sampler.samples_per_pixel */
+    void *stream;         /* hipStream_t or NULL */
+} mi_render_params;
+
+typedef struct mi_pt mi_pt;
+
+/* Create a renderer on HIP device `device_ordinal` and upload the scene. */
+int mi_pt_create(const mi_scene_desc *scene, int device_ordinal, mi_pt **out);
+/* Render. film_sum: [H*W*31] floats, pixel-major (pixel p, bin c at p*31+c) over
+ * the cropped pixel bounds = Film::Pixel::L (sum of L*w*filterWeight, NOT
+ * normalised, src/core/film.cpp:124-142); weight_sum: [H*W] = filterWeightSum.
+ * Either may be NULL. Blocks until done. */
+int mi_pt_render(mi_pt *pt, const mi_render_params *params, float *film_sum,
+                 float *weight_sum, mi_counters *counters);
+/* Device pointer of the resident film (layout [H*W][32]: 31 bins + weight) so a
+ * collective can reduce in place; element count returned through n_floats. */
+int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats);
+/* Seconds spent inside kernels of the last mi_pt_render (HIP events on the
+ * render stream) and per-kernel-class breakdown: [0]=total, [1]=generate,
+ * [2]=extend, [3]=shade, [4]=shadow, [5]=mis/finish. */
+int mi_pt_last_timings(mi_pt *pt, double *seconds, int n);
+void mi_pt_destroy(mi_pt *pt);
+const char *mi_pt_last_error(void);
+
+/* ---- Traversal-only entry point (parity of the BVH2 kernel on
+ * recorded rays). rays: n x {o[3], d[3], tMax} floats (7 per ray);
+ * hits: n x {prim (int32 as float bits), t, b0, b1} ; any_hit!=0 -> IntersectP
+ * semantics (prim = 0/-1 only). Host pointers. */
+int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PT_H */

@@ -1,0 +1,258 @@
+// materials.cpp -- compile a material with constant textures into the fixed BxDF
+// list its ComputeScatteringFunctions() would build at every hit. Parameter names,
+// defaults, clamping and lobe ORDER follow the reference (order matters: BSDF::Sample_f
+// picks lobe floor(u*n), src/core/reflection.cpp:714-725).
+#include <cmath>
+#include "scene.h"
+
+namespace mipt {
+namespace {
+
+inline float RoughnessToAlpha(float roughness) {  // src/core/microfacet.h:140-145
+    roughness = std::max(roughness, (float)1e-3);
+    float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
+           0.000640711f * x * x * x * x;
+}
+inline float sqr(float x) { return x * x; }
+
+mi_bxdf MakeBxDF(int type, int flags, const Spectrum &R) {
+    mi_bxdf b{};
+    b.type = type;
+    b.flags = flags;
+    b.fresnel = MI_FRESNEL_NOOP;
+    for (int i = 0; i < MI_NSPEC; ++i) b.R[i] = R.c[i];
+    return b;
+}
+void SetS(mi_bxdf &b, const Spectrum &S) { for (int i = 0; i < MI_NSPEC; ++i) b.S[i] = S.c[i]; }
+
+bool Add(mi_material *m, const mi_bxdf &b, std::vector<std::string> *errs) {
+    if (m->n_bxdfs >= MI_MAX_BXDFS) { errs->push_back("more than 8 BxDFs in a BSDF"); return false; }
+    m->bxdf[m->n_bxdfs++] = b;
+    return true;
+}
+
+mi_bxdf Lambertian(const Spectrum &R) {
+    return MakeBxDF(MI_BXDF_LAMBERTIAN_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_DIFFUSE, R);
+}
+mi_bxdf OrenNayar(const Spectrum &R, float sigma) {  // src/core/reflection.h:414-420
+    mi_bxdf b = MakeBxDF(MI_BXDF_OREN_NAYAR, MI_BSDF_REFLECTION | MI_BSDF_DIFFUSE, R);
+    sigma = Radians(sigma);
+    float sigma2 = sigma * sigma;
+    b.p[0] = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+    b.p[1] = 0.45f * sigma2 / (sigma2 + 0.09f);
+    return b;
+}
+mi_bxdf MicrofacetReflectionDielectric(const Spectrum &R, float ax, float ay, float etaI, float etaT) {
+    mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, R);
+    b.fresnel = MI_FRESNEL_DIELECTRIC;
+    b.p[0] = ax; b.p[1] = ay; b.p[2] = etaI; b.p[3] = etaT;
+    return b;
+}
+mi_bxdf SpecularReflectionDielectric(const Spectrum &R, float etaI, float etaT) {
+    mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_SPECULAR, R);
+    b.fresnel = MI_FRESNEL_DIELECTRIC;
+    b.p[2] = etaI; b.p[3] = etaT;
+    return b;
+}
+mi_bxdf SpecularTransmission(const Spectrum &T, float etaA, float etaB) {
+    mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_SPECULAR, T);
+    b.p[0] = etaA; b.p[1] = etaB;
+    return b;
+}
+mi_bxdf MicrofacetTransmission(const Spectrum &T, float ax, float ay, float etaA, float etaB, bool sepG) {
+    mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_GLOSSY, T);
+    b.p[0] = ax; b.p[1] = ay; b.p[2] = etaA; b.p[3] = etaB; b.p[5] = sepG ? 1.f : 0.f;
+    return b;
+}
+
+}  // namespace
+
+bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_material *m,
+                     std::vector<std::string> *warnings, std::vector<std::string> *errs) {
+    *m = mi_material{};
+    m->eta = 1.f;
+    float bump;
+    if (mp.GetFloatOrNull("bumpmap", &bump))
+        warnings->push_back("bumpmap ignored: Material::Bump is outside the hot-path scope (SURVEY 8f)");
+
+    if (type == "matte") {  // src/materials/matte.cpp:45-62,64-71
+        m->kind = 0;
+        Spectrum r = mp.GetSpectrum("Kd", Spectrum(0.5f)).Clamp();
+        float sig = Clamp(mp.GetFloat("sigma", 0.f), 0, 90);
+        if (!r.IsBlack()) {
+            if (sig == 0) Add(m, Lambertian(r), errs);
+            else Add(m, OrenNayar(r, sig), errs);
+        }
+        return true;
+    }
+    if (type == "plastic") {  // src/materials/plastic.cpp:45-70,72-84
+        m->kind = 1;
+        Spectrum kd = mp.GetSpectrum("Kd", Spectrum(0.25f)).Clamp();
+        Spectrum ks = mp.GetSpectrum("Ks", Spectrum(0.25f)).Clamp();
+        float rough = mp.GetFloat("roughness", .1f);
+        bool remap = mp.FindBool("remaproughness", true);
+        if (!kd.IsBlack()) Add(m, Lambertian(kd), errs);
+        if (!ks.IsBlack()) {
+            if (remap) rough = RoughnessToAlpha(rough);
+            // FresnelDielectric(1.5f, 1.f): plastic.cpp:59
+            Add(m, MicrofacetReflectionDielectric(ks, rough, rough, 1.5f, 1.f), errs);
+        }
+        return true;
+    }
+    if (type == "mirror") {  // src/materials/mirror.cpp: SpecularReflection(R, FresnelNoOp)
+        m->kind = 5;
+        Spectrum R = mp.GetSpectrum("Kr", Spectrum(0.9f)).Clamp();
+        if (!R.IsBlack()) {
+            mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_SPECULAR, R);
+            b.fresnel = MI_FRESNEL_NOOP;
+            Add(m, b, errs);
+        }
+        return true;
+    }
+    if (type == "glass") {  // src/materials/glass.cpp:45-92,94-111 (allowMultipleLobes = true)
+        m->kind = 2;
+        Spectrum R = mp.GetSpectrum("Kr", Spectrum(1.f)).Clamp();
+        Spectrum T = mp.GetSpectrum("Kt", Spectrum(1.f)).Clamp();
+        float eta;
+        if (!mp.GetFloatOrNull("eta", &eta)) eta = mp.GetFloat("index", 1.5f);
+        float urough = mp.GetFloat("uroughness", 0.f);
+        float vrough = mp.GetFloat("vroughness", 0.f);
+        bool remap = mp.FindBool("remaproughness", true);
+        m->eta = eta;
+        if (R.IsBlack() && T.IsBlack()) return true;
+        bool isSpecular = urough == 0 && vrough == 0;
+        if (isSpecular) {
+            mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_SPECULAR,
+                                 MI_BSDF_REFLECTION | MI_BSDF_TRANSMISSION | MI_BSDF_SPECULAR, R);
+            SetS(b, T);
+            b.p[0] = 1.f; b.p[1] = eta;
+            Add(m, b, errs);
+        } else {
+            if (remap) { urough = RoughnessToAlpha(urough); vrough = RoughnessToAlpha(vrough); }
+            if (!R.IsBlack()) Add(m, MicrofacetReflectionDielectric(R, urough, vrough, 1.f, eta), errs);
+            if (!T.IsBlack()) Add(m, MicrofacetTransmission(T, urough, vrough, 1.f, eta, false), errs);
+        }
+        return true;
+    }
+    if (type == "uber") {  // src/materials/uber.cpp:45-101,103-128
+        m->kind = 3;
+        Spectrum Kd = mp.GetSpectrum("Kd", Spectrum(0.25f));
+        Spectrum Ks = mp.GetSpectrum("Ks", Spectrum(0.25f));
+        Spectrum Kr = mp.GetSpectrum("Kr", Spectrum(0.f));
+        Spectrum Kt = mp.GetSpectrum("Kt", Spectrum(0.f));
+        float roughness = mp.GetFloat("roughness", .1f);
+        float ur, vr;
+        bool hasU = mp.GetFloatOrNull("uroughness", &ur);
+        bool hasV = mp.GetFloatOrNull("vroughness", &vr);
+        float e;
+        if (!mp.GetFloatOrNull("eta", &e)) e = mp.GetFloat("index", 1.5f);
+        Spectrum opacity = mp.GetSpectrum("opacity", Spectrum(1.f));
+        bool remap = mp.FindBool("remaproughness", true);
+
+        Spectrum op = opacity.Clamp();
+        Spectrum t = (-op + Spectrum(1.f)).Clamp();
+        if (!t.IsBlack()) {
+            m->eta = 1.f;
+            Add(m, SpecularTransmission(t, 1.f, 1.f), errs);
+        } else
+            m->eta = e;
+        Spectrum kd = op * Kd.Clamp();
+        if (!kd.IsBlack()) Add(m, Lambertian(kd), errs);
+        Spectrum ks = op * Ks.Clamp();
+        if (!ks.IsBlack()) {
+            float roughu = hasU ? ur : roughness;
+            float roughv = hasV ? vr : roughu;
+            if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            Add(m, MicrofacetReflectionDielectric(ks, roughu, roughv, 1.f, e), errs);
+        }
+        Spectrum kr = op * Kr.Clamp();
+        if (!kr.IsBlack()) Add(m, SpecularReflectionDielectric(kr, 1.f, e), errs);
+        Spectrum kt = op * Kt.Clamp();
+        if (!kt.IsBlack()) Add(m, SpecularTransmission(kt, 1.f, e), errs);
+        return true;
+    }
+    if (type == "disney") {  // src/materials/disney.cpp:474-587,589-624
+        m->kind = 4;
+        Spectrum c = mp.GetSpectrum("color", Spectrum(0.5f)).Clamp();
+        float metallicWeight = mp.GetFloat("metallic", 0.f);
+        float e = mp.GetFloat("eta", 1.5f);
+        float rough = mp.GetFloat("roughness", .5f);
+        float specTint = mp.GetFloat("speculartint", 0.f);
+        float anisotropic = mp.GetFloat("anisotropic", 0.f);
+        float sheenWeight = mp.GetFloat("sheen", 0.f);
+        float stint = mp.GetFloat("sheentint", .5f);
+        float cc = mp.GetFloat("clearcoat", 0.f);
+        float ccGloss = mp.GetFloat("clearcoatgloss", 1.f);
+        float strans = mp.GetFloat("spectrans", 0.f);
+        Spectrum sd = mp.GetSpectrum("scatterdistance", Spectrum(0.));
+        bool thin = mp.FindBool("thin", false);
+        float flat = mp.GetFloat("flatness", 0.f);
+        float dtIn = mp.GetFloat("difftrans", 1.f);
+
+        float diffuseWeight = (1 - metallicWeight) * (1 - strans);
+        float dt = dtIn / 2;
+        float lum = c.y();
+        Spectrum Ctint = lum > 0 ? (c / lum) : Spectrum(1.);
+        Spectrum Csheen;
+        if (sheenWeight > 0) Csheen = Lerp(stint, Spectrum(1.), Ctint);
+        const int diffFlags = MI_BSDF_REFLECTION | MI_BSDF_DIFFUSE;
+        if (diffuseWeight > 0) {
+            if (thin) {
+                Add(m, MakeBxDF(MI_BXDF_DISNEY_DIFFUSE, diffFlags, diffuseWeight * (1 - flat) * (1 - dt) * c), errs);
+                mi_bxdf ss = MakeBxDF(MI_BXDF_DISNEY_FAKE_SS, diffFlags, diffuseWeight * flat * (1 - dt) * c);
+                ss.p[0] = rough;
+                Add(m, ss, errs);
+            } else {
+                if (sd.IsBlack())
+                    Add(m, MakeBxDF(MI_BXDF_DISNEY_DIFFUSE, diffFlags, diffuseWeight * c), errs);
+                else {
+                    errs->push_back("disney \"scatterdistance\" (BSSRDF) is outside the hot-path scope (SURVEY 2 row 6)");
+                    return false;
+                }
+            }
+            mi_bxdf retro = MakeBxDF(MI_BXDF_DISNEY_RETRO, diffFlags, diffuseWeight * c);
+            retro.p[0] = rough;
+            Add(m, retro, errs);
+            if (sheenWeight > 0)
+                Add(m, MakeBxDF(MI_BXDF_DISNEY_SHEEN, diffFlags, diffuseWeight * sheenWeight * Csheen), errs);
+        }
+        // "1 - anisotropic * .9" is evaluated in double, then sqrt(double) -> Float
+        float aspect = (float)std::sqrt(1 - (double)anisotropic * .9);
+        float ax = std::max(float(.001), sqr(rough) / aspect);
+        float ay = std::max(float(.001), sqr(rough) * aspect);
+        float r0 = sqr(e - 1) / sqr(e + 1);  // SchlickR0FromEta
+        Spectrum Cspec0 = Lerp(metallicWeight, r0 * Lerp(specTint, Spectrum(1.), Ctint), c);
+        {
+            mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, c);
+            b.fresnel = MI_FRESNEL_DISNEY;
+            SetS(b, Cspec0);
+            b.p[0] = ax; b.p[1] = ay; b.p[2] = metallicWeight; b.p[3] = e; b.p[5] = 1.f;
+            Add(m, b, errs);
+        }
+        if (cc > 0) {
+            mi_bxdf b = MakeBxDF(MI_BXDF_DISNEY_CLEARCOAT, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, Spectrum(0.f));
+            b.p[0] = cc;
+            // Lerp(gloss, .1, .001): double literals converted to Float arguments
+            b.p[1] = Lerp(ccGloss, (float).1, (float).001);
+            Add(m, b, errs);
+        }
+        if (strans > 0) {
+            Spectrum T = strans * Sqrt(c);
+            if (thin) {
+                float rscaled = (0.65f * e - 0.35f) * rough;
+                float ax2 = std::max(float(.001), sqr(rscaled) / aspect);
+                float ay2 = std::max(float(.001), sqr(rscaled) * aspect);
+                Add(m, MicrofacetTransmission(T, ax2, ay2, 1.f, e, false), errs);
+            } else
+                Add(m, MicrofacetTransmission(T, ax, ay, 1.f, e, true), errs);
+        }
+        if (thin)
+            Add(m, MakeBxDF(MI_BXDF_LAMBERTIAN_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_DIFFUSE, dt * c), errs);
+        return errs->empty() || m->n_bxdfs <= MI_MAX_BXDFS;
+    }
+    errs->push_back("material \"" + type + "\" is outside the PathIntegrator hot-path scope (SURVEY 2 row 18)");
+    return false;
+}
+
+}  // namespace mipt

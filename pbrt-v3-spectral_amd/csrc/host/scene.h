@@ -1,0 +1,88 @@
+// scene.h -- the host front end's flat scene: owning storage behind the POD
+// mi_scene_desc that crosses the C ABI (include/mi_pt.h). Produced by the .pbrt
+// front end (api.cpp) the way pbrtWorldEnd() produces Scene + Integrator in the
+// reference (src/core/api.cpp:1617-1737), but as flat arrays because the
+// reference's Scene/BVHAccel internals are private.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../../include/mi_pt.h"
+#include "paramset.h"
+
+namespace mipt {
+
+struct SceneStats {
+    int nTriangles = 0, nSpheres = 0, nMeshes = 0;
+    int interiorNodes = 0, leafNodes = 0;
+    int nLights = 0, nMaterials = 0;
+};
+
+struct HostScene {
+    // geometry
+    std::vector<mi_bvh_node> nodes;
+    std::vector<mi_prim> prims;  // BVH leaf order
+    std::vector<int32_t> triIndices;
+    std::vector<uint32_t> triMesh;
+    std::vector<float> P, N, UV;
+    std::vector<mi_mesh> meshes;
+    std::vector<mi_sphere> spheres;
+    std::vector<mi_material> materials;
+    std::vector<mi_light> lights;
+    // light distribution
+    std::vector<float> ldFunc, ldCdf, ldFuncInt;
+    // sampler tables
+    std::vector<int32_t> primes, primeSums;
+    std::vector<uint16_t> perms;
+    // output
+    std::string filmFilename = "pbrt.exr";
+    bool spectralFlag = true;
+    std::string integratorName = "path", samplerName = "halton", lightStrategy = "spatial";
+    std::vector<std::string> warnings, errors;
+    SceneStats stats;
+    mi_scene_desc desc{};
+
+    void Finalize();  // point desc at the vectors
+};
+
+// ---- builders (each cites the reference routine it restates)
+// Loop subdivision to the limit surface, src/shapes/loopsubdiv.cpp:149-400.
+bool LoopSubdivide(int nLevels, const std::vector<int> &indices, const std::vector<Vec3> &P,
+                   std::vector<int> *outIndices, std::vector<Vec3> *outP, std::vector<Vec3> *outN,
+                   std::string *err);
+
+// SAH BVH2 build + depth-first flatten, src/accelerators/bvh.cpp:183-402,640-658.
+struct BuildPrim { Bounds3 bounds; };
+enum class SplitMethod { SAH, Middle, EqualCounts };
+void BuildBVH(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, SplitMethod method,
+              std::vector<mi_bvh_node> *nodes, std::vector<int> *orderedPrims, int *interior,
+              int *leaves);
+
+// Halton tables, src/core/lowdiscrepancy.cpp:2490-2504 (+ rng.h PCG32, sampling.h Shuffle).
+void ComputeHaltonTables(int nDims, std::vector<int32_t> *primes, std::vector<int32_t> *primeSums,
+                         std::vector<uint16_t> *perms);
+float RadicalInverseHost(int baseIndex, uint64_t a);  // unscrambled, lowdiscrepancy.cpp:389-424
+
+// Light-selection distributions, src/core/lightdistrib.cpp:48-300.
+void BuildLightDistribution(HostScene *scene, const std::string &strategy);
+
+// Material compilation (constant textures -> fixed BxDF list),
+// src/materials/{matte,plastic,glass,uber,disney,mirror}.cpp.
+// Returns false (and appends to errs) for materials this path does not cover.
+bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_material *out,
+                     std::vector<std::string> *warnings, std::vector<std::string> *errs);
+
+// .pbrt front end. Overrides < 0 / empty leave the file's values.
+struct LoadOverrides {
+    int spp = -1, xres = -1, yres = -1, maxDepth = -1;
+    float crop[4] = {-1, -1, -1, -1};
+    std::string lightStrategy;
+};
+HostScene *LoadSceneFile(const std::string &path, const LoadOverrides &ov, std::string *err);
+HostScene *LoadSceneString(const std::string &text, const std::string &baseDir, const LoadOverrides &ov,
+                           std::string *err);
+
+// Spectral film writer, src/core/film.cpp:226-308 (".dat": text header + 31 planes of float64).
+bool WriteSpectralDat(const std::string &filename, int w, int h, const float *filmSum, float scale,
+                      std::string *err);
+
+}  // namespace mipt

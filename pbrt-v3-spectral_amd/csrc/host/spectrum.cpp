@@ -1,0 +1,75 @@
+// spectrum.cpp -- RGB -> 31-bin SPD conversion (Smits-style basis) and y().
+// Basis data: spectral_basis_31.inc (derived, see tools/make_spectral_basis.py).
+// Branch structure follows SampledSpectrum::FromRGB, src/core/spectrum.cpp:98-180.
+#include "spectrum.h"
+
+namespace mipt {
+namespace {
+#include "spectral_basis_31.inc"
+inline Spectrum S(const float *v) { return Spectrum::FromArray(v); }
+inline void XYZToRGB(const float xyz[3], float rgb[3]) {  // spectrum.h:56-60
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+}  // namespace
+
+const float *Spectrum::CIE_Y() { return kCIE_Y; }
+
+float Spectrum::y() const {
+    float yy = 0.f;
+    for (int i = 0; i < kNSpec; ++i) yy += kCIE_Y[i] * c[i];
+    yy = (yy < 0) ? 0 : yy;
+    return yy * float(kLambdaEnd - kLambdaStart) / float(kCIE_Y_integral * kNSpec);
+}
+
+Spectrum Spectrum::FromRGB(const float rgb[3], SpectrumType type) {
+    Spectrum r;
+    const bool refl = (type == SpectrumType::Reflectance);
+    const Spectrum white = S(refl ? kRGBRefl2SpectWhite : kRGBIllum2SpectWhite);
+    const Spectrum cyan = S(refl ? kRGBRefl2SpectCyan : kRGBIllum2SpectCyan);
+    const Spectrum magenta = S(refl ? kRGBRefl2SpectMagenta : kRGBIllum2SpectMagenta);
+    const Spectrum yellow = S(refl ? kRGBRefl2SpectYellow : kRGBIllum2SpectYellow);
+    const Spectrum red = S(refl ? kRGBRefl2SpectRed : kRGBIllum2SpectRed);
+    const Spectrum green = S(refl ? kRGBRefl2SpectGreen : kRGBIllum2SpectGreen);
+    const Spectrum blue = S(refl ? kRGBRefl2SpectBlue : kRGBIllum2SpectBlue);
+    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
+        r += rgb[0] * white;
+        if (rgb[1] <= rgb[2]) {
+            r += (rgb[1] - rgb[0]) * cyan;
+            r += (rgb[2] - rgb[1]) * blue;
+        } else {
+            r += (rgb[2] - rgb[0]) * cyan;
+            r += (rgb[1] - rgb[2]) * green;
+        }
+    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
+        r += rgb[1] * white;
+        if (rgb[0] <= rgb[2]) {
+            r += (rgb[0] - rgb[1]) * magenta;
+            r += (rgb[2] - rgb[0]) * blue;
+        } else {
+            r += (rgb[2] - rgb[1]) * magenta;
+            r += (rgb[0] - rgb[2]) * red;
+        }
+    } else {
+        r += rgb[2] * white;
+        if (rgb[0] <= rgb[1]) {
+            r += (rgb[0] - rgb[2]) * yellow;
+            r += (rgb[1] - rgb[0]) * green;
+        } else {
+            r += (rgb[1] - rgb[2]) * yellow;
+            r += (rgb[0] - rgb[1]) * red;
+        }
+    }
+    // "r *= .94" converts the double literal to Float first (operator*=(Float))
+    r *= refl ? (float).94 : .86445f;
+    return r.Clamp();
+}
+
+Spectrum Spectrum::FromXYZ(const float xyz[3], SpectrumType type) {
+    float rgb[3];
+    XYZToRGB(xyz, rgb);
+    return FromRGB(rgb, type);
+}
+
+}  // namespace mipt
