@@ -1,0 +1,330 @@
+"""pbrt-v3-spectral_amd -- MI355X-native spectral PathIntegrator hot path.
+
+Python here is plumbing only (ctypes over the two C-ABI libraries):
+
+* ``libmipt_host.so``  -- .pbrt front end -> flat ``mi_scene_desc`` (include/mi_scene.h)
+* ``libmipt_hip.so``   -- hand-written HIP wavefront path tracer (include/mi_pt.h)
+
+The host-side mirror of the reference's integrator surface is
+:class:`PathIntegrator` with ``Render(scene)`` (reference:
+``SamplerIntegrator::Render``, src/core/integrator.cpp:228-342, created by
+``CreatePathIntegrator``, src/integrators/path.cpp:190-213).  There is no CPU
+fallback: if the HIP library or a GPU is missing, ``PathIntegrator`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NSPEC = 31
+MAX_BXDFS = 8
+
+
+# ----------------------------------------------------------------------------
+# ctypes mirrors of include/mi_pt.h
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32),
+                ("n_prims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class Prim(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("material", C.c_int32), ("area_light", C.c_int32), ("pad", C.c_int32)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("first_vertex", C.c_uint32), ("n_vertices", C.c_uint32),
+                ("first_tri", C.c_uint32), ("n_tris", C.c_uint32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("o2w", C.c_float * 16), ("w2o", C.c_float * 16), ("radius", C.c_float), ("z_min", C.c_float),
+                ("z_max", C.c_float), ("theta_min", C.c_float), ("theta_max", C.c_float), ("phi_max", C.c_float),
+                ("reverse_orientation", C.c_int32), ("swaps_handedness", C.c_int32)]
+
+
+class Bxdf(C.Structure):
+    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("fresnel", C.c_int32), ("pad", C.c_int32),
+                ("p", C.c_float * 8), ("R", C.c_float * NSPEC), ("S", C.c_float * NSPEC)]
+
+
+class Material(C.Structure):
+    _fields_ = [("n_bxdfs", C.c_int32), ("eta", C.c_float), ("kind", C.c_int32), ("pad", C.c_int32),
+                ("bxdf", Bxdf * MAX_BXDFS)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("shape", C.c_int32), ("two_sided", C.c_int32), ("area", C.c_float),
+                ("L", C.c_float * NSPEC), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
+                ("world_radius", C.c_float), ("world_center", C.c_float * 3)]
+
+
+class LightDistrib(C.Structure):
+    _fields_ = [("type", C.c_int32), ("n_voxels", C.c_int32 * 3), ("n_distributions", C.c_uint32),
+                ("func", C.POINTER(C.c_float)), ("cdf", C.POINTER(C.c_float)), ("func_int", C.POINTER(C.c_float))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float), ("shutter_open", C.c_float),
+                ("shutter_close", C.c_float)]
+
+
+class Film(C.Structure):
+    _fields_ = [("full_res", C.c_int32 * 2), ("cropped_bounds", C.c_int32 * 4), ("sample_bounds", C.c_int32 * 4),
+                ("filter_radius", C.c_float * 2), ("filter_table", C.c_float * 256), ("scale", C.c_float),
+                ("max_sample_luminance", C.c_float)]
+
+
+class Sampler(C.Structure):
+    _fields_ = [("samples_per_pixel", C.c_int64), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
+                ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
+                ("n_dims", C.c_int32), ("primes", C.POINTER(C.c_int32)), ("prime_sums", C.POINTER(C.c_int32)),
+                ("perms", C.POINTER(C.c_uint16)), ("n_perms", C.c_uint32)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("nodes", C.POINTER(BvhNode)),
+                ("n_prims", C.c_uint32), ("prims", C.POINTER(Prim)),
+                ("n_tris", C.c_uint32), ("tri_indices", C.POINTER(C.c_int32)), ("tri_mesh", C.POINTER(C.c_uint32)),
+                ("n_verts", C.c_uint32), ("P", C.POINTER(C.c_float)), ("N", C.POINTER(C.c_float)),
+                ("UV", C.POINTER(C.c_float)),
+                ("n_meshes", C.c_uint32), ("meshes", C.POINTER(Mesh)),
+                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
+                ("light_distrib", LightDistrib), ("camera", Camera), ("film", Film), ("sampler", Sampler),
+                ("integrator", Integrator), ("cie_y", C.c_float * NSPEC)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("regular_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("total_paths", C.c_uint64), ("zero_radiance_paths", C.c_uint64), ("path_length_sum", C.c_uint64),
+                ("bvh_nodes_visited", C.c_uint64), ("tri_tests", C.c_uint64), ("bad_samples", C.c_uint64),
+                ("reserved", C.c_uint64 * 7)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("shard_index", C.c_int32), ("shard_count", C.c_int32), ("flags", C.c_uint32),
+                ("path_pool", C.c_uint32), ("spp_override", C.c_int64), ("stream", C.c_void_p)]
+
+
+class SceneOverrides(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("xres", C.c_int32), ("yres", C.c_int32), ("max_depth", C.c_int32),
+                ("crop", C.c_float * 4), ("light_strategy", C.c_char_p)]
+
+
+class SceneStats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_triangles", "n_spheres", "n_meshes", "interior_nodes", "leaf_nodes",
+                                          "n_lights", "n_materials", "n_warnings", "n_errors")]
+
+
+RENDER_FILM_ON_DEVICE = 1
+RENDER_ACCUMULATE = 2
+
+HOST_LIB = os.path.join(_HERE, "libmipt_host.so")
+HIP_LIB = os.path.join(_HERE, "libmipt_hip.so")
+
+_host = None
+_hip = None
+
+
+def host_lib():
+    """The .pbrt front-end library (pure host C++)."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % HOST_LIB)
+        lib = C.CDLL(HOST_LIB)
+        lib.mi_scene_load_file.argtypes = [C.c_char_p, C.POINTER(SceneOverrides), C.POINTER(C.c_void_p)]
+        lib.mi_scene_load_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SceneOverrides), C.POINTER(C.c_void_p)]
+        lib.mi_scene_get_desc.argtypes = [C.c_void_p]
+        lib.mi_scene_get_desc.restype = C.POINTER(SceneDesc)
+        lib.mi_scene_get_stats.argtypes = [C.c_void_p, C.POINTER(SceneStats)]
+        lib.mi_scene_message.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.mi_scene_message.restype = C.c_char_p
+        lib.mi_scene_film_filename.argtypes = [C.c_void_p]
+        lib.mi_scene_film_filename.restype = C.c_char_p
+        lib.mi_scene_free.argtypes = [C.c_void_p]
+        lib.mi_scene_last_error.restype = C.c_char_p
+        lib.mi_film_write_dat.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float]
+        lib.mi_film_read_dat.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                         C.c_uint64]
+        lib.mi_integrator_render.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(Counters)]
+        _host = lib
+    return _host
+
+
+def hip_lib():
+    """The HIP path (hand-written gfx950 kernels). Raises if it is not built / loadable."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError("HIP extension %s is missing; the product path has no CPU fallback" % HIP_LIB)
+        lib = C.CDLL(HIP_LIB)
+        lib.mi_pt_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        lib.mi_pt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(Counters)]
+        lib.mi_pt_device_film.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        lib.mi_pt_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        lib.mi_pt_destroy.argtypes = [C.c_void_p]
+        lib.mi_pt_last_error.restype = C.c_char_p
+        lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+        _hip = lib
+    return _hip
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Scene:
+    """A parsed .pbrt scene flattened to ``mi_scene_desc`` (reference: pbrtParseFile +
+    pbrtWorldEnd up to, not including, ``integrator->Render``; src/core/api.cpp:1617-1707)."""
+
+    def __init__(self, path=None, text=None, base_dir=None, spp=-1, xres=-1, yres=-1, max_depth=-1, crop=None,
+                 light_strategy=None):
+        lib = host_lib()
+        ov = SceneOverrides(spp, xres, yres, max_depth, (C.c_float * 4)(*(crop or (-1, -1, -1, -1))),
+                            light_strategy.encode() if light_strategy else None)
+        h = C.c_void_p()
+        if path is not None:
+            rc = lib.mi_scene_load_file(os.fsencode(path), C.byref(ov), C.byref(h))
+        else:
+            rc = lib.mi_scene_load_string(text.encode(), os.fsencode(base_dir or "."), C.byref(ov), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("scene load failed: %s" % lib.mi_scene_last_error().decode())
+        self._h = h
+        self.desc_ptr = lib.mi_scene_get_desc(h)
+        self.desc = self.desc_ptr.contents
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host_lib().mi_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stats(self):
+        st = SceneStats()
+        host_lib().mi_scene_get_stats(self._h, C.byref(st))
+        return {n: getattr(st, n) for n, _ in SceneStats._fields_}
+
+    def messages(self, kind):
+        out, i = [], 0
+        while True:
+            m = host_lib().mi_scene_message(self._h, kind, i)
+            if m is None:
+                return out
+            out.append(m.decode())
+            i += 1
+
+    warnings = property(lambda self: self.messages(0))
+    errors = property(lambda self: self.messages(1))
+
+    @property
+    def film_filename(self):
+        return host_lib().mi_scene_film_filename(self._h).decode()
+
+    @property
+    def film_size(self):
+        cb = self.desc.film.cropped_bounds
+        return cb[2] - cb[0], cb[3] - cb[1]
+
+    @property
+    def spp(self):
+        return int(self.desc.sampler.samples_per_pixel)
+
+
+class PathIntegrator:
+    """Host mirror of ``PathIntegrator`` for ``Integrator "path"``: ``Render(scene)`` runs
+    the HIP wavefront pipeline through the C ABI and returns the spectral film sums."""
+
+    def __init__(self, scene, device=0):
+        lib = hip_lib()
+        self.scene = scene
+        h = C.c_void_p()
+        rc = lib.mi_pt_create(scene.desc_ptr, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("mi_pt_create failed (%d): %s" % (rc, lib.mi_pt_last_error().decode()))
+        self._h = h
+        self.counters = Counters()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            hip_lib().mi_pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Render(self, shard_index=0, shard_count=1, spp=0, path_pool=0, download=True, accumulate=False):
+        w, h = self.scene.film_size
+        film = np.zeros((h, w, NSPEC), np.float32) if download else None
+        weight = np.zeros((h, w), np.float32) if download else None
+        rp = RenderParams(shard_index, shard_count, RENDER_ACCUMULATE if accumulate else 0, path_pool, spp, None)
+        rc = hip_lib().mi_pt_render(self._h, C.byref(rp), _fptr(film) if download else None,
+                                    _fptr(weight) if download else None, C.byref(self.counters))
+        if rc != 0:
+            raise RuntimeError("mi_pt_render failed (%d): %s" % (rc, hip_lib().mi_pt_last_error().decode()))
+        return film, weight
+
+    def timings(self):
+        t = (C.c_double * 8)()
+        hip_lib().mi_pt_last_timings(self._h, t, 8)
+        return list(t)
+
+    def device_film(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        hip_lib().mi_pt_device_film(self._h, C.byref(p), C.byref(n))
+        return p.value, int(n.value)
+
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        hits = np.zeros((n, 4), np.float32)
+        rc = hip_lib().mi_pt_trace(self._h, _fptr(rays), n, 1 if any_hit else 0, _fptr(hits))
+        if rc != 0:
+            raise RuntimeError("mi_pt_trace failed: %s" % hip_lib().mi_pt_last_error().decode())
+        return hits
+
+
+def CreatePathIntegrator(scene, device=0):
+    """Factory named after the reference's (src/integrators/path.h:69-71)."""
+    return PathIntegrator(scene, device)
+
+
+def write_dat(filename, film, scale=1.0):
+    film = np.ascontiguousarray(film, np.float32)
+    h, w, _ = film.shape
+    rc = host_lib().mi_film_write_dat(os.fsencode(filename), w, h, _fptr(film), scale)
+    if rc != 0:
+        raise RuntimeError(host_lib().mi_scene_last_error().decode())
+
+
+def read_dat(filename):
+    w, h = C.c_int(), C.c_int()
+    lib = host_lib()
+    if lib.mi_film_read_dat(os.fsencode(filename), C.byref(w), C.byref(h), None, 0) != 0:
+        raise RuntimeError(lib.mi_scene_last_error().decode())
+    out = np.zeros((h.value, w.value, NSPEC), np.float32)
+    if lib.mi_film_read_dat(os.fsencode(filename), C.byref(w), C.byref(h), _fptr(out), out.size) != 0:
+        raise RuntimeError(lib.mi_scene_last_error().decode())
+    return out

@@ -1,0 +1,75 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_pt.so). TEST INFRASTRUCTURE:
+imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import pbrt_v3_spectral_amd as pt
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB = os.path.join(_ROOT, "oracle", "liboracle_pt.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            raise RuntimeError("oracle not built: make -C oracle")
+        l = C.CDLL(ORACLE_LIB)
+        D = C.POINTER(pt.SceneDesc)
+        F = C.POINTER(C.c_float)
+        l.oracle_render.argtypes = [D, C.c_int, C.c_int, C.c_int, C.c_int64, F, F, C.POINTER(pt.Counters)]
+        l.oracle_render.restype = C.c_double
+        l.oracle_li.argtypes = [D, C.POINTER(C.c_int32), C.c_int, F, C.POINTER(pt.Counters)]
+        l.oracle_camera_rays.argtypes = [D, C.POINTER(C.c_int32), C.c_int, F]
+        l.oracle_trace.argtypes = [D, F, C.c_uint32, C.c_int, F, C.POINTER(pt.Counters)]
+        l.oracle_radical_inverse.argtypes = [D, C.c_int, C.c_uint64]
+        l.oracle_radical_inverse.restype = C.c_float
+        l.oracle_scrambled_radical_inverse.argtypes = [D, C.c_int, C.c_uint64]
+        l.oracle_scrambled_radical_inverse.restype = C.c_float
+        l.oracle_sample_dimension.argtypes = [D, C.c_int, C.c_int, C.c_int64, C.c_int]
+        l.oracle_sample_dimension.restype = C.c_float
+        l.oracle_tri_test.argtypes = [F, F, F]
+        l.oracle_bsdf.argtypes = [D, C.c_int, C.c_int, F, F, F, C.c_int, F]
+        l.oracle_light_pmf.argtypes = [D, F, F]
+        _lib = l
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def render(scene, n_threads=None, shard_index=0, shard_count=1, max_samples=-1):
+    w, h = scene.film_size
+    film = np.zeros((h, w, pt.NSPEC), np.float32)
+    weight = np.zeros((h, w), np.float32)
+    c = pt.Counters()
+    nt = n_threads or os.cpu_count() or 1
+    secs = lib().oracle_render(scene.desc_ptr, nt, shard_index, shard_count, max_samples, _f(film), _f(weight), C.byref(c))
+    return film, weight, c, secs
+
+
+def li(scene, samples):
+    s = np.ascontiguousarray(samples, np.int32)
+    out = np.zeros((len(s), pt.NSPEC), np.float32)
+    c = pt.Counters()
+    lib().oracle_li(scene.desc_ptr, s.ctypes.data_as(C.POINTER(C.c_int32)), len(s), _f(out), C.byref(c))
+    return out, c
+
+
+def camera_rays(scene, samples):
+    s = np.ascontiguousarray(samples, np.int32)
+    out = np.zeros((len(s), 7), np.float32)
+    lib().oracle_camera_rays(scene.desc_ptr, s.ctypes.data_as(C.POINTER(C.c_int32)), len(s), _f(out))
+    return out
+
+
+def trace(scene, rays, any_hit=False):
+    rays = np.ascontiguousarray(rays, np.float32)
+    hits = np.zeros((len(rays), 4), np.float32)
+    c = pt.Counters()
+    lib().oracle_trace(scene.desc_ptr, _f(rays), len(rays), 1 if any_hit else 0, _f(hits), C.byref(c))
+    return hits, c
