@@ -6,7 +6,7 @@ HOSTSRC  := $(filter-out $(PKG)/csrc/host/main.cpp,$(HOSTSRC))
 CXX      ?= g++
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude
-HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Iinclude -Wno-unused-result
+HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Iinclude -Wno-unused-result -Wno-unused-value
 
 all: host hip cli
 

@@ -1,0 +1,518 @@
+// d_bsdf.h -- device BSDF over the compiled lobe list (mi_material in HBM).
+//
+// A BSDF value is a 31-bin spectrum; to keep VGPR pressure flat the kernels never
+// hold one. Each lobe evaluation is reduced to a few scalars (LobeEval: how to get
+// f_lobe[bin] from the lobe's reflectance R[bin]) in a scalar phase, and the
+// spectral phase streams bins: f[bin] = sum over lobes. The per-bin operation
+// chains reproduce the reference's operator order so values match its rounding:
+//   BSDF::f / Sample_f / Pdf      src/core/reflection.cpp:670-785
+//   BxDFs, Fresnel                src/core/reflection.cpp:47-511, reflection.h:50-127
+//   Trowbridge-Reitz              src/core/microfacet.cpp:165-184,238-344
+//   Disney lobes                  src/materials/disney.cpp:61-356
+#pragma once
+#include "d_scene.h"
+
+namespace dpt {
+
+DEV float CosTheta(const V3 &w) { return w.z; }
+DEV float Cos2Theta(const V3 &w) { return w.z * w.z; }
+DEV float AbsCosTheta(const V3 &w) { return absf(w.z); }
+DEV float Sin2Theta(const V3 &w) { return maxf(0.f, 1.f - Cos2Theta(w)); }
+DEV float SinTheta(const V3 &w) { return __builtin_sqrtf(Sin2Theta(w)); }
+DEV float TanTheta(const V3 &w) { return SinTheta(w) / CosTheta(w); }
+DEV float Tan2Theta(const V3 &w) { return Sin2Theta(w) / Cos2Theta(w); }
+DEV float CosPhi(const V3 &w) { float s = SinTheta(w); return (s == 0) ? 1 : clampf(w.x / s, -1, 1); }
+DEV float SinPhi(const V3 &w) { float s = SinTheta(w); return (s == 0) ? 0 : clampf(w.y / s, -1, 1); }
+DEV float Cos2Phi(const V3 &w) { return CosPhi(w) * CosPhi(w); }
+DEV float Sin2Phi(const V3 &w) { return SinPhi(w) * SinPhi(w); }
+DEV V3 Reflect(const V3 &wo, const V3 &n) { return -wo + 2 * Dot(wo, n) * n; }
+DEV bool Refract(const V3 &wi, const V3 &n, float eta, V3 *wt) {
+    float cosThetaI = Dot(n, wi);
+    float sin2ThetaI = maxf(0.f, 1 - cosThetaI * cosThetaI);
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = __builtin_sqrtf(1 - sin2ThetaT);
+    *wt = eta * -wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+DEV bool SameHemisphere(const V3 &w, const V3 &wp) { return w.z * wp.z > 0; }
+
+DEV float FrDielectric(float cosThetaI, float etaI, float etaT) {  // reflection.cpp:47-69
+    cosThetaI = clampf(cosThetaI, -1, 1);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = absf(cosThetaI); }
+    float sinThetaI = __builtin_sqrtf(maxf(0.f, 1 - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1;
+    float cosThetaT = __builtin_sqrtf(maxf(0.f, 1 - sinThetaT * sinThetaT));
+    float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+
+DEV void ConcentricSampleDisk(float u0, float u1, float *dx, float *dy) {  // sampling.cpp:113-130
+    float ox = 2.f * u0 - 1, oy = 2.f * u1 - 1;
+    if (ox == 0 && oy == 0) { *dx = 0; *dy = 0; return; }
+    float theta, r;
+    if (absf(ox) > absf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
+    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
+    *dx = r * cosf(theta);
+    *dy = r * sinf(theta);
+}
+DEV V3 CosineSampleHemisphere(float u0, float u1) {
+    float dx, dy;
+    ConcentricSampleDisk(u0, u1, &dx, &dy);
+    float z = __builtin_sqrtf(maxf(0.f, 1 - dx * dx - dy * dy));
+    return V3(dx, dy, z);
+}
+
+// ---- Trowbridge-Reitz (GGX), visible-normal sampling
+struct TRDist {
+    float alphax, alphay;
+    bool separableG;
+    DEV float D(const V3 &wh) const {
+        float tan2Theta = Tan2Theta(wh);
+        if (isinff(tan2Theta)) return 0.;
+        const float cos4Theta = Cos2Theta(wh) * Cos2Theta(wh);
+        float e = (Cos2Phi(wh) / (alphax * alphax) + Sin2Phi(wh) / (alphay * alphay)) * tan2Theta;
+        return 1 / (kPi * alphax * alphay * cos4Theta * (1 + e) * (1 + e));
+    }
+    DEV float Lambda(const V3 &w) const {
+        float absTanTheta = absf(TanTheta(w));
+        if (isinff(absTanTheta)) return 0.;
+        float alpha = __builtin_sqrtf(Cos2Phi(w) * alphax * alphax + Sin2Phi(w) * alphay * alphay);
+        float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+        return (-1 + __builtin_sqrtf(1.f + alpha2Tan2Theta)) / 2;
+    }
+    DEV float G1(const V3 &w) const { return 1 / (1 + Lambda(w)); }
+    DEV float G(const V3 &wo, const V3 &wi) const {
+        if (separableG) return G1(wo) * G1(wi);
+        return 1 / (1 + Lambda(wo) + Lambda(wi));
+    }
+    DEV float Pdf(const V3 &wo, const V3 &wh) const { return D(wh) * G1(wo) * AbsDot(wo, wh) / AbsCosTheta(wo); }
+    DEV static void Sample11(float cosTheta, float U1, float U2, float *slope_x, float *slope_y) {
+        if ((double)cosTheta > .9999) {
+            float r = (float)__builtin_sqrt((double)(U1 / (1 - U1)));
+            float phi = (float)(6.28318530718 * (double)U2);
+            *slope_x = r * (float)cos((double)phi);
+            *slope_y = r * (float)sin((double)phi);
+            return;
+        }
+        float sinTheta = __builtin_sqrtf(maxf(0.f, 1.f - cosTheta * cosTheta));
+        float tanTheta = sinTheta / cosTheta;
+        float a = 1 / tanTheta;
+        float G1 = 2 / (1 + __builtin_sqrtf(1.f + 1.f / (a * a)));
+        float A = 2 * U1 / G1 - 1;
+        float tmp = 1.f / (A * A - 1.f);
+        if ((double)tmp > 1e10) tmp = (float)1e10;
+        float B = tanTheta;
+        float D = __builtin_sqrtf(maxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+        float slope_x_1 = B * tmp - D;
+        float slope_x_2 = B * tmp + D;
+        *slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+        float S;
+        if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+        else { S = -1.f; U2 = 2.f * (.5f - U2); }
+        float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+                  (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+        *slope_y = S * z * __builtin_sqrtf(1.f + *slope_x * *slope_x);
+    }
+    DEV V3 Sample_wh(const V3 &wo, float u0, float u1) const {
+        bool flip = wo.z < 0;
+        V3 wi = flip ? -wo : wo;
+        V3 wiStretched = Normalize(V3(alphax * wi.x, alphay * wi.y, wi.z));
+        float slope_x, slope_y;
+        Sample11(CosTheta(wiStretched), u0, u1, &slope_x, &slope_y);
+        float tmp = CosPhi(wiStretched) * slope_x - SinPhi(wiStretched) * slope_y;
+        slope_y = SinPhi(wiStretched) * slope_x + CosPhi(wiStretched) * slope_y;
+        slope_x = tmp;
+        slope_x = alphax * slope_x;
+        slope_y = alphay * slope_y;
+        V3 wh = Normalize(V3(-slope_x, -slope_y, 1.f));
+        if (flip) wh = -wh;
+        return wh;
+    }
+};
+
+DEV float SchlickWeight(float cosTheta) { float m = clampf(1 - cosTheta, 0, 1); return (m * m) * (m * m) * m; }
+DEV float FrSchlickF(float R0, float cosTheta) { return lerpf(SchlickWeight(cosTheta), R0, 1); }
+DEV float GTR1(float cosTheta, float alpha) {
+    float alpha2 = alpha * alpha;
+    return (alpha2 - 1) / (kPi * logf(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
+}
+DEV float smithG_GGX(float cosTheta, float alpha) {
+    float alpha2 = alpha * alpha;
+    float cosTheta2 = cosTheta * cosTheta;
+    return 1 / (cosTheta + (float)__builtin_sqrt((double)(alpha2 + cosTheta2 - alpha2 * cosTheta2)));
+}
+
+// ---- scalar description of one lobe's f for a fixed (wo, wi)
+enum LobeKind : int {
+    LK_NONE = 0,
+    LK_MUL1,      // R*a
+    LK_MUL2,      // (R*a)*b
+    LK_MUL3,      // ((R*a)*b)*c
+    LK_MUL3_DIV,  // (((R*a)*b)*c)/d
+    LK_MUL1_DIV,  // (R*a)/d
+    LK_MUL2_DIV,  // ((R*a)*b)/d
+    LK_MICRO_DISNEY,  // (((R*a)*b)*F[bin])/d, F = lerp(c, FrDielectric=e, FrSchlick(S[bin], w=f))
+    LK_MTRANS,    // ((1-a)*R)*b
+    LK_CONST      // a
+};
+struct LobeEval {
+    int kind;
+    int lobe;  // index into material.bxdf
+    float a, b, c, d, e, f;
+};
+
+DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
+    const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
+    float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
+    switch (le.kind) {
+    case LK_MUL1: return R * le.a;
+    case LK_MUL2: return (R * le.a) * le.b;
+    case LK_MUL3: return ((R * le.a) * le.b) * le.c;
+    case LK_MUL3_DIV: return (((R * le.a) * le.b) * le.c) / le.d;
+    case LK_MUL1_DIV: return (R * le.a) / le.d;
+    case LK_MUL2_DIV: return ((R * le.a) * le.b) / le.d;
+    case LK_MICRO_DISNEY: {
+        float S = bx[li].S[bin];
+        // Lerp(metallic, Spectrum(FrDielectric), FrSchlick(R0, cosI)); FrSchlick = Lerp(w, R0, 1)
+        float schlick = (1 - le.f) * S + le.f * 1.f;
+        float F = (1 - le.c) * le.e + le.c * schlick;
+        return (((R * le.a) * le.b) * F) / le.d;
+    }
+    case LK_MTRANS: return ((1.f - le.a) * R) * le.b;
+    case LK_CONST: return le.a;
+    default: return 0.f;
+    }
+}
+
+struct BSDFFrame {
+    V3 ns, ng, ss, ts;
+    const mi_material *m;
+    DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
+    DEV V3 LocalToWorld(const V3 &v) const {
+        return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
+                  ss.z * v.x + ts.z * v.y + ns.z * v.z);
+    }
+};
+DEV bool MatchesFlags(const mi_bxdf &b, int t) { return (b.flags & t) == b.flags; }
+DEV int NumComponents(const mi_material *m, int flags) {
+    int num = 0;
+    for (int i = 0; i < m->n_bxdfs; ++i) if (MatchesFlags(m->bxdf[i], flags)) ++num;
+    return num;
+}
+DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.f}; }
+
+// BxDF::f for lobe i (local wo, wi) -> LobeEval. Mirrors o_bsdf / reflection.cpp per lobe.
+DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
+    LobeEval le;
+    le.kind = LK_NONE; le.lobe = i; le.a = le.b = le.c = le.d = le.e = le.f = 0;
+    switch (b.type) {
+    case MI_BXDF_LAMBERTIAN_REFLECTION:
+    case MI_BXDF_LAMBERTIAN_TRANSMISSION:
+        le.kind = LK_MUL1; le.a = kInvPi; break;
+    case MI_BXDF_OREN_NAYAR: {
+        float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
+        float maxCos = 0;
+        if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+            float sinPhiI = SinPhi(wi), cosPhiI = CosPhi(wi);
+            float sinPhiO = SinPhi(wo), cosPhiO = CosPhi(wo);
+            float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+            maxCos = maxf(0.f, dCos);
+        }
+        float sinAlpha, tanBeta;
+        if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / AbsCosTheta(wi); }
+        else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
+        le.kind = LK_MUL2; le.a = kInvPi; le.b = (b.p[0] + b.p[1] * maxCos * sinAlpha * tanBeta);
+        break;
+    }
+    case MI_BXDF_MICROFACET_REFLECTION: {
+        float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
+        V3 wh = wi + wo;
+        if (cosThetaI == 0 || cosThetaO == 0) break;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        TRDist d = DistOf(b);
+        float cosI = Dot(wi, wh);
+        le.a = d.D(wh); le.b = d.G(wo, wi); le.d = (4 * cosThetaI * cosThetaO);
+        if (b.fresnel == MI_FRESNEL_DISNEY) {
+            le.kind = LK_MICRO_DISNEY;
+            le.c = b.p[2];                       // metallic
+            le.e = FrDielectric(cosI, 1, b.p[3]);
+            le.f = SchlickWeight(cosI);
+        } else {
+            le.kind = LK_MUL3_DIV;
+            le.c = (b.fresnel == MI_FRESNEL_DIELECTRIC) ? FrDielectric(cosI, b.p[2], b.p[3]) : 1.f;
+        }
+        break;
+    }
+    case MI_BXDF_MICROFACET_TRANSMISSION: {
+        if (SameHemisphere(wo, wi)) break;
+        float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) break;
+        const float etaA = b.p[2], etaB = b.p[3];
+        float eta = CosTheta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        float F = FrDielectric(Dot(wo, wh), etaA, etaB);
+        float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        float factor = 1 / eta;
+        TRDist d = DistOf(b);
+        le.kind = LK_MTRANS;
+        le.a = F;
+        le.b = absf(d.D(wh) * d.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
+                    (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+        break;
+    }
+    case MI_BXDF_DISNEY_DIFFUSE: {
+        float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
+        le.kind = LK_MUL3; le.a = kInvPi; le.b = (1 - Fo / 2); le.c = (1 - Fi / 2);
+        break;
+    }
+    case MI_BXDF_DISNEY_FAKE_SS: {
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        float cosThetaD = Dot(wi, wh);
+        float Fss90 = cosThetaD * cosThetaD * b.p[0];
+        float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
+        float Fss = lerpf(Fo, 1.0f, Fss90) * lerpf(Fi, 1.0f, Fss90);
+        float ss = 1.25f * (Fss * (1 / (AbsCosTheta(wo) + AbsCosTheta(wi)) - .5f) + .5f);
+        le.kind = LK_MUL2; le.a = kInvPi; le.b = ss;
+        break;
+    }
+    case MI_BXDF_DISNEY_RETRO: {
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        float cosThetaD = Dot(wi, wh);
+        float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
+        float Rr = 2 * b.p[0] * cosThetaD * cosThetaD;
+        le.kind = LK_MUL3; le.a = kInvPi; le.b = Rr; le.c = (Fo + Fi + Fo * Fi * (Rr - 1));
+        break;
+    }
+    case MI_BXDF_DISNEY_SHEEN: {
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        le.kind = LK_MUL1; le.a = SchlickWeight(Dot(wi, wh));
+        break;
+    }
+    case MI_BXDF_DISNEY_CLEARCOAT: {
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        float Dr = GTR1(AbsCosTheta(wh), b.p[1]);
+        float Fr = FrSchlickF(.04f, Dot(wo, wh));
+        float Gr = smithG_GGX(AbsCosTheta(wo), .25f) * smithG_GGX(AbsCosTheta(wi), .25f);
+        le.kind = LK_CONST; le.a = b.p[0] * Gr * Fr * Dr / 4;
+        break;
+    }
+    default: break;  // specular lobes: f == 0
+    }
+    return le;
+}
+
+DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+    switch (b.type) {
+    case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR: return 0;
+    case MI_BXDF_LAMBERTIAN_TRANSMISSION: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
+    case MI_BXDF_MICROFACET_REFLECTION: {
+        if (!SameHemisphere(wo, wi)) return 0;
+        V3 wh = Normalize(wo + wi);
+        return DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
+    }
+    case MI_BXDF_MICROFACET_TRANSMISSION: {
+        if (SameHemisphere(wo, wi)) return 0;
+        const float etaA = b.p[2], etaB = b.p[3];
+        float eta = CosTheta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        float dwh_dwi = absf((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        return DistOf(b).Pdf(wo, wh) * dwh_dwi;
+    }
+    case MI_BXDF_DISNEY_CLEARCOAT: {
+        if (!SameHemisphere(wo, wi)) return 0;
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return 0;
+        wh = Normalize(wh);
+        float Dr = GTR1(AbsCosTheta(wh), b.p[1]);
+        return Dr * AbsCosTheta(wh) / (4 * Dot(wo, wh));
+    }
+    default: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
+    }
+}
+
+struct BSDFEval {
+    int n;  // number of contributing lobes
+    LobeEval lobes[MI_MAX_BXDFS];
+};
+
+// BSDF::f(woW, wiW, flags): fills the lobe list (reflection.cpp:670-683).
+DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BSDFEval *ev) {
+    ev->n = 0;
+    V3 wi = fr.WorldToLocal(wiW), wo = fr.WorldToLocal(woW);
+    if (wo.z == 0) return;
+    bool reflect = Dot(wiW, fr.ng) * Dot(woW, fr.ng) > 0;
+    const mi_material *m = fr.m;
+#pragma unroll
+    for (int i = 0; i < MI_MAX_BXDFS; ++i) {
+        if (i < m->n_bxdfs) {
+            const mi_bxdf &b = m->bxdf[i];
+            if (MatchesFlags(b, flags) &&
+                ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION)))) {
+                LobeEval le = LobeF(b, i, wo, wi);
+                if (le.kind != LK_NONE) ev->lobes[ev->n++] = le;
+            }
+        }
+    }
+}
+DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags) {  // reflection.cpp:770-785
+    const mi_material *m = fr.m;
+    if (m->n_bxdfs == 0) return 0.f;
+    V3 wo = fr.WorldToLocal(woW), wi = fr.WorldToLocal(wiW);
+    if (wo.z == 0) return 0.;
+    float pdf = 0.f;
+    int matchingComps = 0;
+    for (int i = 0; i < m->n_bxdfs; ++i)
+        if (MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf(m->bxdf[i], wo, wi); }
+    return matchingComps > 0 ? pdf / matchingComps : 0.f;
+}
+
+DEV float EvalBin(const BSDFEval &ev, const mi_bxdf *bx, int bin) {
+    float f = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI_MAX_BXDFS; ++i)
+        if (i < ev.n) f += LobeValue(ev.lobes[i], bx, bin);
+    return f;
+}
+
+// BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a
+// black f (including the early-outs that leave *pdf untouched). On success the value is
+// described by *ev (one specular LobeEval, or the lobe list for the sampled direction).
+DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, float u0, float u1, float *pdf, int type,
+                       int *sampledType, BSDFEval *ev) {
+    const mi_material *m = fr.m;
+    ev->n = 0;
+    int matchingComps = NumComponents(m, type);
+    if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return false; }
+    int comp = min((int)floorf(u0 * matchingComps), matchingComps - 1);
+    int bi = -1, count = comp;
+    for (int i = 0; i < m->n_bxdfs; ++i)
+        if (MatchesFlags(m->bxdf[i], type) && count-- == 0) { bi = i; break; }
+    const mi_bxdf &b = m->bxdf[bi];
+    float ur0 = minf(u0 * matchingComps - comp, kOneMinusEpsilon), ur1 = u1;
+    V3 wi, wo = fr.WorldToLocal(woWorld);
+    if (wo.z == 0) return false;
+    *pdf = 0;
+    *sampledType = b.flags;
+    LobeEval spec;
+    spec.kind = LK_NONE; spec.lobe = bi; spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = 0;
+    bool isSpecular = (b.flags & MI_BSDF_SPECULAR) != 0;
+    switch (b.type) {
+    case MI_BXDF_SPECULAR_REFLECTION: {  // (F*R)/|cos|
+        wi = V3(-wo.x, -wo.y, wo.z);
+        *pdf = 1;
+        float F = (b.fresnel == MI_FRESNEL_DIELECTRIC) ? FrDielectric(CosTheta(wi), b.p[2], b.p[3]) : 1.f;
+        spec.kind = LK_MUL1_DIV; spec.a = F; spec.d = AbsCosTheta(wi);
+        break;
+    }
+    case MI_BXDF_SPECULAR_TRANSMISSION: {  // ((T*(1-F))*ratio)/|cos|
+        const float etaA = b.p[0], etaB = b.p[1];
+        bool entering = CosTheta(wo) > 0;
+        float etaI = entering ? etaA : etaB, etaT = entering ? etaB : etaA;
+        if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, &wi)) break;
+        *pdf = 1;
+        spec.kind = LK_MUL2_DIV;
+        spec.a = (1.f - FrDielectric(CosTheta(wi), etaA, etaB));
+        spec.b = (etaI * etaI) / (etaT * etaT);
+        spec.d = AbsCosTheta(wi);
+        break;
+    }
+    case MI_BXDF_FRESNEL_SPECULAR: {
+        const float etaA = b.p[0], etaB = b.p[1];
+        float F = FrDielectric(CosTheta(wo), etaA, etaB);
+        if (ur0 < F) {
+            wi = V3(-wo.x, -wo.y, wo.z);
+            *sampledType = MI_BSDF_SPECULAR | MI_BSDF_REFLECTION;
+            *pdf = F;
+            spec.kind = LK_MUL1_DIV; spec.a = F; spec.d = AbsCosTheta(wi);
+        } else {
+            bool entering = CosTheta(wo) > 0;
+            float etaI = entering ? etaA : etaB, etaT = entering ? etaB : etaA;
+            if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, &wi)) break;
+            *sampledType = MI_BSDF_SPECULAR | MI_BSDF_TRANSMISSION;
+            *pdf = 1 - F;
+            spec.kind = LK_MUL2_DIV; spec.lobe = bi | 0x100;  // bit 8: use S (= T) instead of R
+            spec.a = (1 - F); spec.b = (etaI * etaI) / (etaT * etaT); spec.d = AbsCosTheta(wi);
+        }
+        break;
+    }
+    case MI_BXDF_LAMBERTIAN_TRANSMISSION: {
+        wi = CosineSampleHemisphere(ur0, ur1);
+        if (wo.z > 0) wi.z *= -1;
+        *pdf = LobePdf(b, wo, wi);
+        break;
+    }
+    case MI_BXDF_MICROFACET_REFLECTION: {
+        V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
+        wi = Reflect(wo, wh);
+        if (!SameHemisphere(wo, wi)) break;
+        *pdf = DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
+        break;
+    }
+    case MI_BXDF_MICROFACET_TRANSMISSION: {
+        V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
+        float eta = CosTheta(wo) > 0 ? (b.p[2] / b.p[3]) : (b.p[3] / b.p[2]);
+        if (!Refract(wo, wh, eta, &wi)) break;
+        *pdf = LobePdf(b, wo, wi);
+        break;
+    }
+    case MI_BXDF_DISNEY_CLEARCOAT: {
+        float alpha2 = b.p[1] * b.p[1];
+        float cosTheta = __builtin_sqrtf(maxf(0.f, (1 - powf(alpha2, 1 - ur0)) / (1 - alpha2)));
+        float sinTheta = __builtin_sqrtf(maxf(0.f, 1 - cosTheta * cosTheta));
+        float phi = 2 * kPi * ur1;
+        V3 wh = SphericalDirection(sinTheta, cosTheta, phi);
+        if (!SameHemisphere(wo, wh)) wh = -wh;
+        wi = Reflect(wo, wh);
+        if (!SameHemisphere(wo, wi)) break;
+        *pdf = LobePdf(b, wo, wi);
+        break;
+    }
+    default: {
+        wi = CosineSampleHemisphere(ur0, ur1);
+        if (wo.z < 0) wi.z *= -1;
+        *pdf = LobePdf(b, wo, wi);
+        break;
+    }
+    }
+    if (*pdf == 0) { *sampledType = 0; return false; }
+    *wiWorld = fr.LocalToWorld(wi);
+    if (!isSpecular && matchingComps > 1)
+        for (int i = 0; i < m->n_bxdfs; ++i)
+            if (i != bi && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf(m->bxdf[i], wo, wi);
+    if (matchingComps > 1) *pdf /= matchingComps;
+    if (isSpecular) {
+        ev->n = 1;
+        ev->lobes[0] = spec;
+    } else {
+        bool reflect = Dot(*wiWorld, fr.ng) * Dot(woWorld, fr.ng) > 0;
+#pragma unroll
+        for (int i = 0; i < MI_MAX_BXDFS; ++i) {
+            if (i < m->n_bxdfs) {
+                const mi_bxdf &bb = m->bxdf[i];
+                if (MatchesFlags(bb, type) &&
+                    ((reflect && (bb.flags & MI_BSDF_REFLECTION)) || (!reflect && (bb.flags & MI_BSDF_TRANSMISSION)))) {
+                    LobeEval le = LobeF(bb, i, wo, wi);
+                    if (le.kind != LK_NONE) ev->lobes[ev->n++] = le;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace dpt

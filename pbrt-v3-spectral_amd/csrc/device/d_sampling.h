@@ -1,0 +1,231 @@
+// d_sampling.h -- device Halton sampler, light sampling and light-selection pmfs.
+//   HaltonSampler / GlobalSampler   src/samplers/halton.cpp:98-127, src/core/sampler.cpp:46-52,136-195
+//   (Scrambled)RadicalInverse       src/core/lowdiscrepancy.cpp:130-175,389-424; lowdiscrepancy.h:82-91
+//   DiffuseAreaLight / Point / Distant  src/lights/diffuse.cpp:68-87, point.cpp:44-53, distant.cpp:49-59
+//   Shape::Sample(ref) / Pdf(ref,wi)    src/core/shape.cpp:56-87 (+ sphere.cpp:232-306)
+//   Distribution1D / SpatialLightDistribution  src/core/sampling.h:55-109, src/core/lightdistrib.cpp:135-300
+#pragma once
+#include "d_bsdf.h"
+
+namespace dpt {
+
+DEV uint32_t ReverseBits32(uint32_t n) { return __brev(n); }
+DEV uint64_t ReverseBits64(uint64_t n) {
+    uint64_t n0 = ReverseBits32((uint32_t)n);
+    uint64_t n1 = ReverseBits32((uint32_t)(n >> 32));
+    return (n0 << 32) | n1;
+}
+
+// digit loop shared by the plain and scrambled radical inverse; indices on this path
+// fit 32 bits (spp * 31104 < 2^32 up to 138k spp), so the divisions are 32-bit unless
+// the index really is wider.
+DEV float RadicalInverseBase(int base, uint64_t a) {
+    const float invBase = 1.f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    if (a >> 32) {
+        while (a >> 32) {
+            uint64_t next = a / (uint64_t)base;
+            uint64_t digit = a - next * (uint64_t)base;
+            reversedDigits = reversedDigits * (uint64_t)base + digit;
+            invBaseN *= invBase;
+            a = next;
+        }
+    }
+    uint32_t a32 = (uint32_t)a;
+    const uint32_t ub = (uint32_t)base;
+    while (a32) {
+        uint32_t next = a32 / ub;
+        uint32_t digit = a32 - next * ub;
+        reversedDigits = reversedDigits * ub + digit;
+        invBaseN *= invBase;
+        a32 = next;
+    }
+    return minf((float)reversedDigits * invBaseN, kOneMinusEpsilon);
+}
+DEV float ScrambledRadicalInverseBase(int base, const uint16_t *perm, uint64_t a) {
+    const float invBase = 1.f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    if (a >> 32) {
+        while (a >> 32) {
+            uint64_t next = a / (uint64_t)base;
+            uint64_t digit = a - next * (uint64_t)base;
+            reversedDigits = reversedDigits * (uint64_t)base + perm[digit];
+            invBaseN *= invBase;
+            a = next;
+        }
+    }
+    uint32_t a32 = (uint32_t)a;
+    const uint32_t ub = (uint32_t)base;
+    while (a32) {
+        uint32_t next = a32 / ub;
+        uint32_t digit = a32 - next * ub;
+        reversedDigits = reversedDigits * ub + perm[digit];
+        invBaseN *= invBase;
+        a32 = next;
+    }
+    return minf(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1 - invBase)), kOneMinusEpsilon);
+}
+DEV float RadicalInverse(const DScene &s, int baseIndex, uint64_t a) {
+    if (baseIndex == 0) return (float)((double)ReverseBits64(a) * 0x1p-64);
+    return RadicalInverseBase(s.primes[baseIndex], a);
+}
+DEV uint64_t InverseRadicalInverse(uint32_t base, uint64_t inverse, int nDigits) {
+    uint64_t index = 0;
+    for (int i = 0; i < nDigits; ++i) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+DEV int ModI(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
+
+DEV uint64_t HaltonPixelOffset(const DScene &s, int px, int py) {  // halton.cpp:98-118
+    int64_t offset = 0;
+    if (s.sampleStride > 1) {
+        int pm[2] = {ModI(px, 128), ModI(py, 128)};
+        for (int i = 0; i < 2; ++i) {
+            uint64_t dimOffset = InverseRadicalInverse(i == 0 ? 2u : 3u, (uint64_t)pm[i], s.baseExponents[i]);
+            offset += (int64_t)(dimOffset * (uint64_t)(s.sampleStride / s.baseScales[i]) * (uint64_t)s.multInverse[i]);
+        }
+        offset %= (int64_t)s.sampleStride;
+    }
+    return (uint64_t)offset;
+}
+DEV float SampleDimension(const DScene &s, uint64_t index, int dim) {  // halton.cpp:120-127
+    if (s.sampleAtPixelCenter && (dim == 0 || dim == 1)) return 0.5f;
+    if (dim == 0) return RadicalInverse(s, 0, index >> s.baseExponents[0]);
+    else if (dim == 1) return RadicalInverse(s, 1, index / (uint64_t)s.baseScales[1]);
+    else return ScrambledRadicalInverseBase(s.primes[dim], &s.perms[s.primeSums[dim]], index);
+}
+
+// ------------------------------------------------------------------ lights
+DEV float SpecYBinAccum(const DScene &s, int bin, float v) { return s.cieY[bin] * v; }
+DEV float YScale(float yy) {  // tail of SampledSpectrum::y(), spectrum.h:418-420
+    yy = (yy < 0) ? 0 : yy;
+    return yy * (float)(705 - 395) / (float)(106.856895f * 31);
+}
+DEV float LightY(const DScene &s, const mi_light &l) {
+    float yy = 0.f;
+    for (int i = 0; i < MI_NSPEC; ++i) yy += s.cieY[i] * l.L[i];
+    return YScale(yy);
+}
+
+DEV Interaction ShapeSample(const DScene &s, int shape, const Interaction &ref, float u0, float u1, float *pdf) {
+    if (shape < 0) return SphereSample(s.spheres[~shape], ref, u0, u1, pdf);
+    Interaction intr = TriSample(s, shape, u0, u1, pdf);
+    V3 wi = intr.p - ref.p;
+    if (wi.LengthSquared() == 0) *pdf = 0;
+    else {
+        wi = Normalize(wi);
+        *pdf *= DistanceSquared(ref.p, intr.p) / AbsDot(intr.n, -wi);
+        if (isinff(*pdf)) *pdf = 0.f;
+    }
+    return intr;
+}
+
+// Shape::Pdf(ref, wi) for the light's own shape (no BVH: it intersects only that shape).
+DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &ref, const V3 &wi) {
+    Ray ray = SpawnRay(ref, wi);
+    if (shape < 0) {
+        const mi_sphere &sp = s.spheres[~shape];
+        V3 pCenter = XfPoint(sp.o2w, V3(0, 0, 0));
+        V3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
+        if (!(DistanceSquared(pOrigin, pCenter) <= sp.radius * sp.radius)) {
+            float sinThetaMax2 = sp.radius * sp.radius / DistanceSquared(ref.p, pCenter);
+            float cosThetaMax = __builtin_sqrtf(maxf(0.f, 1 - sinThetaMax2));
+            return 1 / (2 * kPi * (1 - cosThetaMax));
+        }
+        SurfaceInteraction il;
+        float tHit;
+        if (!SphereInteraction(sp, ray.o, ray.d, kInfinity, &il, &tHit)) return 0;
+        float pdf = DistanceSquared(ref.p, il.p) / (AbsDot(il.n, -wi) * area);
+        if (isinff(pdf)) pdf = 0.f;
+        return pdf;
+    }
+    const int32_t *v = &s.triIndices[3 * shape];
+    V3 p0 = LoadV3(s.P, v[0]), p1 = LoadV3(s.P, v[1]), p2 = LoadV3(s.P, v[2]);
+    TriHit h;
+    if (!TriTest(p0, p1, p2, ray.o, ray.d, kInfinity, &h)) return 0;
+    {   // Triangle::Intersect rejects degenerate triangles after the t test
+        const mi_mesh m = s.meshes[s.triMesh[shape]];
+        float uv[3][2];
+        GetUVs(s, shape, m, uv);
+        V3 dpdu, dpdv;
+        if (!TriPartials(p0, p1, p2, uv, &dpdu, &dpdv)) return 0;
+    }
+    SurfaceInteraction il;
+    TriInteraction(s, shape, h.b0, h.b1, h.b2, ray.d, &il);
+    float pdf = DistanceSquared(ref.p, il.p) / (AbsDot(il.n, -wi) * area);
+    if (isinff(pdf)) pdf = 0.f;
+    return pdf;
+}
+
+DEV bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT; }
+
+struct LightSample {
+    V3 wi;
+    float pdf;
+    bool black;      // Li == 0 (back-facing area light)
+    float liScale;   // Li[bin] = L[bin] * liScale (point light: I / d^2 is a true division, flag below)
+    bool divide;     // Li[bin] = L[bin] / liScale
+    Interaction pLight;
+};
+DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &ref, float u0, float u1) {
+    LightSample ls;
+    ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.divide = false;
+    if (l.type == MI_LIGHT_DIFFUSE_AREA) {
+        Interaction pShape = ShapeSample(s, l.shape, ref, u0, u1, &ls.pdf);
+        if (ls.pdf == 0 || (pShape.p - ref.p).LengthSquared() == 0) { ls.pdf = 0; return ls; }
+        ls.wi = Normalize(pShape.p - ref.p);
+        ls.pLight = pShape;
+        ls.black = !(l.two_sided || Dot(pShape.n, -ls.wi) > 0);
+    } else if (l.type == MI_LIGHT_POINT) {
+        V3 pLight(l.pos[0], l.pos[1], l.pos[2]);
+        ls.wi = Normalize(pLight - ref.p);
+        ls.pdf = 1.f;
+        ls.pLight.p = pLight;
+        ls.black = false;
+        ls.divide = true;
+        ls.liScale = DistanceSquared(pLight, ref.p);
+    } else {
+        V3 wLight(l.dir[0], l.dir[1], l.dir[2]);
+        ls.wi = wLight;
+        ls.pdf = 1;
+        ls.pLight.p = ref.p + wLight * (2 * l.world_radius);
+        ls.black = false;
+    }
+    return ls;
+}
+DEV float LiBin(const mi_light &l, const LightSample &ls, int bin) { return ls.divide ? l.L[bin] / ls.liScale : l.L[bin]; }
+
+// ------------------------------------------------------------------ Distribution1D
+DEV int SampleDiscrete(const float *func, const float *cdf, float funcInt, int n, float u, float *pdf) {
+    int size = n + 1;
+    int first = 0, len = size;  // FindInterval, pbrt.h:405-418
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    *pdf = (funcInt > 0) ? func[offset] / (funcInt * n) : 0;
+    return offset;
+}
+// Which distribution serves point p (lightdistrib.cpp:135-151; the hash table there is a cache).
+DEV uint32_t LightDistribIndex(const DScene &s, const V3 &p) {
+    if (s.ldType != MI_LD_SPATIAL) return 0;
+    float o[3] = {p.x - s.wbMin[0], p.y - s.wbMin[1], p.z - s.wbMin[2]};
+    int pi[3];
+    for (int i = 0; i < 3; ++i) {
+        if (s.wbMax[i] > s.wbMin[i]) o[i] /= s.wbMax[i] - s.wbMin[i];
+        int v = (int)(o[i] * s.nVoxels[i]);
+        pi[i] = v < 0 ? 0 : (v > s.nVoxels[i] - 1 ? s.nVoxels[i] - 1 : v);
+    }
+    return ((uint32_t)pi[2] * s.nVoxels[1] + pi[1]) * s.nVoxels[0] + pi[0];
+}
+
+}  // namespace dpt

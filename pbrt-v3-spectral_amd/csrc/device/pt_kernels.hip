@@ -1,0 +1,1046 @@
+// pt_kernels.hip -- wavefront (Laine-style) spectral path tracer for gfx950 + the
+// mi_pt_* C ABI (include/mi_pt.h). One resident pool of path slots lives in HBM as
+// structure-of-arrays "planes" (plane k of slot i at base + k*pool + i, so every
+// per-bin access of a wave is one coalesced 256-B transaction). One iteration is
+//
+//   generate : flush finished paths into the film, refill empty slots from a global
+//              work counter (pixel, sample#) -> Halton camera sample -> camera ray
+//   extend   : BVH2 closest-hit traversal, short stack staged in LDS
+//   shade    : emission, termination, BSDF frame, light choice + light sample (NEE),
+//              BSDF sample for MIS, BSDF sample for the continuation, Russian roulette;
+//              streams the 31 bins of beta / contributions through HBM planes
+//   shadow   : any-hit traversal of the NEE shadow rays, adds unoccluded contributions
+//   mis      : closest-hit traversal of the MIS rays, adds emission if the sampled
+//              light was hit; closes the per-vertex direct-lighting statistics
+//
+// which restates, per path vertex, PathIntegrator::Li (src/integrators/path.cpp:64-188)
+// with UniformSampleOneLight / EstimateDirect (src/core/integrator.cpp:85-215) inside
+// SamplerIntegrator::Render's sample loop (src/core/integrator.cpp:228-342). Halton
+// dimensions are consumed in the reference's order, so every path makes the same
+// decisions as the CPU reference up to floating-point differences of libm functions.
+// No MFMA: this path is latency/bandwidth bound (traversal) and VALU bound (shading).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "d_sampling.h"
+
+using namespace dpt;
+
+namespace {
+
+thread_local std::string g_err;
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            g_err = std::string(#x) + ": " + hipGetErrorString(e_);                       \
+            return MI_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+constexpr int BLOCK = 256;
+constexpr int STACK_LDS = 24;    // traversal stack entries staged in LDS per lane
+constexpr int STACK_SPILL = 40;  // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
+
+// ---- float planes
+enum : int {
+    P_OX = 0, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TMAX,
+    P_HIT_T, P_B0, P_B1, P_B2,
+    P_ETASCALE, P_FILMX, P_FILMY,
+    P_SOX, P_SOY, P_SOZ, P_SDX, P_SDY, P_SDZ,       // shadow ray (tMax = 1 - ShadowEpsilon)
+    P_MOX, P_MOY, P_MOZ, P_MDX, P_MDY, P_MDZ,       // MIS ray
+    P_L,                                            // 31 planes each from here on
+    P_BETA = P_L + MI_NSPEC,
+    P_LNEE = P_BETA + MI_NSPEC,
+    P_LMIS = P_LNEE + MI_NSPEC,
+    P_COUNT = P_LMIS + MI_NSPEC
+};
+// ---- int planes
+enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT, I_COUNT };
+// ---- slot flags
+enum : int {
+    F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128
+};
+
+struct Pool {
+    float *f;
+    int *i;
+    uint32_t n;
+    DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
+    DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
+};
+
+struct DevCounters {
+    unsigned long long cameraRays, regularRays, shadowRays, totalPaths, zeroRadiancePaths, pathLengthSum, nodesVisited,
+        triTests, badSamples;
+    unsigned long long nextWork;   // global work counter
+    unsigned int alive;            // slots alive after generate
+    unsigned int pad;
+};
+
+struct WorkDesc {
+    unsigned long long totalWork;
+    int nTilesX, nTilesY, nTilesShard, shardIndex, shardCount;
+    long long spp;
+};
+
+DEV unsigned long long WaveSum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+DEV void CountAdd(unsigned long long *ctr, unsigned long long v) {
+    v = WaveSum(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// ------------------------------------------------------------------ traversal
+struct Hit {
+    int prim;
+    float t, b0, b1, b2;
+};
+
+// BVHAccel::Intersect / IntersectP (bvh.cpp:662-738) with Bounds3::IntersectP
+// (geometry.h:1420-1447): same visiting order (near child first, leaf primitives in
+// order), so equal-t ties resolve as in the reference.
+template <bool ANY>
+DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, int (*lds)[BLOCK],
+                  unsigned &nodeCount, unsigned &triCount) {
+    if (s.nNodes == 0) return false;
+    const int lane = threadIdx.x;
+    V3 invDir(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+    const int neg0 = invDir.x < 0, neg1 = invDir.y < 0, neg2 = invDir.z < 0;
+    int spill[STACK_SPILL];
+    int sp = 0, cur = 0;
+    bool found = false;
+    const float k = 1 + 2 * gammaf(3);
+    while (true) {
+        const float4 na = s.nodes[2 * cur], nb = s.nodes[2 * cur + 1];
+        ++nodeCount;
+        const float bminx = na.x, bminy = na.y, bminz = na.z, bmaxx = na.w, bmaxy = nb.x, bmaxz = nb.y;
+        const int offset = __float_as_int(nb.z);
+        const unsigned meta = __float_as_uint(nb.w);
+        const int nPrims = meta & 0xffff, axis = (meta >> 16) & 0xff;
+        bool hitBox;
+        {
+            float tMin = ((neg0 ? bmaxx : bminx) - ro.x) * invDir.x;
+            float tMx = ((neg0 ? bminx : bmaxx) - ro.x) * invDir.x;
+            float tyMin = ((neg1 ? bmaxy : bminy) - ro.y) * invDir.y;
+            float tyMax = ((neg1 ? bminy : bmaxy) - ro.y) * invDir.y;
+            tMx *= k;
+            tyMax *= k;
+            hitBox = !(tMin > tyMax || tyMin > tMx);
+            if (hitBox) {
+                if (tyMin > tMin) tMin = tyMin;
+                if (tyMax < tMx) tMx = tyMax;
+                float tzMin = ((neg2 ? bmaxz : bminz) - ro.z) * invDir.z;
+                float tzMax = ((neg2 ? bminz : bmaxz) - ro.z) * invDir.z;
+                tzMax *= k;
+                if (tMin > tzMax || tzMin > tMx) hitBox = false;
+                else {
+                    if (tzMin > tMin) tMin = tzMin;
+                    if (tzMax < tMx) tMx = tzMax;
+                    hitBox = (tMin < tMax) && (tMx > 0);
+                }
+            }
+        }
+        bool pop = true;
+        if (hitBox) {
+            if (nPrims > 0) {
+                for (int i = 0; i < nPrims; ++i) {
+                    const int prim = offset + i;
+                    const float4 v0 = s.primTri[3 * prim];
+                    const unsigned pf = __float_as_uint(v0.w);
+                    if (pf & PRIM_FLAG_SPHERE) {
+                        const float4 v1 = s.primTri[3 * prim + 1];
+                        const int sph = __float_as_int(v1.w);
+                        float t;
+                        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+                            if (ANY) return true;
+                            tMax = t;
+                            hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+                            found = true;
+                        }
+                    } else {
+                        const float4 v1 = s.primTri[3 * prim + 1], v2 = s.primTri[3 * prim + 2];
+                        ++triCount;
+                        TriHit th;
+                        if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
+                            if (ANY) return true;
+                            if (!(pf & PRIM_FLAG_DEGENERATE)) {
+                                tMax = th.t;
+                                hit->prim = prim; hit->t = th.t; hit->b0 = th.b0; hit->b1 = th.b1; hit->b2 = th.b2;
+                                found = true;
+                            }
+                        }
+                    }
+                }
+            } else {
+                int farNode, nearNode;
+                const int negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
+                if (negAxis) { farNode = cur + 1; nearNode = offset; }
+                else { farNode = offset; nearNode = cur + 1; }
+                if (sp < STACK_LDS) lds[sp][lane] = farNode;
+                else spill[sp - STACK_LDS] = farNode;
+                ++sp;
+                cur = nearNode;
+                pop = false;
+            }
+        }
+        if (pop) {
+            if (sp == 0) break;
+            --sp;
+            cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS];
+        }
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------ generate
+DEV void CameraRay(const DScene &s, float pFilmX, float pFilmY, float lensU, float lensV, Ray *out) {
+    // PerspectiveCamera::GenerateRayDifferential, perspective.cpp:95-146 (differentials feed
+    // only texture filtering; every texture on this path is constant)
+    const mi_camera &cam = s.camera;
+    V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
+    V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
+    Ray ray(V3(0, 0, 0), dir);
+    if (cam.lens_radius > 0) {
+        float dx, dy;
+        ConcentricSampleDisk(lensU, lensV, &dx, &dy);
+        float lx = cam.lens_radius * dx, ly = cam.lens_radius * dy;
+        float ft = cam.focal_distance / ray.d.z;
+        V3 pFocus = ray.at(ft);
+        ray.o = V3(lx, ly, 0);
+        ray.d = Normalize(pFocus - ray.o);
+    }
+    *out = XfRay(cam.camera_to_world, ray);
+}
+
+// FilmTile::AddSample + MergeFilmTile (film.h:123-163, film.cpp:124-142) as float
+// atomics into the resident film [pixel][32] (31 bins + filter weight sum).
+DEV void FilmAddSample(const DScene &s, const Pool &pool, uint32_t slot, float *film, DevCounters *ctr, unsigned &bad) {
+    // guards of SamplerIntegrator::Render, integrator.cpp:295-316
+    float yy = 0.f;
+    bool hasNaN = false;
+    for (int b = 0; b < MI_NSPEC; ++b) {
+        float v = pool.F(P_L + b, slot);
+        hasNaN |= isnanf_(v);
+        yy += s.cieY[b] * v;
+    }
+    float y = YScale(yy);
+    bool zero = false;
+    if (hasNaN) zero = true;
+    else if ((double)y < -1e-5) zero = true;
+    else if (isinff(y)) zero = true;
+    if (zero) ++bad;
+    float scaleL = 1.f;
+    bool clampL = false;
+    if (!zero && y > s.maxSampleLuminance) { clampL = true; scaleL = s.maxSampleLuminance / y; }
+    const float pfx = pool.F(P_FILMX, slot), pfy = pool.F(P_FILMY, slot);
+    const int filterTableSize = 16;
+    float dx = pfx - 0.5f, dy = pfy - 0.5f;
+    int p0x = (int)ceilf(dx - s.filterRadius[0]), p0y = (int)ceilf(dy - s.filterRadius[1]);
+    int p1x = (int)floorf(dx + s.filterRadius[0]) + 1, p1y = (int)floorf(dy + s.filterRadius[1]) + 1;
+    p0x = max(p0x, s.croppedBounds[0]); p0y = max(p0y, s.croppedBounds[1]);
+    p1x = min(p1x, s.croppedBounds[2]); p1y = min(p1y, s.croppedBounds[3]);
+    const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
+    const int w = s.croppedBounds[2] - s.croppedBounds[0];
+    for (int y2 = p0y; y2 < p1y; ++y2) {
+        float fy = absf((y2 - dy) * invRy * filterTableSize);
+        int iy = min((int)floorf(fy), filterTableSize - 1);
+        for (int x2 = p0x; x2 < p1x; ++x2) {
+            float fx = absf((x2 - dx) * invRx * filterTableSize);
+            int ix = min((int)floorf(fx), filterTableSize - 1);
+            float fw = s.filterTable[iy * filterTableSize + ix];
+            size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
+            float *dst = film + pix * 32;
+            if (!zero) {
+                for (int b = 0; b < MI_NSPEC; ++b) {
+                    float v = pool.F(P_L + b, slot);
+                    if (clampL) v *= scaleL;
+                    atomicAdd(dst + b, (v * 1.f) * fw);  // L * sampleWeight * filterWeight
+                }
+            }
+            atomicAdd(dst + 31, fw);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *film, DevCounters *ctr, WorkDesc wd) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = slot < pool.n;
+    int flags = valid ? pool.I(I_FLAGS, slot) : 0;
+    unsigned bad = 0, cam = 0;
+    if (valid && (flags & F_FINISHED)) {
+        FilmAddSample(s, pool, slot, film, ctr, bad);
+        flags = 0;
+    }
+    // refill: up to 4 tries to draw a work item that maps inside the sample / pixel bounds
+    bool need = valid && flags == 0;
+    bool got = false;
+    int px = 0, py = 0;
+    long long sampleNum = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        unsigned long long mask = __ballot(need && !got);
+        if (mask == 0) break;
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == (__ffsll((long long)mask) - 1)) base = atomicAdd(&ctr->nextWork, (unsigned long long)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+        if (need && !got) {
+            unsigned long long w = base + __popcll(mask & ((1ull << lane) - 1));
+            if (w >= wd.totalWork) { need = false; }
+            else {
+                const unsigned long long perSample = (unsigned long long)wd.nTilesShard * 256ull;
+                sampleNum = (long long)(w / perSample);
+                unsigned rem = (unsigned)(w % perSample);
+                int tileLocal = rem >> 8, pix = rem & 255;
+                int tile = wd.shardIndex + tileLocal * wd.shardCount;
+                int tx = tile % wd.nTilesX, ty = tile / wd.nTilesX;
+                int blk = pix >> 6, within = pix & 63;
+                px = s.sampleBounds[0] + tx * 16 + (within & 7) + (blk & 1) * 8;
+                py = s.sampleBounds[1] + ty * 16 + (within >> 3) + (blk >> 1) * 8;
+                if (px < s.sampleBounds[2] && py < s.sampleBounds[3] && px >= s.pixelBounds[0] && px < s.pixelBounds[2] &&
+                    py >= s.pixelBounds[1] && py < s.pixelBounds[3])
+                    got = true;
+            }
+        }
+    }
+    if (got) {
+        const uint64_t index = HaltonPixelOffset(s, px, py) + (uint64_t)sampleNum * (uint64_t)s.sampleStride;
+        // GetCameraSample (sampler.cpp:46-52): pFilm = dims 0,1; time = dim 2; pLens = dims 3,4
+        float u0 = SampleDimension(s, index, 0), u1 = SampleDimension(s, index, 1);
+        float pfx = (float)px + u0, pfy = (float)py + u1;
+        float lu = 0, lv = 0;
+        if (s.camera.lens_radius > 0) { lu = SampleDimension(s, index, 3); lv = SampleDimension(s, index, 4); }
+        Ray ray;
+        CameraRay(s, pfx, pfy, lu, lv, &ray);
+        ++cam;
+        pool.F(P_OX, slot) = ray.o.x; pool.F(P_OY, slot) = ray.o.y; pool.F(P_OZ, slot) = ray.o.z;
+        pool.F(P_DX, slot) = ray.d.x; pool.F(P_DY, slot) = ray.d.y; pool.F(P_DZ, slot) = ray.d.z;
+        pool.F(P_TMAX, slot) = ray.tMax;
+        pool.F(P_ETASCALE, slot) = 1.f;
+        pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
+        for (int b = 0; b < MI_NSPEC; ++b) { pool.F(P_L + b, slot) = 0.f; pool.F(P_BETA + b, slot) = 1.f; }
+        pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
+        pool.I(I_SAMPLE, slot) = (int)sampleNum;
+        pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
+        pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
+        pool.I(I_DIM, slot) = 5;
+        pool.I(I_BOUNCES, slot) = 0;
+        flags = F_ALIVE;
+    }
+    if (valid) pool.I(I_FLAGS, slot) = flags;
+    unsigned long long aliveMask = __ballot(valid && (flags & F_ALIVE));
+    if ((threadIdx.x & 63) == 0 && aliveMask) atomicAdd(&ctr->alive, (unsigned)__popcll(aliveMask));
+    CountAdd(&ctr->cameraRays, cam);
+    CountAdd(&ctr->badSamples, bad);
+}
+
+// ------------------------------------------------------------------ extend
+__global__ void __launch_bounds__(BLOCK) k_extend(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned nodes = 0, tris = 0, rays = 0;
+    if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
+        V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
+        V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+        float tMax = pool.F(P_TMAX, slot);
+        Hit h;
+        h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
+        bool found = Traverse<false>(s, ro, rd, tMax, &h, lds, nodes, tris);
+        ++rays;
+        pool.I(I_HITPRIM, slot) = found ? h.prim : -1;
+        pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
+    }
+    CountAdd(&ctr->regularRays, rays);
+    CountAdd(&ctr->nodesVisited, nodes);
+    CountAdd(&ctr->triTests, tris);
+}
+
+// Build the SurfaceInteraction of a recorded hit.
+DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si) {
+    const mi_prim p = s.prims[prim];
+    if (p.shape >= 0) TriInteraction(s, p.shape, b0, b1, b2, rd, si);
+    else { float t; SphereInteraction(s.spheres[~p.shape], ro, rd, kInfinity, si, &t); }
+}
+
+DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimension(s, index, dim++); }
+
+// ------------------------------------------------------------------ shade
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned totalPaths = 0, pathLen = 0;
+    if (slot < pool.n) {
+        int flags = pool.I(I_FLAGS, slot);
+        if (flags & F_ALIVE) {
+            int bounces = pool.I(I_BOUNCES, slot);
+            const int prim = pool.I(I_HITPRIM, slot);
+            const bool found = prim >= 0;
+            V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
+            V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+            SurfaceInteraction isect;
+            bool finished = false, passThrough = false;
+            if (found) HitInteraction(s, prim, ro, rd, pool.F(P_B0, slot), pool.F(P_B1, slot), pool.F(P_B2, slot), &isect);
+            // emitted light at the vertex, path.cpp:91-101
+            if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
+                const int li = s.prims[prim].area_light;
+                if (li >= 0) {
+                    const mi_light &l = s.lights[li];
+                    if (l.two_sided || Dot(isect.n, -rd) > 0)
+                        for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_L + b, slot) += pool.F(P_BETA + b, slot) * l.L[b];
+                }
+            }
+            if (!found || bounces >= s.maxDepth) finished = true;
+            int newFlags = 0;
+            if (!finished) {
+                const int matIdx = s.prims[prim].material;
+                if (matIdx < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
+                    Ray r = SpawnRay(isect, rd);
+                    pool.F(P_OX, slot) = r.o.x; pool.F(P_OY, slot) = r.o.y; pool.F(P_OZ, slot) = r.o.z;
+                    pool.F(P_TMAX, slot) = r.tMax;
+                    passThrough = true;  // flags and bounce count stay as they are
+                }
+            }
+            if (!finished && !passThrough) {
+                const int matIdx = s.prims[prim].material;
+                const mi_material *mat = &s.materials[matIdx];
+                BSDFFrame fr;  // BSDF ctor, reflection.h:170-176
+                fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
+                fr.m = mat;
+                uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
+                int dim = pool.I(I_DIM, slot);
+                const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
+                // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
+                if (NumComponents(mat, nonSpec) > 0) {
+                    ++totalPaths;
+                    newFlags |= F_NEE;
+                    if (s.nLights > 0) {
+                        const uint32_t di = LightDistribIndex(s, isect.p);
+                        float selPdf;
+                        const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
+                                                            s.ldFuncInt[di], (int)s.nLights, Get1D(s, index, dim), &selPdf);
+                        if (selPdf != 0) {
+                            float uL0 = Get1D(s, index, dim), uL1 = Get1D(s, index, dim);
+                            float uS0 = Get1D(s, index, dim), uS1 = Get1D(s, index, dim);
+                            const mi_light &light = s.lights[lightNum];
+                            LightSample ls = SampleLi(s, light, isect, uL0, uL1);
+                            float lightPdf = ls.pdf, scatteringPdf = 0;
+                            if (lightPdf > 0 && !ls.black) {
+                                BSDFEval ev;
+                                BSDF_f(fr, isect.wo, ls.wi, nonSpec, &ev);
+                                const float absdot = AbsDot(ls.wi, isect.shN);
+                                scatteringPdf = BSDF_Pdf(fr, isect.wo, ls.wi, nonSpec);
+                                const bool delta = IsDeltaLight(light);
+                                float weight = 1.f;
+                                if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
+                                bool fNonBlack = false, liNonBlack = false, cNonBlack = false;
+                                for (int b = 0; b < MI_NSPEC; ++b) {
+                                    float f = EvalBin(ev, mat->bxdf, b) * absdot;
+                                    float Li = LiBin(light, ls, b);
+                                    fNonBlack |= (f != 0.f);
+                                    liNonBlack |= (Li != 0.f);
+                                    float Ld = delta ? (f * Li) / lightPdf : ((f * Li) * weight) / lightPdf;
+                                    float c = pool.F(P_BETA + b, slot) * (Ld / selPdf);
+                                    cNonBlack |= (c != 0.f);
+                                    pool.F(P_LNEE + b, slot) = c;
+                                }
+                                if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
+                                    Ray sr = SpawnRayTo(isect, ls.pLight);
+                                    pool.F(P_SOX, slot) = sr.o.x; pool.F(P_SOY, slot) = sr.o.y; pool.F(P_SOZ, slot) = sr.o.z;
+                                    pool.F(P_SDX, slot) = sr.d.x; pool.F(P_SDY, slot) = sr.d.y; pool.F(P_SDZ, slot) = sr.d.z;
+                                    newFlags |= F_SHADOW;
+                                    if (!cNonBlack) newFlags |= 0;  // contribution may still be black; resolved in k_shadow
+                                }
+                            }
+                            if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
+                                V3 wi;
+                                float sPdf = 0;
+                                int sampledType = 0;
+                                BSDFEval ev;
+                                bool ok = BSDF_Sample_f(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
+                                if (ok && sPdf > 0) {
+                                    const float absdot = AbsDot(wi, isect.shN);
+                                    bool fNonBlack = false;
+                                    for (int b = 0; b < MI_NSPEC && !fNonBlack; ++b) fNonBlack |= (EvalBin(ev, mat->bxdf, b) * absdot != 0.f);
+                                    if (fNonBlack) {
+                                        float weight = 1;
+                                        bool go = true;
+                                        if (!(sampledType & MI_BSDF_SPECULAR)) {
+                                            float lp = ShapePdf(s, light.shape, light.area, isect, wi);
+                                            if (lp == 0) go = false;
+                                            else { float f = 1 * sPdf, g = 1 * lp; weight = (f * f) / (f * f + g * g); }
+                                        }
+                                        if (go) {
+                                            for (int b = 0; b < MI_NSPEC; ++b) {
+                                                float f = EvalBin(ev, mat->bxdf, b) * absdot;
+                                                float Ld = ((f * light.L[b]) * weight) / sPdf;  // f * Li * Tr(=1) * weight / scatteringPdf
+                                                pool.F(P_LMIS + b, slot) = pool.F(P_BETA + b, slot) * (Ld / selPdf);
+                                            }
+                                            Ray mr = SpawnRay(isect, wi);
+                                            pool.F(P_MOX, slot) = mr.o.x; pool.F(P_MOY, slot) = mr.o.y; pool.F(P_MOZ, slot) = mr.o.z;
+                                            pool.F(P_MDX, slot) = mr.d.x; pool.F(P_MDY, slot) = mr.d.y; pool.F(P_MDZ, slot) = mr.d.z;
+                                            pool.I(I_MISLIGHT, slot) = lightNum;
+                                            newFlags |= F_MIS;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- sample the BSDF for the next direction, path.cpp:131-150
+                {
+                    V3 wo = -rd, wi;
+                    float pdf = 0;
+                    int sflags = 0;
+                    float u0 = Get1D(s, index, dim), u1 = Get1D(s, index, dim);
+                    BSDFEval ev;
+                    bool ok = BSDF_Sample_f(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
+                    bool fNonBlack = false;
+                    float etaScale = pool.F(P_ETASCALE, slot);
+                    if (ok && pdf != 0.f) {
+                        const float absdot = AbsDot(wi, isect.shN);
+                        for (int b = 0; b < MI_NSPEC && !fNonBlack; ++b) fNonBlack |= (EvalBin(ev, mat->bxdf, b) != 0.f);
+                        if (fNonBlack) {
+                            if ((sflags & MI_BSDF_SPECULAR) && (sflags & MI_BSDF_TRANSMISSION)) {
+                                float eta = mat->eta;
+                                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                            }
+                            float maxRR = 0;
+                            for (int b = 0; b < MI_NSPEC; ++b) {
+                                float f = EvalBin(ev, mat->bxdf, b);
+                                float nb = pool.F(P_BETA + b, slot) * ((f * absdot) / pdf);
+                                pool.F(P_BETA + b, slot) = nb;
+                                float rr = nb * etaScale;
+                                maxRR = (b == 0) ? rr : maxf(maxRR, rr);
+                            }
+                            Ray nr = SpawnRay(isect, wi);
+                            // Russian roulette, path.cpp:176-184
+                            bool killed = false;
+                            if (maxRR < s.rrThreshold && bounces > 3) {
+                                float q = maxf(.05f, 1 - maxRR);
+                                if (Get1D(s, index, dim) < q) killed = true;
+                                else {
+                                    const float inv = 1 - q;
+                                    for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_BETA + b, slot) /= inv;
+                                }
+                            }
+                            if (killed) finished = true;
+                            else {
+                                pool.F(P_OX, slot) = nr.o.x; pool.F(P_OY, slot) = nr.o.y; pool.F(P_OZ, slot) = nr.o.z;
+                                pool.F(P_DX, slot) = nr.d.x; pool.F(P_DY, slot) = nr.d.y; pool.F(P_DZ, slot) = nr.d.z;
+                                pool.F(P_TMAX, slot) = nr.tMax;
+                                pool.F(P_ETASCALE, slot) = etaScale;
+                                if (sflags & MI_BSDF_SPECULAR) newFlags |= F_SPECULAR;
+                            }
+                        }
+                    }
+                    if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
+                }
+                pool.I(I_DIM, slot) = dim;
+            }
+            if (passThrough) {
+                // nothing else changes
+            } else if (finished) {
+                // ReportValue(pathLength, bounces): the loop's ++bounces has not run on break;
+                // a path killed by RR / black f at vertex `bounces` reports `bounces`.
+                pathLen = (unsigned)bounces;
+                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS)) | F_FINISHED;
+            } else {
+                newFlags |= F_ALIVE;
+                pool.I(I_BOUNCES, slot) = bounces + 1;
+            }
+            if (!passThrough) pool.I(I_FLAGS, slot) = newFlags;
+        }
+    }
+    CountAdd(&ctr->totalPaths, totalPaths);
+    CountAdd(&ctr->pathLengthSum, pathLen);
+}
+
+// ------------------------------------------------------------------ shadow rays
+__global__ void __launch_bounds__(BLOCK) k_shadow(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned nodes = 0, tris = 0, rays = 0;
+    if (slot < pool.n) {
+        int flags = pool.I(I_FLAGS, slot);
+        if (flags & F_SHADOW) {
+            V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
+            V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
+            Hit h;
+            ++rays;
+            bool occluded = Traverse<true>(s, ro, rd, 1 - kShadowEpsilon, &h, lds, nodes, tris);
+            if (!occluded) {
+                bool nonBlack = false;
+                for (int b = 0; b < MI_NSPEC; ++b) {
+                    float c = pool.F(P_LNEE + b, slot);
+                    nonBlack |= (c != 0.f);
+                    pool.F(P_L + b, slot) += c;
+                }
+                if (nonBlack) flags |= F_A_ADDED;
+            }
+            pool.I(I_FLAGS, slot) = flags & ~F_SHADOW;
+        }
+    }
+    CountAdd(&ctr->shadowRays, rays);
+    CountAdd(&ctr->nodesVisited, nodes);
+    CountAdd(&ctr->triTests, tris);
+}
+
+// ------------------------------------------------------------------ MIS rays + NEE bookkeeping
+__global__ void __launch_bounds__(BLOCK) k_mis(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned nodes = 0, tris = 0, rays = 0, zero = 0;
+    if (slot < pool.n) {
+        int flags = pool.I(I_FLAGS, slot);
+        if (flags & F_MIS) {
+            V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
+            V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
+            Hit h;
+            h.prim = -1;
+            ++rays;
+            if (Traverse<false>(s, ro, rd, kInfinity, &h, lds, nodes, tris)) {
+                const int lightNum = pool.I(I_MISLIGHT, slot);
+                if (s.prims[h.prim].area_light == lightNum) {
+                    const mi_light &l = s.lights[lightNum];
+                    bool emit = l.two_sided != 0;
+                    if (!emit) {
+                        SurfaceInteraction li;
+                        HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
+                        emit = Dot(li.n, -rd) > 0;
+                    }
+                    if (emit) {
+                        bool nonBlack = false;
+                        for (int b = 0; b < MI_NSPEC; ++b) {
+                            float c = pool.F(P_LMIS + b, slot);
+                            nonBlack |= (c != 0.f);
+                            pool.F(P_L + b, slot) += c;
+                        }
+                        if (nonBlack) flags |= F_B_ADDED;
+                    }
+                }
+            }
+        }
+        if (flags & F_NEE) {
+            if (!(flags & (F_A_ADDED | F_B_ADDED))) ++zero;
+            pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
+        }
+    }
+    CountAdd(&ctr->regularRays, rays);
+    CountAdd(&ctr->nodesVisited, nodes);
+    CountAdd(&ctr->triTests, tris);
+    CountAdd(&ctr->zeroRadiancePaths, zero);
+}
+
+// ------------------------------------------------------------------ spatial light distribution (create time)
+__global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcInt, uint32_t nVox) {
+    const uint32_t vox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= nVox) return;
+    const int nL = (int)s.nLights;
+    int pi[3];
+    pi[0] = vox % s.nVoxels[0];
+    pi[1] = (vox / s.nVoxels[0]) % s.nVoxels[1];
+    pi[2] = vox / (s.nVoxels[0] * s.nVoxels[1]);
+    float lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+        float t0 = (float)pi[i] / (float)s.nVoxels[i], t1 = (float)(pi[i] + 1) / (float)s.nVoxels[i];
+        float a = lerpf(t0, s.wbMin[i], s.wbMax[i]), b = lerpf(t1, s.wbMin[i], s.wbMax[i]);
+        lo[i] = minf(a, b); hi[i] = maxf(a, b);
+    }
+    float *f = func + (size_t)vox * nL;
+    for (int j = 0; j < nL; ++j) f[j] = 0.f;
+    const int nSamples = 128;
+    for (int i = 0; i < nSamples; ++i) {
+        float t[3] = {RadicalInverse(s, 0, i), RadicalInverse(s, 1, i), RadicalInverse(s, 2, i)};
+        Interaction intr;
+        intr.p = V3(lerpf(t[0], lo[0], hi[0]), lerpf(t[1], lo[1], hi[1]), lerpf(t[2], lo[2], hi[2]));
+        intr.wo = V3(1, 0, 0);
+        float u0 = RadicalInverse(s, 3, i), u1 = RadicalInverse(s, 4, i);
+        for (int j = 0; j < nL; ++j) {
+            const mi_light &l = s.lights[j];
+            LightSample ls = SampleLi(s, l, intr, u0, u1);
+            if (ls.pdf > 0) {
+                float yy = 0.f;
+                if (!ls.black) for (int b = 0; b < MI_NSPEC; ++b) yy += s.cieY[b] * LiBin(l, ls, b);
+                f[j] += YScale(yy) / ls.pdf;
+            }
+        }
+    }
+    float sumContrib = 0;
+    for (int j = 0; j < nL; ++j) sumContrib += f[j];
+    float avgContrib = sumContrib / (float)((size_t)nSamples * (size_t)nL);
+    float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
+    for (int j = 0; j < nL; ++j) f[j] = maxf(f[j], minContrib);
+    // Distribution1D ctor, sampling.h:57-70
+    float *c = cdf + (size_t)vox * (nL + 1);
+    c[0] = 0;
+    for (int j = 1; j < nL + 1; ++j) c[j] = c[j - 1] + f[j - 1] / nL;
+    float fi = c[nL];
+    if (fi == 0) { for (int j = 1; j < nL + 1; ++j) c[j] = (float)j / (float)nL; }
+    else { for (int j = 1; j < nL + 1; ++j) c[j] /= fi; }
+    funcInt[vox] = fi;
+}
+
+// ------------------------------------------------------------------ standalone traversal (mi_pt_trace)
+__global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, uint32_t n, int anyHit, float *hits) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + (size_t)i * 7;
+    V3 ro(r[0], r[1], r[2]), rd(r[3], r[4], r[5]);
+    unsigned nodes = 0, tris = 0;
+    Hit h;
+    h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
+    int prim;
+    if (anyHit) prim = Traverse<true>(s, ro, rd, r[6], &h, lds, nodes, tris) ? 0 : -1;
+    else prim = Traverse<false>(s, ro, rd, r[6], &h, lds, nodes, tris) ? h.prim : -1;
+    float *o = hits + (size_t)i * 4;
+    o[0] = __int_as_float(prim);
+    o[1] = (prim >= 0 && !anyHit) ? h.t : 0.f;
+    o[2] = (prim >= 0 && !anyHit) ? h.b0 : 0.f;
+    o[3] = (prim >= 0 && !anyHit) ? h.b1 : 0.f;
+}
+
+__global__ void k_film_split(const float *film32, float *filmSum, float *weightSum, size_t nPix) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPix * 32) return;
+    size_t pix = i >> 5;
+    int b = (int)(i & 31);
+    float v = film32[i];
+    if (b < 31) { if (filmSum) filmSum[pix * 31 + b] = v; }
+    else if (weightSum) weightSum[pix] = v;
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+struct mi_pt {
+    int device = 0;
+    DScene scene{};
+    std::vector<void *> allocs;
+    float *film = nullptr;  // [nPix][32]
+    size_t nPix = 0;
+    int filmW = 0, filmH = 0;
+    long long spp = 0;
+    Pool pool{};
+    DevCounters *ctr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    double lastSeconds[8] = {0};
+    bool haveEvents = false;
+};
+
+namespace {
+
+template <typename T>
+int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
+    *dst = nullptr;
+    if (count == 0 || !src) {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, 16));
+        pt->allocs.push_back(p);
+        *dst = (const T *)p;
+        return MI_OK;
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, count * sizeof(T)));
+    pt->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)p;
+    return MI_OK;
+}
+
+int EnsurePool(mi_pt *pt, uint32_t n) {
+    if (pt->pool.n == n && pt->pool.f) return MI_OK;
+    if (pt->pool.f) { hipFree(pt->pool.f); hipFree(pt->pool.i); pt->pool.f = nullptr; pt->pool.i = nullptr; }
+    HIPCHK(hipMalloc((void **)&pt->pool.f, (size_t)P_COUNT * n * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&pt->pool.i, (size_t)I_COUNT * n * sizeof(int)));
+    pt->pool.n = n;
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mi_pt_last_error(void) { return g_err.c_str(); }
+
+int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
+    if (!d || !out) { g_err = "null argument"; return MI_ERR_INVALID; }
+    if (d->abi_version != MI_ABI_VERSION) { g_err = "mi_scene_desc ABI version mismatch"; return MI_ERR_INVALID; }
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0) { g_err = "no HIP device available (this path has no CPU fallback)"; return MI_ERR_NO_DEVICE; }
+    if (device_ordinal < 0 || device_ordinal >= nDev) { g_err = "device ordinal out of range"; return MI_ERR_NO_DEVICE; }
+    // host-side shape checks before anything is launched
+    if (d->n_prims && !d->n_nodes) { g_err = "primitives without BVH nodes"; return MI_ERR_INVALID; }
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+        const mi_bvh_node &n = d->nodes[i];
+        if (n.n_prims > 0) { if (n.offset < 0 || (uint32_t)n.offset + n.n_prims > d->n_prims) { g_err = "BVH leaf out of range"; return MI_ERR_INVALID; } }
+        else if (n.offset <= (int)i || (uint32_t)n.offset >= d->n_nodes || i + 1 >= d->n_nodes) { g_err = "BVH child out of range"; return MI_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const mi_prim &p = d->prims[i];
+        if (p.shape >= 0 ? (uint32_t)p.shape >= d->n_tris : (uint32_t)(~p.shape) >= d->n_spheres) { g_err = "primitive shape index out of range"; return MI_ERR_INVALID; }
+        if (p.material >= (int)d->n_materials || p.area_light >= (int)d->n_lights) { g_err = "primitive material/light index out of range"; return MI_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < d->n_tris * 3; ++i)
+        if (d->tri_indices[i] < 0 || (uint32_t)d->tri_indices[i] >= d->n_verts) { g_err = "triangle vertex index out of range"; return MI_ERR_INVALID; }
+    for (uint32_t i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].n_bxdfs < 0 || d->materials[i].n_bxdfs > MI_MAX_BXDFS) { g_err = "material lobe count out of range"; return MI_ERR_INVALID; }
+    if (d->sampler.n_dims < 16 + 8 * (d->integrator.max_depth + 1)) { g_err = "Halton tables cover too few dimensions for max_depth"; return MI_ERR_INVALID; }
+
+    HIPCHK(hipSetDevice(device_ordinal));
+    mi_pt *pt = new mi_pt();
+    pt->device = device_ordinal;
+    DScene &s = pt->scene;
+    int rc;
+#define UP(src, count, dst) if ((rc = Upload(pt, src, count, &dst)) != MI_OK) { mi_pt_destroy(pt); return rc; }
+    {
+        const float4 *nodes;
+        UP((const float4 *)d->nodes, (size_t)d->n_nodes * 2, nodes);
+        s.nodes = nodes;
+    }
+    // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
+    {
+        std::vector<float4> pt3((size_t)d->n_prims * 3);
+        for (uint32_t i = 0; i < d->n_prims; ++i) {
+            const mi_prim &p = d->prims[i];
+            float4 a{0, 0, 0, 0}, b{0, 0, 0, 0}, c{0, 0, 0, 0};
+            unsigned flags = 0;
+            int shapeIdx = 0;
+            if (p.shape >= 0) {
+                const int32_t *v = &d->tri_indices[3 * p.shape];
+                const float *P = d->P;
+                a = float4{P[3 * v[0]], P[3 * v[0] + 1], P[3 * v[0] + 2], 0};
+                b = float4{P[3 * v[1]], P[3 * v[1] + 1], P[3 * v[1] + 2], 0};
+                c = float4{P[3 * v[2]], P[3 * v[2] + 1], P[3 * v[2] + 2], 0};
+                shapeIdx = p.shape;
+                // degenerate triangles are rejected by Triangle::Intersect (triangle.cpp:303-314):
+                // decide it once here with the same arithmetic (doubles in Cross)
+                auto cross = [](const float *u, const float *w, double *o) {
+                    o[0] = (double)u[1] * w[2] - (double)u[2] * w[1];
+                    o[1] = (double)u[2] * w[0] - (double)u[0] * w[2];
+                    o[2] = (double)u[0] * w[1] - (double)u[1] * w[0];
+                };
+                const mi_mesh &m = d->meshes[d->tri_mesh[p.shape]];
+                float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+                if (m.flags & MI_MESH_HAS_UV) for (int k = 0; k < 3; ++k) { uv[k][0] = d->UV[2 * v[k]]; uv[k][1] = d->UV[2 * v[k] + 1]; }
+                float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]}, duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+                float dp02[3] = {a.x - c.x, a.y - c.y, a.z - c.z}, dp12[3] = {b.x - c.x, b.y - c.y, b.z - c.z};
+                float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+                bool degenerateUV = std::abs(determinant) < 1e-8;
+                bool needNg = degenerateUV;
+                if (!degenerateUV) {
+                    float invdet = 1 / determinant;
+                    float dpdu[3], dpdv[3];
+                    for (int k = 0; k < 3; ++k) {
+                        dpdu[k] = (duv12[1] * dp02[k] - duv02[1] * dp12[k]) * invdet;
+                        dpdv[k] = (-duv12[0] * dp02[k] + duv02[0] * dp12[k]) * invdet;
+                    }
+                    double cr[3];
+                    cross(dpdu, dpdv, cr);
+                    float cx = (float)cr[0], cy = (float)cr[1], cz = (float)cr[2];
+                    if (cx * cx + cy * cy + cz * cz == 0) needNg = true;
+                }
+                if (needNg) {
+                    float e1[3] = {c.x - a.x, c.y - a.y, c.z - a.z}, e2[3] = {b.x - a.x, b.y - a.y, b.z - a.z};
+                    double cr[3];
+                    cross(e1, e2, cr);
+                    float cx = (float)cr[0], cy = (float)cr[1], cz = (float)cr[2];
+                    if (cx * cx + cy * cy + cz * cz == 0) flags |= PRIM_FLAG_DEGENERATE;
+                }
+            } else {
+                flags |= PRIM_FLAG_SPHERE;
+                shapeIdx = ~p.shape;
+            }
+            memcpy(&a.w, &flags, 4);
+            memcpy(&b.w, &shapeIdx, 4);
+            pt3[3 * i] = a; pt3[3 * i + 1] = b; pt3[3 * i + 2] = c;
+        }
+        const float4 *dev;
+        UP(pt3.data(), pt3.size(), dev);
+        s.primTri = dev;
+    }
+    UP(d->prims, d->n_prims, s.prims);
+    UP(d->tri_indices, (size_t)d->n_tris * 3, s.triIndices);
+    UP(d->tri_mesh, d->n_tris, s.triMesh);
+    UP(d->P, (size_t)d->n_verts * 3, s.P);
+    UP(d->N, (size_t)d->n_verts * 3, s.N);
+    UP(d->UV, (size_t)d->n_verts * 2, s.UV);
+    UP(d->meshes, d->n_meshes, s.meshes);
+    UP(d->spheres, d->n_spheres, s.spheres);
+    UP(d->materials, d->n_materials, s.materials);
+    UP(d->lights, d->n_lights, s.lights);
+    UP(d->sampler.primes, d->sampler.n_dims, s.primes);
+    UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
+    UP(d->sampler.perms, d->sampler.n_perms, s.perms);
+    UP(d->film.filter_table, 256, s.filterTable);
+    s.nNodes = d->n_nodes; s.nPrims = d->n_prims; s.nLights = d->n_lights; s.nMaterials = d->n_materials;
+    for (int i = 0; i < MI_NSPEC; ++i) s.cieY[i] = d->cie_y[i];
+    s.camera = d->camera;
+    for (int i = 0; i < 4; ++i) { s.croppedBounds[i] = d->film.cropped_bounds[i]; s.sampleBounds[i] = d->film.sample_bounds[i]; s.pixelBounds[i] = d->integrator.pixel_bounds[i]; }
+    s.filterRadius[0] = d->film.filter_radius[0]; s.filterRadius[1] = d->film.filter_radius[1];
+    s.maxSampleLuminance = d->film.max_sample_luminance;
+    for (int i = 0; i < 2; ++i) { s.baseScales[i] = d->sampler.base_scales[i]; s.baseExponents[i] = d->sampler.base_exponents[i]; s.multInverse[i] = d->sampler.mult_inverse[i]; }
+    s.sampleStride = d->sampler.sample_stride;
+    s.sampleAtPixelCenter = d->sampler.sample_at_pixel_center;
+    s.maxDepth = d->integrator.max_depth;
+    s.rrThreshold = d->integrator.rr_threshold;
+    pt->spp = d->sampler.samples_per_pixel;
+    if (d->n_nodes) for (int i = 0; i < 3; ++i) { s.wbMin[i] = d->nodes[0].bmin[i]; s.wbMax[i] = d->nodes[0].bmax[i]; }
+    // light-selection distributions
+    s.ldType = d->light_distrib.type;
+    for (int i = 0; i < 3; ++i) s.nVoxels[i] = d->light_distrib.n_voxels[i];
+    if (d->n_lights == 0) {
+        UP((const float *)nullptr, 0, s.ldFunc); UP((const float *)nullptr, 0, s.ldCdf); UP((const float *)nullptr, 0, s.ldFuncInt);
+    } else if (s.ldType != MI_LD_SPATIAL) {
+        if (!d->light_distrib.func || !d->light_distrib.cdf || !d->light_distrib.func_int) { g_err = "light distribution tables missing"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+        UP(d->light_distrib.func, d->n_lights, s.ldFunc);
+        UP(d->light_distrib.cdf, d->n_lights + 1, s.ldCdf);
+        UP(d->light_distrib.func_int, 1, s.ldFuncInt);
+    } else {
+        size_t nVox = (size_t)s.nVoxels[0] * s.nVoxels[1] * s.nVoxels[2];
+        if (nVox == 0 || nVox * d->n_lights > (1ull << 31)) { g_err = "spatial light distribution too large for the dense per-voxel table"; mi_pt_destroy(pt); return MI_ERR_UNSUPPORTED; }
+        float *f, *c, *fi;
+        if (hipMalloc((void **)&f, nVox * d->n_lights * 4) != hipSuccess || hipMalloc((void **)&c, nVox * (d->n_lights + 1) * 4) != hipSuccess ||
+            hipMalloc((void **)&fi, nVox * 4) != hipSuccess) { g_err = "hipMalloc(light distribution) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
+        pt->allocs.push_back(f); pt->allocs.push_back(c); pt->allocs.push_back(fi);
+        s.ldFunc = f; s.ldCdf = c; s.ldFuncInt = fi;
+        hipLaunchKernelGGL(k_build_spatial, dim3((unsigned)((nVox + 127) / 128)), dim3(128), 0, 0, s, f, c, fi, (uint32_t)nVox);
+        if (hipDeviceSynchronize() != hipSuccess) { g_err = "k_build_spatial failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
+    }
+#undef UP
+    pt->filmW = d->film.cropped_bounds[2] - d->film.cropped_bounds[0];
+    pt->filmH = d->film.cropped_bounds[3] - d->film.cropped_bounds[1];
+    if (pt->filmW <= 0 || pt->filmH <= 0) { g_err = "empty film"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+    pt->nPix = (size_t)pt->filmW * pt->filmH;
+    if (hipMalloc((void **)&pt->film, pt->nPix * 32 * sizeof(float)) != hipSuccess) { g_err = "hipMalloc(film) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
+    hipMemset(pt->film, 0, pt->nPix * 32 * sizeof(float));
+    if (hipMalloc((void **)&pt->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
+    hipEventCreate(&pt->evStart);
+    hipEventCreate(&pt->evStop);
+    pt->haveEvents = true;
+    *out = pt;
+    return MI_OK;
+}
+
+int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *weight_sum, mi_counters *counters) {
+    if (!pt || !rp) { g_err = "null argument"; return MI_ERR_INVALID; }
+    if (rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) { g_err = "bad shard"; return MI_ERR_INVALID; }
+    HIPCHK(hipSetDevice(pt->device));
+    hipStream_t st = (hipStream_t)rp->stream;
+    const DScene &s = pt->scene;
+    WorkDesc wd{};
+    wd.nTilesX = (s.sampleBounds[2] - s.sampleBounds[0] + 15) / 16;
+    wd.nTilesY = (s.sampleBounds[3] - s.sampleBounds[1] + 15) / 16;
+    const int nTiles = wd.nTilesX * wd.nTilesY;
+    wd.shardIndex = rp->shard_index; wd.shardCount = rp->shard_count;
+    wd.nTilesShard = (nTiles - rp->shard_index + rp->shard_count - 1) / rp->shard_count;
+    wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
+    wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
+    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 21);
+    if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
+    if (poolN < BLOCK) poolN = BLOCK;
+    int rc = EnsurePool(pt, poolN);
+    if (rc != MI_OK) return rc;
+    if (!(rp->flags & MI_RENDER_ACCUMULATE)) HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(pt->pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(pt->ctr, 0, sizeof(DevCounters), st));
+    const dim3 grid((poolN + BLOCK - 1) / BLOCK), block(BLOCK);
+    HIPCHK(hipEventRecord(pt->evStart, st));
+    unsigned alive = 1;
+    unsigned long long iterations = 0;
+    while (true) {
+        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
+        HIPCHK(hipMemcpyAsync(&alive, &pt->ctr->alive, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (alive == 0) break;
+        hipLaunchKernelGGL(k_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_shade, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_mis, grid, block, 0, st, s, pt->pool, pt->ctr);
+        if (++iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; }
+    }
+    HIPCHK(hipEventRecord(pt->evStop, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    hipEventElapsedTime(&ms, pt->evStart, pt->evStop);
+    pt->lastSeconds[0] = ms * 1e-3;
+    if (counters) {
+        DevCounters c;
+        HIPCHK(hipMemcpy(&c, pt->ctr, sizeof(c), hipMemcpyDeviceToHost));
+        *counters = mi_counters{};
+        counters->camera_rays = c.cameraRays; counters->regular_rays = c.regularRays; counters->shadow_rays = c.shadowRays;
+        counters->total_paths = c.totalPaths; counters->zero_radiance_paths = c.zeroRadiancePaths;
+        counters->path_length_sum = c.pathLengthSum; counters->bvh_nodes_visited = c.nodesVisited;
+        counters->tri_tests = c.triTests; counters->bad_samples = c.badSamples;
+        counters->reserved[0] = iterations;
+    }
+    if (film_sum || weight_sum) {
+        const bool onDev = (rp->flags & MI_RENDER_FILM_ON_DEVICE) != 0;
+        float *dSum = nullptr, *dW = nullptr;
+        if (onDev) { dSum = film_sum; dW = weight_sum; }
+        else {
+            if (film_sum) HIPCHK(hipMalloc((void **)&dSum, pt->nPix * 31 * sizeof(float)));
+            if (weight_sum) HIPCHK(hipMalloc((void **)&dW, pt->nPix * sizeof(float)));
+        }
+        size_t total = pt->nPix * 32;
+        hipLaunchKernelGGL(k_film_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pt->film, dSum, dW, pt->nPix);
+        HIPCHK(hipStreamSynchronize(st));
+        if (!onDev) {
+            if (film_sum) { HIPCHK(hipMemcpy(film_sum, dSum, pt->nPix * 31 * sizeof(float), hipMemcpyDeviceToHost)); hipFree(dSum); }
+            if (weight_sum) { HIPCHK(hipMemcpy(weight_sum, dW, pt->nPix * sizeof(float), hipMemcpyDeviceToHost)); hipFree(dW); }
+        }
+    }
+    return MI_OK;
+}
+
+int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats) {
+    if (!pt || !dev_ptr || !n_floats) { g_err = "null argument"; return MI_ERR_INVALID; }
+    *dev_ptr = pt->film;
+    *n_floats = pt->nPix * 32;
+    return MI_OK;
+}
+
+int mi_pt_last_timings(mi_pt *pt, double *seconds, int n) {
+    if (!pt || !seconds) { g_err = "null argument"; return MI_ERR_INVALID; }
+    for (int i = 0; i < n && i < 8; ++i) seconds[i] = pt->lastSeconds[i];
+    return MI_OK;
+}
+
+int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hits) {
+    if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
+    if (n == 0) return MI_OK;
+    HIPCHK(hipSetDevice(pt->device));
+    float *dr = nullptr, *dh = nullptr;
+    HIPCHK(hipMalloc((void **)&dr, (size_t)n * 7 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dh, (size_t)n * 4 * sizeof(float)));
+    HIPCHK(hipMemcpy(dr, rays, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, dr, n, any_hit, dh);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(hits, dh, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(dr);
+    hipFree(dh);
+    return MI_OK;
+}
+
+void mi_pt_destroy(mi_pt *pt) {
+    if (!pt) return;
+    hipSetDevice(pt->device);
+    for (void *p : pt->allocs) hipFree(p);
+    if (pt->film) hipFree(pt->film);
+    if (pt->pool.f) hipFree(pt->pool.f);
+    if (pt->pool.i) hipFree(pt->pool.i);
+    if (pt->ctr) hipFree(pt->ctr);
+    if (pt->haveEvents) { hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop); }
+    delete pt;
+}
+
+}  // extern "C"
