@@ -147,10 +147,12 @@ typedef struct mi_light {
     float world_center[3];
 } mi_light;
 
-/* Light-selection pmf (src/core/lightdistrib.cpp). For UNIFORM / POWER there is
- * one Distribution1D; for SPATIAL one per voxel, all voxels precomputed by the
- * host with the reference's 128-point Halton estimator (lightdistrib.cpp:232-300).
- * Distribution d lives at func[d*n_lights .. ], cdf[d*(n_lights+1) .. ], func_int[d]. */
+/* Light-selection pmf (src/core/lightdistrib.cpp). For UNIFORM / POWER the host
+ * supplies one Distribution1D (func[n_lights], cdf[n_lights+1], func_int[1]). For
+ * SPATIAL only the voxel resolution is given (func/cdf/func_int NULL,
+ * n_distributions 0): mi_pt_create estimates one pmf per voxel on the device with
+ * the reference's 128-point Halton estimator (lightdistrib.cpp:232-300), because the
+ * estimator needs Light::Sample_Li, which lives on the render side of this ABI. */
 typedef enum mi_lightdistrib_type { MI_LD_UNIFORM = 0, MI_LD_POWER, MI_LD_SPATIAL } mi_lightdistrib_type;
 typedef struct mi_lightdistrib {
     int32_t type;
@@ -233,7 +235,9 @@ typedef struct mi_counters {
     uint64_t bvh_nodes_visited; /* build's own traversal, for B_ray */
     uint64_t tri_tests;
     uint64_t bad_samples;  /* NaN / negative / inf guards, integrator.cpp:295-316 */
-    uint64_t reserved[7];
+    uint64_t iterations;   /* wavefront iterations of the last render */
+    uint64_t extend_rays, extend_nodes, extend_tri_tests; /* closest-hit (extend) kernel only */
+    uint64_t launches[3];  /* kernel launches of the last render: extend, shade, shadow */
 } mi_counters;
 
 #define MI_RENDER_FILM_ON_DEVICE 1u /* film_sum / weight_sum are device pointers */
@@ -243,6 +247,8 @@ typedef struct mi_render_params {
     uint32_t flags;
     uint32_t path_pool;   /* resident path slots; 0 = default */
     int64_t spp_override; /* 0 = use sampler.samples_per_pixel */
+    int64_t sample_begin; /* first Halton sample number of this pass (0 = from the start);
+                             a pass renders sample numbers [sample_begin, sample_begin + spp) */
     void *stream;         /* hipStream_t or NULL */
 } mi_render_params;
 
@@ -259,9 +265,9 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *params, float *film_sum,
 /* Device pointer of the resident film (layout [H*W][32]: 31 bins + weight) so a
  * collective can reduce in place; element count returned through n_floats. */
 int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats);
-/* Seconds spent inside kernels of the last mi_pt_render (HIP events on the
- * render stream) and per-kernel-class breakdown: [0]=total, [1]=generate,
- * [2]=extend, [3]=shade, [4]=shadow, [5]=mis/finish. */
+/* Seconds of the last mi_pt_render measured with HIP events on the render stream:
+ * [0]=whole render loop, then the sum over launches per kernel class: [1]=generate,
+ * [2]=extend, [3]=shade, [4]=shadow, [5]=mis. */
 int mi_pt_last_timings(mi_pt *pt, double *seconds, int n);
 void mi_pt_destroy(mi_pt *pt);
 const char *mi_pt_last_error(void);

@@ -106,15 +106,17 @@ class Counters(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("regular_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("total_paths", C.c_uint64), ("zero_radiance_paths", C.c_uint64), ("path_length_sum", C.c_uint64),
                 ("bvh_nodes_visited", C.c_uint64), ("tri_tests", C.c_uint64), ("bad_samples", C.c_uint64),
-                ("reserved", C.c_uint64 * 7)]
+                ("iterations", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_nodes", C.c_uint64),
+                ("extend_tri_tests", C.c_uint64), ("launches", C.c_uint64 * 3)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "launches"}
 
 
 class RenderParams(C.Structure):
     _fields_ = [("shard_index", C.c_int32), ("shard_count", C.c_int32), ("flags", C.c_uint32),
-                ("path_pool", C.c_uint32), ("spp_override", C.c_int64), ("stream", C.c_void_p)]
+                ("path_pool", C.c_uint32), ("spp_override", C.c_int64), ("sample_begin", C.c_int64),
+                ("stream", C.c_void_p)]
 
 
 class SceneOverrides(C.Structure):
@@ -274,11 +276,25 @@ class PathIntegrator:
         except Exception:
             pass
 
-    def Render(self, shard_index=0, shard_count=1, spp=0, path_pool=0, download=True, accumulate=False):
+    def Render(self, shard_index=0, shard_count=1, spp=0, path_pool=0, download=True, accumulate=False,
+               sample_begin=0, film_out=None, weight_out=None):
+        """Render sample numbers [sample_begin, sample_begin+spp) of this shard's tiles.
+        film_out / weight_out: optional device pointers (ints) that receive the film sums
+        (e.g. torch CUDA tensors' data_ptr()) instead of a host download."""
+        if film_out is not None:
+            rp = RenderParams(shard_index, shard_count, (RENDER_ACCUMULATE if accumulate else 0) | RENDER_FILM_ON_DEVICE,
+                              path_pool, spp, sample_begin, None)
+            rc = hip_lib().mi_pt_render(self._h, C.byref(rp), C.cast(film_out, C.POINTER(C.c_float)),
+                                        C.cast(weight_out, C.POINTER(C.c_float)) if weight_out else None,
+                                        C.byref(self.counters))
+            if rc != 0:
+                raise RuntimeError("mi_pt_render failed (%d): %s" % (rc, hip_lib().mi_pt_last_error().decode()))
+            return None, None
         w, h = self.scene.film_size
         film = np.zeros((h, w, NSPEC), np.float32) if download else None
         weight = np.zeros((h, w), np.float32) if download else None
-        rp = RenderParams(shard_index, shard_count, RENDER_ACCUMULATE if accumulate else 0, path_pool, spp, None)
+        rp = RenderParams(shard_index, shard_count, RENDER_ACCUMULATE if accumulate else 0, path_pool, spp,
+                          sample_begin, None)
         rc = hip_lib().mi_pt_render(self._h, C.byref(rp), _fptr(film) if download else None,
                                     _fptr(weight) if download else None, C.byref(self.counters))
         if rc != 0:

@@ -56,8 +56,8 @@ DEV void ConcentricSampleDisk(float u0, float u1, float *dx, float *dy) {  // sa
     float theta, r;
     if (absf(ox) > absf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
     else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
-    *dx = r * cosf(theta);
-    *dy = r * sinf(theta);
+    *dx = r * cosF(theta);
+    *dy = r * sinF(theta);
 }
 DEV V3 CosineSampleHemisphere(float u0, float u1) {
     float dx, dy;
@@ -138,7 +138,7 @@ DEV float SchlickWeight(float cosTheta) { float m = clampf(1 - cosTheta, 0, 1); 
 DEV float FrSchlickF(float R0, float cosTheta) { return lerpf(SchlickWeight(cosTheta), R0, 1); }
 DEV float GTR1(float cosTheta, float alpha) {
     float alpha2 = alpha * alpha;
-    return (alpha2 - 1) / (kPi * logf(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
+    return (alpha2 - 1) / (kPi * logF(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
 }
 DEV float smithG_GGX(float cosTheta, float alpha) {
     float alpha2 = alpha * alpha;
@@ -472,7 +472,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     }
     case MI_BXDF_DISNEY_CLEARCOAT: {
         float alpha2 = b.p[1] * b.p[1];
-        float cosTheta = __builtin_sqrtf(maxf(0.f, (1 - powf(alpha2, 1 - ur0)) / (1 - alpha2)));
+        float cosTheta = __builtin_sqrtf(maxf(0.f, (1 - powF(alpha2, 1 - ur0)) / (1 - alpha2)));
         float sinTheta = __builtin_sqrtf(maxf(0.f, 1 - cosTheta * cosTheta));
         float phi = 2 * kPi * ur1;
         V3 wh = SphericalDirection(sinTheta, cosTheta, phi);

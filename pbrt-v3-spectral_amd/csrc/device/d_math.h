@@ -32,6 +32,17 @@ DEV float absf(float a) { return __builtin_fabsf(a); }
 DEV bool isinff(float a) { return __builtin_isinf(a); }
 DEV bool isnanf_(float a) { return a != a; }
 
+// libm calls. The CPU reference uses glibc's float functions, which are correctly
+// rounded in (nearly) all cases; ocml's float versions are only ~1-2 ulp. Evaluating
+// in double and rounding once gives the correctly rounded float result (up to
+// double-rounding ties), so a path takes the same discrete decisions as on the CPU.
+DEV float sinF(float x) { return (float)sin((double)x); }
+DEV float cosF(float x) { return (float)cos((double)x); }
+DEV float acosF(float x) { return (float)acos((double)x); }
+DEV float atan2F(float y, float x) { return (float)atan2((double)y, (double)x); }
+DEV float logF(float x) { return (float)log((double)x); }
+DEV float powF(float x, float y) { return (float)pow((double)x, (double)y); }
+
 DEV float NextFloatUp(float v) {  // pbrt.h:244-256
     if (isinff(v) && v > 0.f) return v;
     if (v == -0.f) v = 0.f;
@@ -86,10 +97,10 @@ DEV void CoordinateSystem(const V3 &v1, V3 *v2, V3 *v3) {  // geometry.h:1029-10
     *v3 = Cross(v1, *v2);
 }
 DEV V3 SphericalDirection(float sinTheta, float cosTheta, float phi) {
-    return V3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    return V3(sinTheta * cosF(phi), sinTheta * sinF(phi), cosTheta);
 }
 DEV V3 SphericalDirection(float sinTheta, float cosTheta, float phi, const V3 &x, const V3 &y, const V3 &z) {
-    return sinTheta * cosf(phi) * x + sinTheta * sinf(phi) * y + cosTheta * z;
+    return sinTheta * cosF(phi) * x + sinTheta * sinF(phi) * y + cosTheta * z;
 }
 DEV V3 OffsetRayOrigin(const V3 &p, const V3 &pError, const V3 &n, const V3 &w) {
     float d = Dot(Abs(n), pError);

@@ -386,7 +386,7 @@ DEV bool SphereRoots(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMaxI
     V3 pHit = o + d * tShapeHit.v;
     pHit *= radius / Distance(pHit, V3(0, 0, 0));
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
-    float phi = atan2f(pHit.y, pHit.x);
+    float phi = atan2F(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * kPi;
     if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) {
         if (tShapeHit.v == t1.v) return false;
@@ -395,7 +395,7 @@ DEV bool SphereRoots(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMaxI
         pHit = o + d * tShapeHit.v;
         pHit *= radius / Distance(pHit, V3(0, 0, 0));
         if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
-        phi = atan2f(pHit.y, pHit.x);
+        phi = atan2F(pHit.y, pHit.x);
         if (phi < 0) phi += 2 * kPi;
         if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) return false;
     }
@@ -412,13 +412,13 @@ DEV bool SphereInteraction(const mi_sphere &s, const V3 &ro, const V3 &rd, float
     V3 dObj, pHit; float phi, t;
     if (!SphereRoots(s, ro, rd, tMax, &dObj, &pHit, &phi, &t)) return false;
     const float radius = s.radius, phiMax = s.phi_max, thetaMin = s.theta_min, thetaMax = s.theta_max;
-    float theta = acosf(clampf(pHit.z / radius, -1, 1));
+    float theta = acosF(clampf(pHit.z / radius, -1, 1));
     float zRadius = __builtin_sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
     float invZRadius = 1 / zRadius;
     float cosPhi = pHit.x * invZRadius;
     float sinPhi = pHit.y * invZRadius;
     V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
-    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinf(theta));
+    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinF(theta));
     V3 pError = gammaf(5) * Abs(pHit);
     bool flip = (s.reverse_orientation != 0) ^ (s.swaps_handedness != 0);
     V3 nObj = Normalize(Cross(dpdu, dpdv));
@@ -442,7 +442,7 @@ DEV V3 UniformSampleSphere(float u0, float u1) {  // sampling.cpp:98-103
     float z = 1 - 2 * u0;
     float r = __builtin_sqrtf(maxf(0.f, 1.f - z * z));
     float phi = 2 * kPi * u1;
-    return V3(r * cosf(phi), r * sinf(phi), z);
+    return V3(r * cosF(phi), r * sinF(phi), z);
 }
 DEV Interaction SphereSampleArea(const mi_sphere &s, float u0, float u1, float *pdf) {  // sphere.cpp:219-230
     V3 pObj = V3(0, 0, 0) + s.radius * UniformSampleSphere(u0, u1);

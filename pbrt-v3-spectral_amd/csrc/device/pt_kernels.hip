@@ -74,7 +74,7 @@ struct Pool {
 
 struct DevCounters {
     unsigned long long cameraRays, regularRays, shadowRays, totalPaths, zeroRadiancePaths, pathLengthSum, nodesVisited,
-        triTests, badSamples;
+        triTests, badSamples, extendNodes, extendTris, extendRays;
     unsigned long long nextWork;   // global work counter
     unsigned int alive;            // slots alive after generate
     unsigned int pad;
@@ -83,7 +83,7 @@ struct DevCounters {
 struct WorkDesc {
     unsigned long long totalWork;
     int nTilesX, nTilesY, nTilesShard, shardIndex, shardCount;
-    long long spp;
+    long long spp, sampleBegin;
 };
 
 DEV unsigned long long WaveSum(unsigned long long v) {
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             if (w >= wd.totalWork) { need = false; }
             else {
                 const unsigned long long perSample = (unsigned long long)wd.nTilesShard * 256ull;
-                sampleNum = (long long)(w / perSample);
+                sampleNum = wd.sampleBegin + (long long)(w / perSample);
                 unsigned rem = (unsigned)(w % perSample);
                 int tileLocal = rem >> 8, pix = rem & 255;
                 int tile = wd.shardIndex + tileLocal * wd.shardCount;
@@ -357,6 +357,9 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DScene s, Pool pool, DevCounte
     CountAdd(&ctr->regularRays, rays);
     CountAdd(&ctr->nodesVisited, nodes);
     CountAdd(&ctr->triTests, tris);
+    CountAdd(&ctr->extendNodes, nodes);
+    CountAdd(&ctr->extendTris, tris);
+    CountAdd(&ctr->extendRays, rays);
 }
 
 // Build the SurfaceInteraction of a recorded hit.
@@ -731,7 +734,9 @@ struct mi_pt {
     DevCounters *ctr = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evIter[2][6] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
     double lastSeconds[8] = {0};
+    unsigned long long lastLaunches[3] = {0, 0, 0};
     bool haveEvents = false;
 };
 
@@ -792,7 +797,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (d->tri_indices[i] < 0 || (uint32_t)d->tri_indices[i] >= d->n_verts) { g_err = "triangle vertex index out of range"; return MI_ERR_INVALID; }
     for (uint32_t i = 0; i < d->n_materials; ++i)
         if (d->materials[i].n_bxdfs < 0 || d->materials[i].n_bxdfs > MI_MAX_BXDFS) { g_err = "material lobe count out of range"; return MI_ERR_INVALID; }
-    if (d->sampler.n_dims < 16 + 8 * (d->integrator.max_depth + 1)) { g_err = "Halton tables cover too few dimensions for max_depth"; return MI_ERR_INVALID; }
+    if (d->sampler.n_dims < 6 + 8 * d->integrator.max_depth) { g_err = "Halton tables cover too few dimensions for max_depth"; return MI_ERR_INVALID; }
 
     HIPCHK(hipSetDevice(device_ordinal));
     mi_pt *pt = new mi_pt();
@@ -924,6 +929,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     if (hipMalloc((void **)&pt->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
     hipEventCreate(&pt->evStart);
     hipEventCreate(&pt->evStop);
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventCreate(&pt->evIter[a][b]);
     pt->haveEvents = true;
     *out = pt;
     return MI_OK;
@@ -942,6 +948,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     wd.shardIndex = rp->shard_index; wd.shardCount = rp->shard_count;
     wd.nTilesShard = (nTiles - rp->shard_index + rp->shard_count - 1) / rp->shard_count;
     wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
+    wd.sampleBegin = rp->sample_begin;
     wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
     uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 21);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
@@ -955,16 +962,40 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     HIPCHK(hipEventRecord(pt->evStart, st));
     unsigned alive = 1;
     unsigned long long iterations = 0;
+    double tGen = 0, tExt = 0, tShade = 0, tShadow = 0, tMis = 0;
+    // Per-kernel-class time: HIP events at the kernel boundaries of every iteration,
+    // read back after the per-iteration sync that the alive counter needs anyway.
+    auto harvest = [&](int set, bool full) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, pt->evIter[set][0], pt->evIter[set][1]); tGen += ms;
+        if (!full) return;
+        hipEventElapsedTime(&ms, pt->evIter[set][1], pt->evIter[set][2]); tExt += ms;
+        hipEventElapsedTime(&ms, pt->evIter[set][2], pt->evIter[set][3]); tShade += ms;
+        hipEventElapsedTime(&ms, pt->evIter[set][3], pt->evIter[set][4]); tShadow += ms;
+        hipEventElapsedTime(&ms, pt->evIter[set][4], pt->evIter[set][5]); tMis += ms;
+    };
+    int set = 0;
+    bool prevFull = false, havePrev = false;
     while (true) {
+        hipEvent_t *ev = pt->evIter[set];
         HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, sizeof(unsigned), st));
+        HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
+        HIPCHK(hipEventRecord(ev[1], st));
         HIPCHK(hipMemcpyAsync(&alive, &pt->ctr->alive, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (alive == 0) break;
+        if (havePrev) harvest(set ^ 1, prevFull);
+        if (alive == 0) { harvest(set, false); break; }
         hipLaunchKernelGGL(k_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
+        HIPCHK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_shade, grid, block, 0, st, s, pt->pool, pt->ctr);
+        HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
+        HIPCHK(hipEventRecord(ev[4], st));
         hipLaunchKernelGGL(k_mis, grid, block, 0, st, s, pt->pool, pt->ctr);
+        HIPCHK(hipEventRecord(ev[5], st));
+        havePrev = true; prevFull = true;
+        set ^= 1;
         if (++iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; }
     }
     HIPCHK(hipEventRecord(pt->evStop, st));
@@ -973,6 +1004,8 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     float ms = 0;
     hipEventElapsedTime(&ms, pt->evStart, pt->evStop);
     pt->lastSeconds[0] = ms * 1e-3;
+    pt->lastSeconds[1] = tGen * 1e-3; pt->lastSeconds[2] = tExt * 1e-3; pt->lastSeconds[3] = tShade * 1e-3;
+    pt->lastSeconds[4] = tShadow * 1e-3; pt->lastSeconds[5] = tMis * 1e-3;
     if (counters) {
         DevCounters c;
         HIPCHK(hipMemcpy(&c, pt->ctr, sizeof(c), hipMemcpyDeviceToHost));
@@ -981,7 +1014,10 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         counters->total_paths = c.totalPaths; counters->zero_radiance_paths = c.zeroRadiancePaths;
         counters->path_length_sum = c.pathLengthSum; counters->bvh_nodes_visited = c.nodesVisited;
         counters->tri_tests = c.triTests; counters->bad_samples = c.badSamples;
-        counters->reserved[0] = iterations;
+        counters->iterations = iterations;
+        counters->extend_rays = c.extendRays;
+        counters->extend_nodes = c.extendNodes; counters->extend_tri_tests = c.extendTris;
+        counters->launches[0] = counters->launches[1] = counters->launches[2] = iterations;
     }
     if (film_sum || weight_sum) {
         const bool onDev = (rp->flags & MI_RENDER_FILM_ON_DEVICE) != 0;
@@ -1039,7 +1075,10 @@ void mi_pt_destroy(mi_pt *pt) {
     if (pt->pool.f) hipFree(pt->pool.f);
     if (pt->pool.i) hipFree(pt->pool.i);
     if (pt->ctr) hipFree(pt->ctr);
-    if (pt->haveEvents) { hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop); }
+    if (pt->haveEvents) {
+        hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop);
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventDestroy(pt->evIter[a][b]);
+    }
     delete pt;
 }
 

@@ -817,8 +817,17 @@ struct Parser {
                 ParamSet::Add(ps->spectra, name, v);
                 break;
             }
-            case PT_BLACKBODY: case PT_SPECTRUM:
-                api->Err("\"" + decl + "\": blackbody / sampled spectra are outside the hot-path scope"); break;
+            case PT_SPECTRUM: {  // AddSampledSpectrum, paramset.cpp:152-169
+                if (n % 2) { api->Warn("Non-even number of values given with sampled spectrum parameter \"" + name + "\". Ignoring extra."); n -= n % 2; }
+                if (n == 0) { api->Err("empty sampled spectrum \"" + name + "\""); break; }
+                std::vector<float> wl(n / 2), vv(n / 2);
+                for (size_t i = 0; i < n / 2; ++i) { wl[i] = f(2 * i); vv[i] = f(2 * i + 1); }
+                std::vector<Spectrum> v(1, Spectrum::FromSampled(wl.data(), vv.data(), (int)(n / 2)));
+                ParamSet::Add(ps->spectra, name, v);
+                break;
+            }
+            case PT_BLACKBODY:
+                api->Err("\"" + decl + "\": blackbody spectra are outside the hot-path scope"); break;
             case PT_STRING: ParamSet::Add(ps->strings, name, strs); break;
             case PT_TEXTURE:
                 if (strs.size() == 1) ParamSet::Add(ps->textures, name, strs);

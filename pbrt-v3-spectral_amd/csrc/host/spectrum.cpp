@@ -2,6 +2,8 @@
 // Basis data: spectral_basis_31.inc (derived, see tools/make_spectral_basis.py).
 // Branch structure follows SampledSpectrum::FromRGB, src/core/spectrum.cpp:98-180.
 #include "spectrum.h"
+#include <utility>
+#include <vector>
 
 namespace mipt {
 namespace {
@@ -64,6 +66,45 @@ Spectrum Spectrum::FromRGB(const float rgb[3], SpectrumType type) {
     // "r *= .94" converts the double literal to Float first (operator*=(Float))
     r *= refl ? (float).94 : .86445f;
     return r.Clamp();
+}
+
+// AverageSpectrumSamples, src/core/spectrum.cpp:59-90 (note the double-precision
+// accumulation of each trapezoid through the 0.5 literal).
+static float AverageSpectrumSamples(const float *lambda, const float *vals, int n, float lambdaStart, float lambdaEnd) {
+    if (lambdaEnd <= lambda[0]) return vals[0];
+    if (lambdaStart >= lambda[n - 1]) return vals[n - 1];
+    if (n == 1) return vals[0];
+    float sum = 0;
+    if (lambdaStart < lambda[0]) sum += vals[0] * (lambda[0] - lambdaStart);
+    if (lambdaEnd > lambda[n - 1]) sum += vals[n - 1] * (lambdaEnd - lambda[n - 1]);
+    int i = 0;
+    while (lambdaStart > lambda[i + 1]) ++i;
+    auto lerp = [](float t, float v1, float v2) { return (1 - t) * v1 + t * v2; };
+    auto interp = [&](float w, int i) { return lerp((w - lambda[i]) / (lambda[i + 1] - lambda[i]), vals[i], vals[i + 1]); };
+    for (; i + 1 < n && lambdaEnd >= lambda[i]; ++i) {
+        float segLambdaStart = std::max(lambdaStart, lambda[i]);
+        float segLambdaEnd = std::min(lambdaEnd, lambda[i + 1]);
+        sum += 0.5 * (interp(segLambdaStart, i) + interp(segLambdaEnd, i)) * (segLambdaEnd - segLambdaStart);
+    }
+    return sum / (lambdaEnd - lambdaStart);
+}
+
+Spectrum Spectrum::FromSampled(const float *lambdaIn, const float *vIn, int n) {
+    std::vector<std::pair<float, float>> sv;
+    for (int i = 0; i < n; ++i) sv.push_back(std::make_pair(lambdaIn[i], vIn[i]));
+    bool sorted = true;
+    for (int i = 0; i + 1 < n; ++i) if (lambdaIn[i] > lambdaIn[i + 1]) sorted = false;
+    if (!sorted) std::sort(sv.begin(), sv.end());
+    std::vector<float> lambda(n), v(n);
+    for (int i = 0; i < n; ++i) { lambda[i] = sv[i].first; v[i] = sv[i].second; }
+    Spectrum r;
+    auto lerp = [](float t, float v1, float v2) { return (1 - t) * v1 + t * v2; };
+    for (int i = 0; i < kNSpec; ++i) {
+        float lambda0 = lerp(float(i) / float(kNSpec), (float)kLambdaStart, (float)kLambdaEnd);
+        float lambda1 = lerp(float(i + 1) / float(kNSpec), (float)kLambdaStart, (float)kLambdaEnd);
+        r.c[i] = AverageSpectrumSamples(lambda.data(), v.data(), n, lambda0, lambda1);
+    }
+    return r;
 }
 
 Spectrum Spectrum::FromXYZ(const float xyz[3], SpectrumType type) {

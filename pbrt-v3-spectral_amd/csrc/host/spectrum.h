@@ -36,6 +36,8 @@ struct Spectrum {
     float y() const;  // spectrum.h:415-421 (fork clamps negative sums to 0)
     static Spectrum FromRGB(const float rgb[3], SpectrumType type = SpectrumType::Illuminant);
     static Spectrum FromXYZ(const float xyz[3], SpectrumType type = SpectrumType::Reflectance);
+    // "spectrum" parameters given as (lambda, value) pairs, spectrum.h:302-321
+    static Spectrum FromSampled(const float *lambda, const float *v, int n);
     static const float *CIE_Y();  // the 31-bin Y matching function
 };
 inline Spectrum operator*(float a, const Spectrum &s) { return s * a; }

@@ -1,0 +1,105 @@
+"""Small scene descriptions used by the tests (authored here, .pbrt syntax)."""
+
+_HEAD = """
+LookAt 0 0 0  0 0 1  0 1 0
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d] %(extra)s
+WorldBegin
+"""
+
+
+def _c(v):
+    return "[300 %g 800 %g]" % (v, v)
+
+
+def furnace_point(res=10, spp=256, depth=8, n_lights=1, extra=""):
+    """tests/analytic_scenes.cpp:71-133: unit inward-facing sphere, Kd=0.5, point light(s)
+    of total intensity pi at the centre -> radiance 1."""
+    s = _HEAD % dict(res=res, spp=spp, depth=depth, extra=extra)
+    for _ in range(n_lights):
+        s += 'LightSource "point" "spectrum I" %s\n' % _c(3.14159265358979 / n_lights)
+    s += 'Material "matte" "spectrum Kd" %s\nReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n' % _c(0.5)
+    return s
+
+
+def furnace_area(res=10, spp=256, depth=8):
+    """tests/analytic_scenes.cpp:135-165: Kd=0.5 emissive sphere Le=0.5 -> radiance 1."""
+    s = _HEAD % dict(res=res, spp=spp, depth=depth, extra="")
+    s += 'Material "matte" "spectrum Kd" %s\nReverseOrientation\n' % _c(0.5)
+    s += 'AreaLightSource "diffuse" "spectrum L" %s\nShape "sphere" "float radius" [1]\nWorldEnd\n' % _c(0.5)
+    return s
+
+
+def furnace_uber(res=10, spp=256, depth=8):
+    """tests/analytic_scenes.cpp:167-203: UberMaterial Kd=.25 Kr=.5 (eta 1), I=3pi -> ~1."""
+    s = _HEAD % dict(res=res, spp=spp, depth=depth, extra="")
+    s += 'LightSource "point" "spectrum I" %s\n' % _c(3 * 3.14159265358979)
+    s += ('Material "uber" "spectrum Kd" %s "spectrum Ks" %s "spectrum Kr" %s "spectrum Kt" %s '
+          '"float roughness" [0] "float index" [1] "bool remaproughness" ["false"]\n' % (_c(.25), _c(0), _c(.5), _c(0)))
+    s += 'ReverseOrientation\nShape "sphere" "float radius" [1]\nWorldEnd\n'
+    return s
+
+
+MATERIAL_ZOO = """
+LookAt 0 3 -8  0 0.6 0  0 1 0
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d] "string lightsamplestrategy" "%(strategy)s"
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [18 17 15]
+  Translate 0 5 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.2 0 -1.2  1.2 0 -1.2  1.2 0 1.2  -1.2 0 1.2]
+AttributeEnd
+LightSource "point" "rgb I" [6 6 8] "point from" [-4 3 -3]
+LightSource "distant" "rgb L" [.4 .4 .5] "point from" [0 10 -4] "point to" [0 0 0]
+AttributeBegin
+  Material "matte" "rgb Kd" [.6 .6 .6] "float sigma" [20]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 -8  -8 0 8  8 0 8  8 0 -8]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 6  -8 8 6  8 8 6  8 0 6]
+AttributeEnd
+AttributeBegin
+  Material "glass" "float index" [1.5]
+  Translate -2.4 0.8 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  Material "uber" "rgb Kd" [.3 .1 .1] "rgb Ks" [.4 .4 .4] "rgb Kr" [.2 .2 .2] "float roughness" [.05] "rgb opacity" [.8 .8 .8]
+  Translate -0.8 0.8 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  Material "disney" "rgb color" [.2 .5 .3] "float metallic" [.4] "float roughness" [.3] "float sheen" [.5] "float clearcoat" [.6] "float anisotropic" [.3]
+  Translate 0.8 0.8 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  Material "disney" "rgb color" [.7 .6 .2] "float spectrans" [.6] "float roughness" [.2] "bool thin" ["true"] "float flatness" [.3] "float difftrans" [.8]
+  Translate 2.4 0.8 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  Material "glass" "float index" [1.4] "float uroughness" [.1] "float vroughness" [.2] "rgb Kt" [.9 .9 1]
+  Translate 0 0.5 -2.2
+  Shape "sphere" "float radius" [.5]
+AttributeEnd
+AttributeBegin
+  Material "mirror" "rgb Kr" [.8 .8 .8]
+  Translate 1.6 0.5 -2.2
+  Shape "sphere" "float radius" [.5]
+AttributeEnd
+AttributeBegin
+  Material "plastic" "rgb Kd" [.1 .2 .6] "rgb Ks" [.5 .5 .5] "float roughness" [.08]
+  Translate -1.6 0 -2.2
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 0 3 1 1 3 2]
+     "point P" [0 0 0  .9 0 0  .45 0 .8  .45 .9 .3] "normal N" [-.5 -.3 -.4  .6 -.3 -.4  0 -.2 .8  0 1 0]
+AttributeEnd
+WorldEnd
+"""
+
+
+def material_zoo(res=96, spp=16, depth=6, strategy="spatial"):
+    return MATERIAL_ZOO % dict(res=res, spp=spp, depth=depth, strategy=strategy)

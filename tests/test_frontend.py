@@ -1,0 +1,206 @@
+"""Host front end (.pbrt -> mi_scene_desc) and C-ABI surface. No GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import KILLEROO, CORNELL, ROOT
+import scenes_text as st
+
+
+def test_killeroo_matches_reference_scene_statistics(pt):
+    """66 532 triangles + 1 sphere; 59 188 interior + 59 189 leaf
+    BVH nodes (src/accelerators/bvh.cpp:44-47 counters printed by the reference)."""
+    s = pt.Scene(KILLEROO)
+    st_ = s.stats
+    assert st_["n_triangles"] == 66532 and st_["n_spheres"] == 1
+    assert st_["interior_nodes"] == 59188 and st_["leaf_nodes"] == 59189
+    assert st_["n_lights"] == 1 and st_["n_errors"] == 0
+    d = s.desc
+    assert s.film_size == (700, 700) and s.spp == 8
+    assert d.integrator.max_depth == 5 and d.integrator.rr_threshold == 1.0
+    # HaltonSampler ctor (src/samplers/halton.cpp:75-96): 700 -> scales 128 x 243
+    assert list(d.sampler.base_scales) == [128, 243] and list(d.sampler.base_exponents) == [7, 5]
+    assert d.sampler.sample_stride == 31104
+    assert (d.sampler.mult_inverse[0] * 243) % 128 == 1 and (d.sampler.mult_inverse[1] * 128) % 243 == 1
+    assert list(d.film.sample_bounds) == [0, 0, 700, 700] and list(d.film.filter_radius) == [0.5, 0.5]
+    assert d.light_distrib.type == 0  # one light -> uniform (lightdistrib.cpp:50)
+    assert s.film_filename == "killeroo-simple.exr"
+    # one plastic material per killeroo + matte ground + black matte + default matte
+    assert st_["n_materials"] == 5
+
+
+def test_bvh_structure_is_a_valid_depth_first_tree(pt):
+    s = pt.Scene(KILLEROO)
+    d = s.desc
+    nodes = np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_uint8)), shape=(d.n_nodes * 32,)).reshape(-1, 32)
+    offs = nodes[:, 24:28].copy().view(np.int32).ravel()
+    nprims = nodes[:, 28:30].copy().view(np.uint16).ravel()
+    interior = nprims == 0
+    idx = np.arange(d.n_nodes)
+    assert (offs[interior] > idx[interior]).all() and (offs[interior] < d.n_nodes).all()
+    assert nprims.sum() == d.n_prims  # every primitive in exactly one leaf
+    leaf_ranges = sorted((int(o), int(n)) for o, n in zip(offs[~interior], nprims[~interior]))
+    pos = 0
+    for o, n in leaf_ranges:
+        assert o == pos
+        pos += n
+    assert pos == d.n_prims
+
+
+def test_halton_permutations_are_permutations_and_deterministic(pt):
+    s = pt.Scene(KILLEROO)
+    d = s.desc
+    primes = [d.sampler.primes[i] for i in range(d.sampler.n_dims)]
+    assert primes[:8] == [2, 3, 5, 7, 11, 13, 17, 19]
+    off = 0
+    for i, p in enumerate(primes):
+        assert d.sampler.prime_sums[i] == off
+        perm = [d.sampler.perms[off + j] for j in range(p)]
+        assert sorted(perm) == list(range(p))
+        off += p
+    assert off == d.sampler.n_perms
+    s2 = pt.Scene(CORNELL)
+    assert [s2.desc.sampler.perms[i] for i in range(100)] == [d.sampler.perms[i] for i in range(100)]
+
+
+def test_directives_transforms_named_materials_textures(pt):
+    txt = """
+    LookAt 0 0 -5 0 0 0 0 1 0
+    Camera "perspective" "float fov" [30] "float lensradius" [0.1] "float focaldistance" [5]
+    Film "image" "integer xresolution" [32] "integer yresolution" [16] "float cropwindow" [0.25 0.75 0 1]
+    PixelFilter "gaussian" "float xwidth" [1.5] "float ywidth" [1.5]
+    Sampler "halton" "integer pixelsamples" [2]
+    WorldBegin
+    Texture "kd" "spectrum" "constant" "rgb value" [.2 .3 .4]
+    Texture "rough" "float" "constant" "float value" [.3]
+    MakeNamedMaterial "m1" "string type" "plastic" "texture Kd" "kd" "texture roughness" "rough"
+    AttributeBegin
+      NamedMaterial "m1"
+      Translate 1 2 3
+      Scale 2 2 2
+      Rotate 90 0 0 1
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
+    AttributeEnd
+    TransformBegin
+      ConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  5 6 7 1]
+      Shape "sphere" "float radius" [2] "float zmin" [-1]
+    TransformEnd
+    LightSource "point"
+    WorldEnd
+    """
+    s = pt.Scene(text=txt)
+    assert s.errors == []
+    d = s.desc
+    assert list(d.film.cropped_bounds) == [8, 0, 24, 16] and s.film_size == (16, 16)
+    assert list(d.film.sample_bounds) == [7, -1, 25, 17]  # Film::GetSampleBounds with radius 1.5
+    assert d.camera.lens_radius == pytest.approx(0.1)
+    # triangle: Translate * Scale * RotateZ(90) applied to (1,0,0) -> (1,4,3)
+    P = [d.P[i] for i in range(9)]
+    assert P[0:3] == pytest.approx([1, 2, 3]) and P[3:6] == pytest.approx([1, 4, 3], abs=1e-6)
+    sph = d.spheres[0]
+    assert sph.o2w[3] == 5 and sph.o2w[7] == 6 and sph.o2w[11] == 7 and sph.z_min == -1
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    plastic = [m for m in mats if m.kind == 1][0]
+    assert plastic.n_bxdfs == 2 and plastic.bxdf[1].type == 5  # Lambertian + microfacet reflection
+    assert plastic.bxdf[1].p[2] == 1.5 and plastic.bxdf[1].p[3] == 1.0  # FresnelDielectric(1.5, 1)
+
+
+def test_out_of_scope_features_are_reported_not_ignored(pt):
+    txt = """
+    Camera "orthographic"
+    Sampler "sobol"
+    Integrator "bdpt"
+    WorldBegin
+    Material "metal"
+    Shape "cylinder"
+    LightSource "infinite"
+    ObjectBegin "o"
+    ObjectEnd
+    Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
+    WorldEnd
+    """
+    s = pt.Scene(text=txt)
+    errs = "\n".join(s.errors)
+    for word in ("orthographic", "sobol", "bdpt", "metal", "cylinder", "infinite", "instancing"):
+        assert word in errs, word
+    assert s.stats["n_triangles"] == 1
+
+
+def test_parse_errors_fail_with_message(pt):
+    with pytest.raises(RuntimeError, match="unknown directive"):
+        pt.Scene(text="WorldBegin\nFooBar\nWorldEnd\n")
+    with pytest.raises(RuntimeError, match="no WorldEnd"):
+        pt.Scene(text="WorldBegin\n")
+    with pytest.raises(RuntimeError, match="open scene file"):
+        pt.Scene("/nonexistent/file.pbrt")
+
+
+def test_material_lobe_lists_follow_reference_order(pt):
+    s = pt.Scene(text=st.material_zoo())
+    assert s.errors == []
+    d = s.desc
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    uber = [m for m in mats if m.kind == 3][0]
+    # uber.cpp: opacity<1 -> SpecularTransmission first, then Lambert, microfacet, specular reflection
+    assert [uber.bxdf[i].type for i in range(uber.n_bxdfs)] == [3, 0, 5, 2] and uber.eta == 1.0
+    glass = [m for m in mats if m.kind == 2 and m.n_bxdfs == 1][0]
+    assert glass.bxdf[0].type == 4 and glass.eta == 1.5
+    rough_glass = [m for m in mats if m.kind == 2 and m.n_bxdfs == 2][0]
+    assert [rough_glass.bxdf[i].type for i in range(2)] == [5, 6]
+    disney = [m for m in mats if m.kind == 4]
+    assert sorted(m.n_bxdfs for m in disney) == [5, 6]
+    thin = [m for m in disney if m.n_bxdfs == 6][0]  # diffuse, fakeSS, retro, microfacet, transmission, lambertian T
+    assert [thin.bxdf[i].type for i in range(6)] == [8, 9, 10, 5, 6, 7]
+
+
+def test_spectral_dat_roundtrip_and_header(pt, tmp_path):
+    rng = np.random.default_rng(1)
+    film = rng.random((5, 7, 31), dtype=np.float32)
+    fn = str(tmp_path / "img.exr")
+    pt.write_dat(fn, film, scale=2.0)
+    raw = open(str(tmp_path / "img.dat"), "rb").read()
+    assert raw.startswith(b"7 5 31\nv3 \n")            # src/core/film.cpp:273,286
+    assert len(raw) == len(b"7 5 31\nv3 \n") + 31 * 35 * 8  # float64, plane-major
+    back = pt.read_dat(str(tmp_path / "img.dat"))
+    assert np.array_equal(back, film * np.float32(2.0))
+    first_plane = np.frombuffer(raw[len(b"7 5 31\nv3 \n"):][:35 * 8], dtype=np.float64).reshape(5, 7)
+    assert np.array_equal(first_plane.astype(np.float32), film[:, :, 0] * np.float32(2.0))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z_]+)\s*\(", txt)))
+
+
+def test_c_abi_libraries_export_every_declared_symbol(pt):
+    """Both shared libraries load without a GPU and export exactly the entry points that
+    include/*.h declare (no compute call is made here)."""
+    if not os.path.exists(pt.HIP_LIB):
+        subprocess.check_call(["make", "hip"], cwd=ROOT)
+    hip = C.CDLL(pt.HIP_LIB)
+    host = C.CDLL(pt.HOST_LIB)
+    pt_syms = [s for s in _declared("mi_pt.h")]
+    assert set(pt_syms) >= {"mi_pt_create", "mi_pt_render", "mi_pt_destroy", "mi_pt_last_error", "mi_pt_trace",
+                            "mi_pt_device_film", "mi_pt_last_timings"}
+    for sym in pt_syms:
+        assert hasattr(hip, sym), sym
+    for sym in _declared("mi_scene.h"):
+        assert hasattr(host, sym), sym
+
+
+def test_hip_path_fails_loudly_without_a_gpu(pt):
+    """No CPU fallback: creating the renderer without a device is an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    s = pt.Scene(text=st.furnace_point(res=4, spp=1))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pt.CreatePathIntegrator(s)
+    c = pt.Counters()
+    rc = pt.host_lib().mi_integrator_render(s._h, 0, None, C.byref(c))
+    assert rc != 0

@@ -21,7 +21,8 @@ t = time.time(); film, weight = integ.Render(path_pool=a.pool); dt = time.time()
 c = integ.counters.as_dict()
 rays = c["regular_rays"] + c["shadow_rays"]
 print("GPU render %.3fs (kernel %.3fs) %s" % (dt, integ.timings()[0], c))
-print("GPU Mray/s %.1f Msamples/s %.2f iterations %d" % (rays / integ.timings()[0] / 1e6, c["camera_rays"] / integ.timings()[0] / 1e6, integ.counters.reserved[0]))
+print("timings [total,gen,extend,shade,shadow,mis]", ["%.4f" % t for t in integ.timings()[:6]])
+print("GPU Mray/s %.1f Msamples/s %.2f iterations %d" % (rays / integ.timings()[0] / 1e6, c["camera_rays"] / integ.timings()[0] / 1e6, integ.counters.iterations))
 print("GPU film mean/sample %.6f weight mean %.6f" % (film.mean() / s.spp, weight.mean()))
 if not a.no_oracle:
     ofilm, oweight, oc, secs = ob.render(s)
