@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: Mray/s at fixed spp).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): killeroo-simple.pbrt, 700x700, PathIntegrator maxdepth 5,
+Halton, box filter, SampledSpectrum-31 -- BASELINE.json configs[1] (1024 spp on one
+MI355X). A *step* is one pass of the wavefront pipeline over the whole film for a block
+of `--spp-per-step` (64) consecutive Halton sample numbers; K = 16 steps accumulate the
+1024-spp film of configs[1]. The scene (BVH, meshes, tables) and the film are resident
+in HBM before the timed region starts; nothing crosses PCIe inside it.
+
+With N > 1 the film's 16x16 tiles are sharded over the ranks (tile_id % N == rank, same
+Halton indices as the 1-GPU render), each rank accumulates into its own device film and
+one RCCL sum-reduce of the film closes the timed region (strong scaling: total work is
+the fixed 1024-spp frame). A ray = one Scene::Intersect or Scene::IntersectP call
+(src/core/scene.cpp:40-55), counted on the device.
+
+The JSON line also carries
+  roofline:      closest-hit traversal kernel (k_extend), algorithmic bytes
+                 B_ray = 32*N_node + 48*N_tri + 64 with N_node/N_tri counted by the kernel,
+                 divided by the kernel's average launch duration (HIP events on the
+                 render stream, inside mi_pt_render), against the 8 TB/s HBM peak
+  cpu_baseline:  the CPU oracle (a port of the reference algorithm, oracle/) timed on the
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 measured)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "killeroo-simple.pbrt"))
+    ap.add_argument("--pool", type=int, default=0, help="resident path slots (0 = library default)")
+    ap.add_argument("--cpu-samples", type=int, default=24_000_000,
+                    help="camera samples the CPU oracle renders for cpu_baseline (0 = skip)")
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per k_extend launch from a separate rocprofv3 --pmc pass")
+    a = ap.parse_args()
+
+    import torch
+    import pbrt_v3_spectral_amd as pt
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ptdist", os.path.join(ROOT, "pbrt-v3-spectral_amd", "distributed.py"))
+    ptdist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ptdist)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    rank, world, local_rank = ptdist.init_from_env()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+
+    total_spp = a.steps * a.spp_per_step
+    scene = pt.Scene(a.scene, spp=total_spp)
+    integ = pt.CreatePathIntegrator(scene, local_rank)
+    w, h = scene.film_size
+    film = torch.zeros((h, w, pt.NSPEC), dtype=torch.float32, device="cuda")
+    weight = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    si, sc = ptdist.shard_of(rank, world)
+
+    def step(k, accumulate, out=False):
+        integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=k * a.spp_per_step,
+                     path_pool=a.pool, accumulate=accumulate, download=False,
+                     film_out=film.data_ptr() if out else None, weight_out=weight.data_ptr() if out else None)
+
+    # untimed warm-up steps (discarded: the first timed step clears the film)
+    for k in range(a.warmup):
+        if k == 0:
+            integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=0, path_pool=a.pool,
+                         download=False)
+        else:
+            step(k, True)
+
+    keys = ("camera_rays", "regular_rays", "shadow_rays", "extend_rays", "extend_nodes", "extend_tri_tests",
+            "iterations", "bvh_nodes_visited", "tri_tests")
+    acc = dict.fromkeys(keys, 0)
+    t_kernel = [0.0] * 6
+    ptdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        last = (k == a.steps - 1)
+        if last:
+            integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=k * a.spp_per_step,
+                         path_pool=a.pool, accumulate=(k > 0), film_out=film.data_ptr(), weight_out=weight.data_ptr())
+        else:
+            step(k, k > 0)
+        c = integ.counters.as_dict()
+        for key in keys:
+            acc[key] += c[key]
+        tk = integ.timings()
+        for i in range(6):
+            t_kernel[i] += tk[i]
+    ptdist.reduce_film(film, weight, dst=0)   # RCCL sum over xGMI (no-op for N = 1)
+    ptdist.barrier()
+    torch.cuda.synchronize()
+    dt = ptdist.max_over_ranks(time.perf_counter() - t0)
+
+    sums = ptdist.sum_over_ranks([acc[k] for k in keys])
+    tot = dict(zip(keys, sums))
+    rays = tot["regular_rays"] + tot["shadow_rays"]
+    mrays = rays / dt / 1e6
+    msamples = tot["camera_rays"] / dt / 1e6
+
+    # ---- roofline of the dominant kernel class on this rank (closest-hit traversal)
+    n_launch = max(1, acc["iterations"])
+    ext_rays = max(1, acc["extend_rays"])
+    n_node = acc["extend_nodes"] / ext_rays
+    n_tri = acc["extend_tri_tests"] / ext_rays
+    b_ray = 32.0 * n_node + 48.0 * n_tri + 64.0
+    bytes_per_launch = b_ray * ext_rays / n_launch
+    avg_launch_s = t_kernel[2] / n_launch
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": a.pmc_traffic,
+                "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tri_tests_per_ray": round(n_tri, 2),
+                "rays_per_launch": round(ext_rays / n_launch), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "launches": n_launch,
+                "kernel_time_s": {"generate": round(t_kernel[1], 4), "extend": round(t_kernel[2], 4),
+                                  "shade": round(t_kernel[3], 4), "shadow": round(t_kernel[4], 4),
+                                  "mis": round(t_kernel[5], 4), "render_loop": round(t_kernel[0], 4)}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and a.cpu_samples > 0:
+        import oracle_binding as ob
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        cores = min(cores, 16)   # a 1-GPU box gives this job a 16-core CPU share
+        ofilm, oweight, oc, secs = ob.render(scene, n_threads=cores, max_samples=a.cpu_samples)
+        orays = oc.regular_rays + oc.shadow_rays
+        cpu_baseline = {"value": round(orays / secs / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
+                        "msamples_per_s": round(oc.camera_rays / secs / 1e6, 3),
+                        "sample": "%d camera samples (whole 16x16 tiles, all %d spp per pixel) of the same scene, %.1f s"
+                                  % (oc.camera_rays, total_spp, secs)}
+
+    if rank == 0:
+        line = {
+            "metric": "Mray/s (killeroo-simple, PathIntegrator maxdepth 5, Halton, SampledSpectrum-31, %d spp)" % total_spp,
+            "value": round(mrays, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic: bundled killeroo-simple.pbrt scene, Halton samples",
+            "config": {"workload": "killeroo-simple.pbrt 700x700, %d spp = %d steps x %d spp, film tiles sharded over %d GPU(s)"
+                                   % (total_spp, a.steps, a.spp_per_step, world),
+                       "spp": total_spp, "resolution": [w, h], "max_depth": int(scene.desc.integrator.max_depth)},
+            "msamples_per_s": round(msamples, 2), "rays": int(rays), "camera_samples": int(tot["camera_rays"]),
+            "seconds": round(dt, 4),
+            "film_mean_per_sample": round(float(film.mean().item()) / total_spp, 6),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
