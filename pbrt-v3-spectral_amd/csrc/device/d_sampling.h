@@ -16,26 +16,27 @@ DEV uint64_t ReverseBits64(uint64_t n) {
     return (n0 << 32) | n1;
 }
 
-// digit loop shared by the plain and scrambled radical inverse; indices on this path
-// fit 32 bits (spp * 31104 < 2^32 up to 138k spp), so the divisions are 32-bit unless
-// the index really is wider.
-DEV float RadicalInverseBase(int base, uint64_t a) {
+// Digit loops of the plain and scrambled radical inverse. Indices on this path fit 32
+// bits (spp * 31104 < 2^32 up to 138k spp); the quotient by the (runtime) prime base is
+// then one 64-bit high multiply with the precomputed magic ceil(2^64/base), exact for
+// every 32-bit dividend. Wider indices take the plain 64-bit division first.
+DEV uint32_t DivMagic(uint32_t a, uint64_t magic) { return (uint32_t)__umul64hi((uint64_t)a, magic); }
+
+DEV float RadicalInverseBase(int base, uint64_t magic, uint64_t a) {
     const float invBase = 1.f / (float)base;
     uint64_t reversedDigits = 0;
     float invBaseN = 1;
-    if (a >> 32) {
-        while (a >> 32) {
-            uint64_t next = a / (uint64_t)base;
-            uint64_t digit = a - next * (uint64_t)base;
-            reversedDigits = reversedDigits * (uint64_t)base + digit;
-            invBaseN *= invBase;
-            a = next;
-        }
+    while (a >> 32) {
+        uint64_t next = a / (uint64_t)base;
+        uint64_t digit = a - next * (uint64_t)base;
+        reversedDigits = reversedDigits * (uint64_t)base + digit;
+        invBaseN *= invBase;
+        a = next;
     }
     uint32_t a32 = (uint32_t)a;
     const uint32_t ub = (uint32_t)base;
     while (a32) {
-        uint32_t next = a32 / ub;
+        uint32_t next = DivMagic(a32, magic);
         uint32_t digit = a32 - next * ub;
         reversedDigits = reversedDigits * ub + digit;
         invBaseN *= invBase;
@@ -43,23 +44,21 @@ DEV float RadicalInverseBase(int base, uint64_t a) {
     }
     return minf((float)reversedDigits * invBaseN, kOneMinusEpsilon);
 }
-DEV float ScrambledRadicalInverseBase(int base, const uint16_t *perm, uint64_t a) {
+DEV float ScrambledRadicalInverseBase(int base, uint64_t magic, const uint16_t *perm, uint64_t a) {
     const float invBase = 1.f / (float)base;
     uint64_t reversedDigits = 0;
     float invBaseN = 1;
-    if (a >> 32) {
-        while (a >> 32) {
-            uint64_t next = a / (uint64_t)base;
-            uint64_t digit = a - next * (uint64_t)base;
-            reversedDigits = reversedDigits * (uint64_t)base + perm[digit];
-            invBaseN *= invBase;
-            a = next;
-        }
+    while (a >> 32) {
+        uint64_t next = a / (uint64_t)base;
+        uint64_t digit = a - next * (uint64_t)base;
+        reversedDigits = reversedDigits * (uint64_t)base + perm[digit];
+        invBaseN *= invBase;
+        a = next;
     }
     uint32_t a32 = (uint32_t)a;
     const uint32_t ub = (uint32_t)base;
     while (a32) {
-        uint32_t next = a32 / ub;
+        uint32_t next = DivMagic(a32, magic);
         uint32_t digit = a32 - next * ub;
         reversedDigits = reversedDigits * ub + perm[digit];
         invBaseN *= invBase;
@@ -69,7 +68,7 @@ DEV float ScrambledRadicalInverseBase(int base, const uint16_t *perm, uint64_t a
 }
 DEV float RadicalInverse(const DScene &s, int baseIndex, uint64_t a) {
     if (baseIndex == 0) return (float)((double)ReverseBits64(a) * 0x1p-64);
-    return RadicalInverseBase(s.primes[baseIndex], a);
+    return RadicalInverseBase(s.primes[baseIndex], s.primeMagic[baseIndex], a);
 }
 DEV uint64_t InverseRadicalInverse(uint32_t base, uint64_t inverse, int nDigits) {
     uint64_t index = 0;
@@ -82,23 +81,15 @@ DEV uint64_t InverseRadicalInverse(uint32_t base, uint64_t inverse, int nDigits)
 }
 DEV int ModI(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
 
-DEV uint64_t HaltonPixelOffset(const DScene &s, int px, int py) {  // halton.cpp:98-118
-    int64_t offset = 0;
-    if (s.sampleStride > 1) {
-        int pm[2] = {ModI(px, 128), ModI(py, 128)};
-        for (int i = 0; i < 2; ++i) {
-            uint64_t dimOffset = InverseRadicalInverse(i == 0 ? 2u : 3u, (uint64_t)pm[i], s.baseExponents[i]);
-            offset += (int64_t)(dimOffset * (uint64_t)(s.sampleStride / s.baseScales[i]) * (uint64_t)s.multInverse[i]);
-        }
-        offset %= (int64_t)s.sampleStride;
-    }
-    return (uint64_t)offset;
+DEV uint64_t HaltonPixelOffset(const DScene &s, int px, int py) {  // halton.cpp:98-118, tabulated at create
+    if (s.sampleStride <= 1) return 0;
+    return s.pixelOffsetTable[ModI(py, 128) * 128 + ModI(px, 128)];
 }
 DEV float SampleDimension(const DScene &s, uint64_t index, int dim) {  // halton.cpp:120-127
     if (s.sampleAtPixelCenter && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return RadicalInverse(s, 0, index >> s.baseExponents[0]);
     else if (dim == 1) return RadicalInverse(s, 1, index / (uint64_t)s.baseScales[1]);
-    else return ScrambledRadicalInverseBase(s.primes[dim], &s.perms[s.primeSums[dim]], index);
+    else return ScrambledRadicalInverseBase(s.primes[dim], s.primeMagic[dim], &s.perms[s.primeSums[dim]], index);
 }
 
 // ------------------------------------------------------------------ lights

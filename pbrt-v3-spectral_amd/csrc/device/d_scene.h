@@ -39,6 +39,8 @@ struct DScene {
     // sampler tables
     const int32_t *primes, *primeSums;
     const uint16_t *perms;
+    const uint64_t *primeMagic;        // ceil(2^64 / prime): a / prime == umul64hi(a, magic) for a < 2^32
+    const uint32_t *pixelOffsetTable;  // 128x128 Halton per-pixel index offsets (halton.cpp:98-118)
     const float *filterTable;  // 256 floats
     float cieY[MI_NSPEC];
     mi_camera camera;
@@ -357,7 +359,7 @@ DEV Ray XfRay(const float *m, const Ray &r) {
 
 // ------------------------------------------------------------------ spheres
 // Root selection shared by Sphere::Intersect / IntersectP (sphere.cpp:49-112,158-214).
-DEV bool SphereRoots(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMaxIn, V3 *rayObjD, V3 *pHitOut, float *phiOut, float *tOut) {
+__device__ __attribute__((noinline)) bool SphereRoots(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMaxIn, V3 *rayObjD, V3 *pHitOut, float *phiOut, float *tOut) {
     V3 oErr, dErr;
     V3 o = XfPointErr(s.w2o, ro, &oErr);
     V3 d = XfVectorErr(s.w2o, rd, &dErr);

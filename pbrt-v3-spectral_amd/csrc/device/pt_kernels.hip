@@ -67,6 +67,7 @@ enum : int {
 struct Pool {
     float *f;
     int *i;
+    uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
@@ -76,7 +77,9 @@ struct DevCounters {
     unsigned long long cameraRays, regularRays, shadowRays, totalPaths, zeroRadiancePaths, pathLengthSum, nodesVisited,
         triTests, badSamples, extendNodes, extendTris, extendRays;
     unsigned long long nextWork;   // global work counter
-    unsigned int alive;            // slots alive after generate
+    unsigned int alive;            // slots alive after generate     } cleared together
+    unsigned int shadowCount;      // entries in Pool::shadowQ        } every iteration
+    unsigned int misCount;         // entries in Pool::misQ           }
     unsigned int pad;
 };
 
@@ -95,6 +98,19 @@ DEV void CountAdd(unsigned long long *ctr, unsigned long long v) {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
 }
 
+// Wave-level compaction: every lane of the wave calls this (convergent); lanes with
+// pred get consecutive queue positions from one atomic per wave (ballot + popcount).
+DEV void QueueAppend(unsigned *counter, uint32_t *queue, bool pred, uint32_t value) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1))] = value;
+}
+
 // ------------------------------------------------------------------ traversal
 struct Hit {
     int prim;
@@ -102,96 +118,120 @@ struct Hit {
 };
 
 // BVHAccel::Intersect / IntersectP (bvh.cpp:662-738) with Bounds3::IntersectP
-// (geometry.h:1420-1447): same visiting order (near child first, leaf primitives in
-// order), so equal-t ties resolve as in the reference.
+// (geometry.h:1420-1447). Per ray the nodes are visited and the leaf primitives tested in
+// the reference's order (near child first), so equal-t ties resolve identically; the
+// SIMT schedule is "while-while": every lane first walks interior nodes until it holds a
+// leaf (cheap iterations, all lanes busy), then the wave tests leaves together (the
+// expensive part runs at high lane utilisation). Quadric (sphere) primitives are
+// postponed to the end of the ray's traversal and tested against the final tMax --
+// the closest hit is order-independent -- so the interval-arithmetic sphere code runs
+// once per wave instead of once per lane-iteration.
+constexpr int MAX_PENDING_SPHERES = 3;
+
 template <bool ANY>
 DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, int (*lds)[BLOCK],
                   unsigned &nodeCount, unsigned &triCount) {
     if (s.nNodes == 0) return false;
     const int lane = threadIdx.x;
-    V3 invDir(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
-    const int neg0 = invDir.x < 0, neg1 = invDir.y < 0, neg2 = invDir.z < 0;
+    const float idx = 1.f / rd.x, idy = 1.f / rd.y, idz = 1.f / rd.z;
+    const bool neg0 = idx < 0, neg1 = idy < 0, neg2 = idz < 0;
     int spill[STACK_SPILL];
     int sp = 0, cur = 0;
     bool found = false;
+    int pend[MAX_PENDING_SPHERES];
+    int nPend = 0;
     const float k = 1 + 2 * gammaf(3);
+    const float4 *__restrict__ nodes = s.nodes;
+    const float4 *__restrict__ primTri = s.primTri;
     while (true) {
-        const float4 na = s.nodes[2 * cur], nb = s.nodes[2 * cur + 1];
-        ++nodeCount;
-        const float bminx = na.x, bminy = na.y, bminz = na.z, bmaxx = na.w, bmaxy = nb.x, bmaxz = nb.y;
-        const int offset = __float_as_int(nb.z);
-        const unsigned meta = __float_as_uint(nb.w);
-        const int nPrims = meta & 0xffff, axis = (meta >> 16) & 0xff;
-        bool hitBox;
-        {
-            float tMin = ((neg0 ? bmaxx : bminx) - ro.x) * invDir.x;
-            float tMx = ((neg0 ? bminx : bmaxx) - ro.x) * invDir.x;
-            float tyMin = ((neg1 ? bmaxy : bminy) - ro.y) * invDir.y;
-            float tyMax = ((neg1 ? bminy : bmaxy) - ro.y) * invDir.y;
-            tMx *= k;
-            tyMax *= k;
-            hitBox = !(tMin > tyMax || tyMin > tMx);
-            if (hitBox) {
+        int leafOffset = 0, leafCount = 0;
+        // ---- phase 1: interior nodes
+        while (cur >= 0) {
+            const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
+            ++nodeCount;
+            const int offset = __float_as_int(nb.z);
+            const unsigned meta = __float_as_uint(nb.w);
+            bool hitBox;
+            {
+                float tMin = ((neg0 ? na.w : na.x) - ro.x) * idx;
+                float tMx = ((neg0 ? na.x : na.w) - ro.x) * idx;
+                float tyMin = ((neg1 ? nb.x : na.y) - ro.y) * idy;
+                float tyMax = ((neg1 ? na.y : nb.x) - ro.y) * idy;
+                tMx *= k;
+                tyMax *= k;
+                hitBox = !(tMin > tyMax || tyMin > tMx);
                 if (tyMin > tMin) tMin = tyMin;
                 if (tyMax < tMx) tMx = tyMax;
-                float tzMin = ((neg2 ? bmaxz : bminz) - ro.z) * invDir.z;
-                float tzMax = ((neg2 ? bminz : bmaxz) - ro.z) * invDir.z;
+                float tzMin = ((neg2 ? nb.y : na.z) - ro.z) * idz;
+                float tzMax = ((neg2 ? na.z : nb.y) - ro.z) * idz;
                 tzMax *= k;
-                if (tMin > tzMax || tzMin > tMx) hitBox = false;
-                else {
-                    if (tzMin > tMin) tMin = tzMin;
-                    if (tzMax < tMx) tMx = tzMax;
-                    hitBox = (tMin < tMax) && (tMx > 0);
-                }
+                hitBox = hitBox && !(tMin > tzMax || tzMin > tMx);
+                if (tzMin > tMin) tMin = tzMin;
+                if (tzMax < tMx) tMx = tzMax;
+                hitBox = hitBox && (tMin < tMax) && (tMx > 0);
             }
-        }
-        bool pop = true;
-        if (hitBox) {
-            if (nPrims > 0) {
-                for (int i = 0; i < nPrims; ++i) {
-                    const int prim = offset + i;
-                    const float4 v0 = s.primTri[3 * prim];
-                    const unsigned pf = __float_as_uint(v0.w);
-                    if (pf & PRIM_FLAG_SPHERE) {
-                        const float4 v1 = s.primTri[3 * prim + 1];
-                        const int sph = __float_as_int(v1.w);
-                        float t;
-                        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
-                            if (ANY) return true;
-                            tMax = t;
-                            hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
-                            found = true;
-                        }
-                    } else {
-                        const float4 v1 = s.primTri[3 * prim + 1], v2 = s.primTri[3 * prim + 2];
-                        ++triCount;
-                        TriHit th;
-                        if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
-                            if (ANY) return true;
-                            if (!(pf & PRIM_FLAG_DEGENERATE)) {
-                                tMax = th.t;
-                                hit->prim = prim; hit->t = th.t; hit->b0 = th.b0; hit->b1 = th.b1; hit->b2 = th.b2;
-                                found = true;
-                            }
-                        }
-                    }
-                }
-            } else {
-                int farNode, nearNode;
-                const int negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
-                if (negAxis) { farNode = cur + 1; nearNode = offset; }
-                else { farNode = offset; nearNode = cur + 1; }
+            const int nPrims = meta & 0xffff;
+            if (hitBox && nPrims == 0) {
+                const int axis = (meta >> 16) & 0xff;
+                const bool negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
+                const int farNode = negAxis ? cur + 1 : offset;
+                const int nearNode = negAxis ? offset : cur + 1;
                 if (sp < STACK_LDS) lds[sp][lane] = farNode;
                 else spill[sp - STACK_LDS] = farNode;
                 ++sp;
                 cur = nearNode;
-                pop = false;
+                continue;
+            }
+            // leaf or miss: the next node comes from the stack either way
+            if (sp == 0) cur = -1;
+            else { --sp; cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS]; }
+            if (hitBox) { leafOffset = offset; leafCount = nPrims; break; }
+        }
+        if (leafCount == 0) break;
+        // ---- phase 2: leaf primitives, in order, against the ray's current tMax
+        for (int i = 0; i < leafCount; ++i) {
+            const int prim = leafOffset + i;
+            const float4 v0 = primTri[3 * prim];
+            const unsigned pf = __float_as_uint(v0.w);
+            if (pf & PRIM_FLAG_SPHERE) {
+                if (nPend < MAX_PENDING_SPHERES) pend[nPend++] = prim;
+                else {  // more quadrics than postponement slots: test this one now
+                    const int sph = __float_as_int(primTri[3 * prim + 1].w);
+                    float t;
+                    if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+                        if (ANY) return true;
+                        tMax = t;
+                        hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+                        found = true;
+                    }
+                }
+                continue;
+            }
+            const float4 v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
+            ++triCount;
+            TriHit th;
+            if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
+                if (ANY) return true;
+                if (!(pf & PRIM_FLAG_DEGENERATE)) {
+                    tMax = th.t;
+                    hit->prim = prim; hit->t = th.t; hit->b0 = th.b0; hit->b1 = th.b1; hit->b2 = th.b2;
+                    found = true;
+                }
             }
         }
-        if (pop) {
-            if (sp == 0) break;
-            --sp;
-            cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS];
+    }
+    // ---- postponed quadrics
+    for (int j = 0; j < nPend; ++j) {
+        {
+            const int prim = (j == 0) ? pend[0] : ((j == 1) ? pend[1] : pend[2]);
+            const int sph = __float_as_int(primTri[3 * prim + 1].w);
+            float t;
+            if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+                if (ANY) return true;
+                tMax = t;
+                hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+                found = true;
+            }
         }
     }
     return found;
@@ -217,64 +257,88 @@ DEV void CameraRay(const DScene &s, float pFilmX, float pFilmY, float lensU, flo
     *out = XfRay(cam.camera_to_world, ray);
 }
 
-// FilmTile::AddSample + MergeFilmTile (film.h:123-163, film.cpp:124-142) as float
-// atomics into the resident film [pixel][32] (31 bins + filter weight sum).
-DEV void FilmAddSample(const DScene &s, const Pool &pool, uint32_t slot, float *film, DevCounters *ctr, unsigned &bad) {
-    // guards of SamplerIntegrator::Render, integrator.cpp:295-316
-    float yy = 0.f;
-    bool hasNaN = false;
-    for (int b = 0; b < MI_NSPEC; ++b) {
-        float v = pool.F(P_L + b, slot);
-        hasNaN |= isnanf_(v);
-        yy += s.cieY[b] * v;
-    }
-    float y = YScale(yy);
-    bool zero = false;
-    if (hasNaN) zero = true;
-    else if ((double)y < -1e-5) zero = true;
-    else if (isinff(y)) zero = true;
-    if (zero) ++bad;
-    float scaleL = 1.f;
-    bool clampL = false;
-    if (!zero && y > s.maxSampleLuminance) { clampL = true; scaleL = s.maxSampleLuminance / y; }
-    const float pfx = pool.F(P_FILMX, slot), pfy = pool.F(P_FILMY, slot);
-    const int filterTableSize = 16;
-    float dx = pfx - 0.5f, dy = pfy - 0.5f;
-    int p0x = (int)ceilf(dx - s.filterRadius[0]), p0y = (int)ceilf(dy - s.filterRadius[1]);
-    int p1x = (int)floorf(dx + s.filterRadius[0]) + 1, p1y = (int)floorf(dy + s.filterRadius[1]) + 1;
-    p0x = max(p0x, s.croppedBounds[0]); p0y = max(p0y, s.croppedBounds[1]);
-    p1x = min(p1x, s.croppedBounds[2]); p1y = min(p1y, s.croppedBounds[3]);
-    const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
-    const int w = s.croppedBounds[2] - s.croppedBounds[0];
-    for (int y2 = p0y; y2 < p1y; ++y2) {
-        float fy = absf((y2 - dy) * invRy * filterTableSize);
-        int iy = min((int)floorf(fy), filterTableSize - 1);
-        for (int x2 = p0x; x2 < p1x; ++x2) {
-            float fx = absf((x2 - dx) * invRx * filterTableSize);
-            int ix = min((int)floorf(fx), filterTableSize - 1);
-            float fw = s.filterTable[iy * filterTableSize + ix];
-            size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
-            float *dst = film + pix * 32;
-            if (!zero) {
-                for (int b = 0; b < MI_NSPEC; ++b) {
-                    float v = pool.F(P_L + b, slot);
-                    if (clampL) v *= scaleL;
-                    atomicAdd(dst + b, (v * 1.f) * fw);  // L * sampleWeight * filterWeight
-                }
-            }
-            atomicAdd(dst + 31, fw);
-        }
-    }
-}
-
+// FilmTile::AddSample + MergeFilmTile (film.h:123-163, film.cpp:124-142) as float atomics
+// into the resident film [pixel][32] (31 bins + filter-weight sum = one 128-B row).
+// Wave-cooperative: each finished lane stages its guarded radiance in LDS (row stride 33
+// words: conflict-free both ways); then the wave walks the finished lanes two at a time,
+// half-wave h adding sample h's 32 values to its pixel row -- every atomic
+// wave-instruction touches two full 128-B rows (the full-rate shape for gfx950 float
+// atomics) instead of 64 rows.
 __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *film, DevCounters *ctr, WorkDesc wd) {
+    __shared__ float sL[BLOCK * 33];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = slot < pool.n;
     int flags = valid ? pool.I(I_FLAGS, slot) : 0;
     unsigned bad = 0, cam = 0;
-    if (valid && (flags & F_FINISHED)) {
-        FilmAddSample(s, pool, slot, film, ctr, bad);
+    const int lane = threadIdx.x & 63;
+    const int waveBase = threadIdx.x & ~63;
+    const bool fin = valid && (flags & F_FINISHED);
+    float myFx = 0, myFy = 0;
+    int myZero = 0;
+    if (fin) {
+        // guards of SamplerIntegrator::Render, integrator.cpp:295-316
+        float yy = 0.f;
+        bool hasNaN = false;
+        float *row = &sL[threadIdx.x * 33];
+        for (int b = 0; b < MI_NSPEC; ++b) {
+            float v = pool.F(P_L + b, slot);
+            hasNaN |= isnanf_(v);
+            yy += s.cieY[b] * v;
+            row[b] = v;
+        }
+        float y = YScale(yy);
+        bool zero = false;
+        if (hasNaN) zero = true;
+        else if ((double)y < -1e-5) zero = true;
+        else if (isinff(y)) zero = true;
+        if (zero) ++bad;
+        else if (y > s.maxSampleLuminance) {  // FilmTile::AddSample clamp, film.h:126-127
+            const float scaleL = s.maxSampleLuminance / y;
+            for (int b = 0; b < MI_NSPEC; ++b) row[b] *= scaleL;
+        }
+        myZero = zero ? 1 : 0;
+        myFx = pool.F(P_FILMX, slot);
+        myFy = pool.F(P_FILMY, slot);
         flags = 0;
+    }
+    __syncthreads();
+    {
+        unsigned long long mask = __ballot(fin);
+        const int half = lane >> 5, bin = lane & 31;
+        const int filterTableSize = 16;
+        const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
+        const int w = s.croppedBounds[2] - s.croppedBounds[0];
+        while (mask) {
+            const int j0 = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            int j1 = -1;
+            if (mask) { j1 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+            const int j = half ? j1 : j0;
+            const int src = j >= 0 ? j : 0;
+            const float pfx = __shfl(myFx, src, 64), pfy = __shfl(myFy, src, 64);
+            const int zero = __shfl(myZero, src, 64);
+            if (j >= 0) {
+                const float val = (bin < MI_NSPEC) ? sL[(waveBase + j) * 33 + bin] : 0.f;
+                float dx = pfx - 0.5f, dy = pfy - 0.5f;
+                int p0x = (int)ceilf(dx - s.filterRadius[0]), p0y = (int)ceilf(dy - s.filterRadius[1]);
+                int p1x = (int)floorf(dx + s.filterRadius[0]) + 1, p1y = (int)floorf(dy + s.filterRadius[1]) + 1;
+                p0x = max(p0x, s.croppedBounds[0]); p0y = max(p0y, s.croppedBounds[1]);
+                p1x = min(p1x, s.croppedBounds[2]); p1y = min(p1y, s.croppedBounds[3]);
+                for (int y2 = p0y; y2 < p1y; ++y2) {
+                    float fy = absf((y2 - dy) * invRy * filterTableSize);
+                    int iy = min((int)floorf(fy), filterTableSize - 1);
+                    for (int x2 = p0x; x2 < p1x; ++x2) {
+                        float fx = absf((x2 - dx) * invRx * filterTableSize);
+                        int ix = min((int)floorf(fx), filterTableSize - 1);
+                        float fw = s.filterTable[iy * filterTableSize + ix];
+                        size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
+                        float *dst = film + pix * 32 + bin;
+                        if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
+                        else if (!zero) atomicAdd(dst, (val * 1.f) * fw);      // contribSum += L * sampleWeight * fw
+                    }
+                }
+            }
+        }
     }
     // refill: up to 4 tries to draw a work item that maps inside the sample / pixel bounds
     bool need = valid && flags == 0;
@@ -374,7 +438,8 @@ DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimens
 // ------------------------------------------------------------------ shade
 __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned totalPaths = 0, pathLen = 0;
+    unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
+    bool wantShadow = false, wantMis = false;
     if (slot < pool.n) {
         int flags = pool.I(I_FLAGS, slot);
         if (flags & F_ALIVE) {
@@ -555,82 +620,89 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                 newFlags |= F_ALIVE;
                 pool.I(I_BOUNCES, slot) = bounces + 1;
             }
-            if (!passThrough) pool.I(I_FLAGS, slot) = newFlags;
+            if (!passThrough) {
+                wantShadow = (newFlags & F_SHADOW) != 0;
+                wantMis = (newFlags & F_MIS) != 0;
+                // a direct-lighting estimate with neither ray pending is already known to be black
+                if ((newFlags & F_NEE) && !wantShadow && !wantMis) { ++zeroNow; newFlags &= ~F_NEE; }
+                pool.I(I_FLAGS, slot) = newFlags;
+            }
         }
     }
+    QueueAppend(&ctr->shadowCount, pool.shadowQ, wantShadow, slot);
+    QueueAppend(&ctr->misCount, pool.misQ, wantMis, slot);
     CountAdd(&ctr->totalPaths, totalPaths);
     CountAdd(&ctr->pathLengthSum, pathLen);
+    CountAdd(&ctr->zeroRadiancePaths, zeroNow);
 }
 
 // ------------------------------------------------------------------ shadow rays
 __global__ void __launch_bounds__(BLOCK) k_shadow(DScene s, Pool pool, DevCounters *ctr) {
     __shared__ int lds[STACK_LDS][BLOCK];
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned nodes = 0, tris = 0, rays = 0;
-    if (slot < pool.n) {
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned nodes = 0, tris = 0, rays = 0, zero = 0;
+    if (qi < ctr->shadowCount) {
+        const uint32_t slot = pool.shadowQ[qi];
         int flags = pool.I(I_FLAGS, slot);
-        if (flags & F_SHADOW) {
-            V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
-            V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
-            Hit h;
-            ++rays;
-            bool occluded = Traverse<true>(s, ro, rd, 1 - kShadowEpsilon, &h, lds, nodes, tris);
-            if (!occluded) {
-                bool nonBlack = false;
-                for (int b = 0; b < MI_NSPEC; ++b) {
-                    float c = pool.F(P_LNEE + b, slot);
-                    nonBlack |= (c != 0.f);
-                    pool.F(P_L + b, slot) += c;
-                }
-                if (nonBlack) flags |= F_A_ADDED;
+        V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
+        V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
+        Hit h;
+        ++rays;
+        bool occluded = Traverse<true>(s, ro, rd, 1 - kShadowEpsilon, &h, lds, nodes, tris);
+        bool added = false;
+        if (!occluded) {
+            for (int b = 0; b < MI_NSPEC; ++b) {
+                float c = pool.F(P_LNEE + b, slot);
+                added |= (c != 0.f);
+                pool.F(P_L + b, slot) += c;
             }
-            pool.I(I_FLAGS, slot) = flags & ~F_SHADOW;
         }
+        flags &= ~F_SHADOW;
+        if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_mis closes the estimate
+        else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
+        pool.I(I_FLAGS, slot) = flags;
     }
     CountAdd(&ctr->shadowRays, rays);
     CountAdd(&ctr->nodesVisited, nodes);
     CountAdd(&ctr->triTests, tris);
+    CountAdd(&ctr->zeroRadiancePaths, zero);
 }
 
 // ------------------------------------------------------------------ MIS rays + NEE bookkeeping
 __global__ void __launch_bounds__(BLOCK) k_mis(DScene s, Pool pool, DevCounters *ctr) {
     __shared__ int lds[STACK_LDS][BLOCK];
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned nodes = 0, tris = 0, rays = 0, zero = 0;
-    if (slot < pool.n) {
+    if (qi < ctr->misCount) {
+        const uint32_t slot = pool.misQ[qi];
         int flags = pool.I(I_FLAGS, slot);
-        if (flags & F_MIS) {
-            V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
-            V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
-            Hit h;
-            h.prim = -1;
-            ++rays;
-            if (Traverse<false>(s, ro, rd, kInfinity, &h, lds, nodes, tris)) {
-                const int lightNum = pool.I(I_MISLIGHT, slot);
-                if (s.prims[h.prim].area_light == lightNum) {
-                    const mi_light &l = s.lights[lightNum];
-                    bool emit = l.two_sided != 0;
-                    if (!emit) {
-                        SurfaceInteraction li;
-                        HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
-                        emit = Dot(li.n, -rd) > 0;
-                    }
-                    if (emit) {
-                        bool nonBlack = false;
-                        for (int b = 0; b < MI_NSPEC; ++b) {
-                            float c = pool.F(P_LMIS + b, slot);
-                            nonBlack |= (c != 0.f);
-                            pool.F(P_L + b, slot) += c;
-                        }
-                        if (nonBlack) flags |= F_B_ADDED;
+        V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
+        V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
+        Hit h;
+        h.prim = -1;
+        ++rays;
+        bool added = false;
+        if (Traverse<false>(s, ro, rd, kInfinity, &h, lds, nodes, tris)) {
+            const int lightNum = pool.I(I_MISLIGHT, slot);
+            if (s.prims[h.prim].area_light == lightNum) {
+                const mi_light &l = s.lights[lightNum];
+                bool emit = l.two_sided != 0;
+                if (!emit) {
+                    SurfaceInteraction li;
+                    HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
+                    emit = Dot(li.n, -rd) > 0;
+                }
+                if (emit) {
+                    for (int b = 0; b < MI_NSPEC; ++b) {
+                        float c = pool.F(P_LMIS + b, slot);
+                        added |= (c != 0.f);
+                        pool.F(P_L + b, slot) += c;
                     }
                 }
             }
         }
-        if (flags & F_NEE) {
-            if (!(flags & (F_A_ADDED | F_B_ADDED))) ++zero;
-            pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
-        }
+        if (!added && !(flags & F_A_ADDED)) ++zero;
+        pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
     }
     CountAdd(&ctr->regularRays, rays);
     CountAdd(&ctr->nodesVisited, nodes);
@@ -762,9 +834,14 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
 
 int EnsurePool(mi_pt *pt, uint32_t n) {
     if (pt->pool.n == n && pt->pool.f) return MI_OK;
-    if (pt->pool.f) { hipFree(pt->pool.f); hipFree(pt->pool.i); pt->pool.f = nullptr; pt->pool.i = nullptr; }
+    if (pt->pool.f) {
+        hipFree(pt->pool.f); hipFree(pt->pool.i); hipFree(pt->pool.shadowQ); hipFree(pt->pool.misQ);
+        pt->pool.f = nullptr; pt->pool.i = nullptr; pt->pool.shadowQ = pt->pool.misQ = nullptr;
+    }
     HIPCHK(hipMalloc((void **)&pt->pool.f, (size_t)P_COUNT * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&pt->pool.i, (size_t)I_COUNT * n * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&pt->pool.shadowQ, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&pt->pool.misQ, (size_t)n * sizeof(uint32_t)));
     pt->pool.n = n;
     return MI_OK;
 }
@@ -885,6 +962,35 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
     UP(d->sampler.perms, d->sampler.n_perms, s.perms);
     UP(d->film.filter_table, 256, s.filterTable);
+    {   // division magics and the per-pixel Halton offsets (GetIndexForSample, halton.cpp:98-118)
+        std::vector<uint64_t> magic(d->sampler.n_dims);
+        for (int i = 0; i < d->sampler.n_dims; ++i) {
+            const uint64_t p = (uint64_t)d->sampler.primes[i];
+            magic[i] = (~0ull) / p + 1;  // ceil(2^64 / p) for p not a power of two; p == 2 is never divided here
+        }
+        UP(magic.data(), magic.size(), s.primeMagic);
+        std::vector<uint32_t> table(128 * 128, 0);
+        const mi_sampler &sm = d->sampler;
+        if (sm.sample_stride > 1) {
+            auto inverseRadicalInverse = [](uint64_t base, uint64_t inverse, int nDigits) {
+                uint64_t index = 0;
+                for (int i = 0; i < nDigits; ++i) { uint64_t digit = inverse % base; inverse /= base; index = index * base + digit; }
+                return index;
+            };
+            for (int py = 0; py < 128; ++py)
+                for (int px = 0; px < 128; ++px) {
+                    int64_t offset = 0;
+                    const int pm[2] = {px, py};
+                    for (int i = 0; i < 2; ++i) {
+                        uint64_t dimOffset = inverseRadicalInverse(i == 0 ? 2 : 3, (uint64_t)pm[i], sm.base_exponents[i]);
+                        offset += (int64_t)(dimOffset * (uint64_t)(sm.sample_stride / sm.base_scales[i]) * (uint64_t)sm.mult_inverse[i]);
+                    }
+                    offset %= (int64_t)sm.sample_stride;
+                    table[py * 128 + px] = (uint32_t)offset;
+                }
+        }
+        UP(table.data(), table.size(), s.pixelOffsetTable);
+    }
     s.nNodes = d->n_nodes; s.nPrims = d->n_prims; s.nLights = d->n_lights; s.nMaterials = d->n_materials;
     for (int i = 0; i < MI_NSPEC; ++i) s.cieY[i] = d->cie_y[i];
     s.camera = d->camera;
@@ -978,7 +1084,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     bool prevFull = false, havePrev = false;
     while (true) {
         hipEvent_t *ev = pt->evIter[set];
-        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 3 * sizeof(unsigned), st));
         HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
         HIPCHK(hipEventRecord(ev[1], st));
@@ -1074,6 +1180,8 @@ void mi_pt_destroy(mi_pt *pt) {
     if (pt->film) hipFree(pt->film);
     if (pt->pool.f) hipFree(pt->pool.f);
     if (pt->pool.i) hipFree(pt->pool.i);
+    if (pt->pool.shadowQ) hipFree(pt->pool.shadowQ);
+    if (pt->pool.misQ) hipFree(pt->pool.misQ);
     if (pt->ctr) hipFree(pt->ctr);
     if (pt->haveEvents) {
         hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop);
