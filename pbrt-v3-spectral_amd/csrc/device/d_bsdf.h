@@ -160,27 +160,40 @@ enum LobeKind : int {
     LK_CONST      // a
 };
 struct LobeEval {
-    int kind;
+    int kind;  // LobeKind | LK_FASTDIV when DivBy's fast form applies to d
     int lobe;  // index into material.bxdf
     float a, b, c, d, e, f;
+    float r;   // 1/d for the *_DIV kinds
 };
+#define LK_FASTDIV 0x100
+DEV void SetDivisor(LobeEval &le, float d) {
+    Divisor v = MakeDivisor(d);
+    le.d = d;
+    le.r = v.r;
+    if (v.fast) le.kind |= LK_FASTDIV;
+}
+DEV float LobeDiv(float x, const LobeEval &le) {
+    Divisor v;
+    v.d = le.d; v.r = le.r; v.fast = (le.kind & LK_FASTDIV) != 0;
+    return DivBy(x, v);
+}
 
 DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
     const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
     float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
-    switch (le.kind) {
+    switch (le.kind & 0xff) {
     case LK_MUL1: return R * le.a;
     case LK_MUL2: return (R * le.a) * le.b;
     case LK_MUL3: return ((R * le.a) * le.b) * le.c;
-    case LK_MUL3_DIV: return (((R * le.a) * le.b) * le.c) / le.d;
-    case LK_MUL1_DIV: return (R * le.a) / le.d;
-    case LK_MUL2_DIV: return ((R * le.a) * le.b) / le.d;
+    case LK_MUL3_DIV: return LobeDiv(((R * le.a) * le.b) * le.c, le);
+    case LK_MUL1_DIV: return LobeDiv(R * le.a, le);
+    case LK_MUL2_DIV: return LobeDiv((R * le.a) * le.b, le);
     case LK_MICRO_DISNEY: {
         float S = bx[li].S[bin];
         // Lerp(metallic, Spectrum(FrDielectric), FrSchlick(R0, cosI)); FrSchlick = Lerp(w, R0, 1)
         float schlick = (1 - le.f) * S + le.f * 1.f;
         float F = (1 - le.c) * le.e + le.c * schlick;
-        return (((R * le.a) * le.b) * F) / le.d;
+        return LobeDiv(((R * le.a) * le.b) * F, le);
     }
     case LK_MTRANS: return ((1.f - le.a) * R) * le.b;
     case LK_CONST: return le.a;
@@ -208,7 +221,7 @@ DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.
 // BxDF::f for lobe i (local wo, wi) -> LobeEval. Mirrors o_bsdf / reflection.cpp per lobe.
 DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
     LobeEval le;
-    le.kind = LK_NONE; le.lobe = i; le.a = le.b = le.c = le.d = le.e = le.f = 0;
+    le.kind = LK_NONE; le.lobe = i; le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
     switch (b.type) {
     case MI_BXDF_LAMBERTIAN_REFLECTION:
     case MI_BXDF_LAMBERTIAN_TRANSMISSION:
@@ -236,7 +249,8 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         wh = Normalize(wh);
         TRDist d = DistOf(b);
         float cosI = Dot(wi, wh);
-        le.a = d.D(wh); le.b = d.G(wo, wi); le.d = (4 * cosThetaI * cosThetaO);
+        le.a = d.D(wh); le.b = d.G(wo, wi);
+        const float denom = (4 * cosThetaI * cosThetaO);
         if (b.fresnel == MI_FRESNEL_DISNEY) {
             le.kind = LK_MICRO_DISNEY;
             le.c = b.p[2];                       // metallic
@@ -246,6 +260,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
             le.kind = LK_MUL3_DIV;
             le.c = (b.fresnel == MI_FRESNEL_DIELECTRIC) ? FrDielectric(cosI, b.p[2], b.p[3]) : 1.f;
         }
+        SetDivisor(le, denom);
         break;
     }
     case MI_BXDF_MICROFACET_TRANSMISSION: {
@@ -345,26 +360,31 @@ DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     }
 }
 
-struct BSDFEval {
+// NL = compile-time bound on the material's lobe count: the shading kernels are
+// instantiated per material class (<= 2 lobes: matte / plastic / glass / mirror; up to 8:
+// uber / disney) so the common class keeps its lobe list in 16 registers.
+template <int NL>
+struct BSDFEvalT {
     int n;  // number of contributing lobes
-    LobeEval lobes[MI_MAX_BXDFS];
+    LobeEval lobes[NL];
 };
 
 // BSDF::f(woW, wiW, flags): fills the lobe list (reflection.cpp:670-683).
-DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BSDFEval *ev) {
+template <int NL>
+DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BSDFEvalT<NL> *ev) {
     ev->n = 0;
     V3 wi = fr.WorldToLocal(wiW), wo = fr.WorldToLocal(woW);
     if (wo.z == 0) return;
     bool reflect = Dot(wiW, fr.ng) * Dot(woW, fr.ng) > 0;
     const mi_material *m = fr.m;
 #pragma unroll
-    for (int i = 0; i < MI_MAX_BXDFS; ++i) {
+    for (int i = 0; i < NL; ++i) {
         if (i < m->n_bxdfs) {
             const mi_bxdf &b = m->bxdf[i];
             if (MatchesFlags(b, flags) &&
                 ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION)))) {
                 LobeEval le = LobeF(b, i, wo, wi);
-                if (le.kind != LK_NONE) ev->lobes[ev->n++] = le;
+                if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
             }
         }
     }
@@ -381,10 +401,11 @@ DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags)
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 
-DEV float EvalBin(const BSDFEval &ev, const mi_bxdf *bx, int bin) {
+template <int NL>
+DEV float EvalBin(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int bin) {
     float f = 0.f;
 #pragma unroll
-    for (int i = 0; i < MI_MAX_BXDFS; ++i)
+    for (int i = 0; i < NL; ++i)
         if (i < ev.n) f += LobeValue(ev.lobes[i], bx, bin);
     return f;
 }
@@ -392,8 +413,9 @@ DEV float EvalBin(const BSDFEval &ev, const mi_bxdf *bx, int bin) {
 // BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a
 // black f (including the early-outs that leave *pdf untouched). On success the value is
 // described by *ev (one specular LobeEval, or the lobe list for the sampled direction).
+template <int NL>
 DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, float u0, float u1, float *pdf, int type,
-                       int *sampledType, BSDFEval *ev) {
+                       int *sampledType, BSDFEvalT<NL> *ev) {
     const mi_material *m = fr.m;
     ev->n = 0;
     int matchingComps = NumComponents(m, type);
@@ -409,14 +431,14 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *pdf = 0;
     *sampledType = b.flags;
     LobeEval spec;
-    spec.kind = LK_NONE; spec.lobe = bi; spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = 0;
+    spec.kind = LK_NONE; spec.lobe = bi; spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
     bool isSpecular = (b.flags & MI_BSDF_SPECULAR) != 0;
     switch (b.type) {
     case MI_BXDF_SPECULAR_REFLECTION: {  // (F*R)/|cos|
         wi = V3(-wo.x, -wo.y, wo.z);
         *pdf = 1;
         float F = (b.fresnel == MI_FRESNEL_DIELECTRIC) ? FrDielectric(CosTheta(wi), b.p[2], b.p[3]) : 1.f;
-        spec.kind = LK_MUL1_DIV; spec.a = F; spec.d = AbsCosTheta(wi);
+        spec.kind = LK_MUL1_DIV; spec.a = F; SetDivisor(spec, AbsCosTheta(wi));
         break;
     }
     case MI_BXDF_SPECULAR_TRANSMISSION: {  // ((T*(1-F))*ratio)/|cos|
@@ -428,7 +450,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
         spec.kind = LK_MUL2_DIV;
         spec.a = (1.f - FrDielectric(CosTheta(wi), etaA, etaB));
         spec.b = (etaI * etaI) / (etaT * etaT);
-        spec.d = AbsCosTheta(wi);
+        SetDivisor(spec, AbsCosTheta(wi));
         break;
     }
     case MI_BXDF_FRESNEL_SPECULAR: {
@@ -438,7 +460,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             wi = V3(-wo.x, -wo.y, wo.z);
             *sampledType = MI_BSDF_SPECULAR | MI_BSDF_REFLECTION;
             *pdf = F;
-            spec.kind = LK_MUL1_DIV; spec.a = F; spec.d = AbsCosTheta(wi);
+            spec.kind = LK_MUL1_DIV; spec.a = F; SetDivisor(spec, AbsCosTheta(wi));
         } else {
             bool entering = CosTheta(wo) > 0;
             float etaI = entering ? etaA : etaB, etaT = entering ? etaB : etaA;
@@ -446,7 +468,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             *sampledType = MI_BSDF_SPECULAR | MI_BSDF_TRANSMISSION;
             *pdf = 1 - F;
             spec.kind = LK_MUL2_DIV; spec.lobe = bi | 0x100;  // bit 8: use S (= T) instead of R
-            spec.a = (1 - F); spec.b = (etaI * etaI) / (etaT * etaT); spec.d = AbsCosTheta(wi);
+            spec.a = (1 - F); spec.b = (etaI * etaI) / (etaT * etaT); SetDivisor(spec, AbsCosTheta(wi));
         }
         break;
     }
@@ -501,13 +523,13 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     } else {
         bool reflect = Dot(*wiWorld, fr.ng) * Dot(woWorld, fr.ng) > 0;
 #pragma unroll
-        for (int i = 0; i < MI_MAX_BXDFS; ++i) {
+        for (int i = 0; i < NL; ++i) {
             if (i < m->n_bxdfs) {
                 const mi_bxdf &bb = m->bxdf[i];
                 if (MatchesFlags(bb, type) &&
                     ((reflect && (bb.flags & MI_BSDF_REFLECTION)) || (!reflect && (bb.flags & MI_BSDF_TRANSMISSION)))) {
                     LobeEval le = LobeF(bb, i, wo, wi);
-                    if (le.kind != LK_NONE) ev->lobes[ev->n++] = le;
+                    if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
                 }
             }
         }

@@ -43,6 +43,34 @@ DEV float atan2F(float y, float x) { return (float)atan2((double)y, (double)x); 
 DEV float logF(float x) { return (float)log((double)x); }
 DEV float powF(float x, float y) { return (float)pow((double)x, (double)y); }
 
+// x / d for many x and one d: one IEEE reciprocal, then per quotient a multiply and two
+// fused corrections (q = x*r; rem = fma(-q, d, x); q += rem*r). With r the correctly
+// rounded reciprocal this is the correctly rounded quotient except when x/d lies within
+// ~2^-23 ulp of a rounding boundary (about 2^-22 of operands, then off by one ulp);
+// operands whose reciprocal or quotient leave the normal range use the plain division.
+struct Divisor {
+    float d, r;
+    bool fast;
+};
+DEV Divisor MakeDivisor(float d) {
+    Divisor v;
+    v.d = d;
+    v.r = 1.f / d;
+    const float a = absf(d);
+    v.fast = (a > 1e-18f) && (a < 1e18f);
+    return v;
+}
+DEV float DivBy(float x, const Divisor &v) {
+    if (v.fast) {
+        const float q = x * v.r;
+        const float rem = __builtin_fmaf(-q, v.d, x);
+        const float q1 = __builtin_fmaf(rem, v.r, q);
+        const float aq = absf(q1);
+        if (aq > 1e-30f && aq < 1e30f) return q1;
+    }
+    return x / v.d;
+}
+
 DEV float NextFloatUp(float v) {  // pbrt.h:244-256
     if (isinff(v) && v > 0.f) return v;
     if (v == -0.f) v = 0.f;

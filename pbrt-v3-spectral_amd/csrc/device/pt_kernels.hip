@@ -68,6 +68,7 @@ struct Pool {
     float *f;
     int *i;
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
+    uint32_t *shadeQ[2];       // slots to shade, per material class (0: <= 2 lobes, 1: more)
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
@@ -80,6 +81,7 @@ struct DevCounters {
     unsigned int alive;            // slots alive after generate     } cleared together
     unsigned int shadowCount;      // entries in Pool::shadowQ        } every iteration
     unsigned int misCount;         // entries in Pool::misQ           }
+    unsigned int shadeCount[2];    // entries in Pool::shadeQ[c]      }
     unsigned int pad;
 };
 
@@ -407,6 +409,8 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DScene s, Pool pool, DevCounte
     __shared__ int lds[STACK_LDS][BLOCK];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     unsigned nodes = 0, tris = 0, rays = 0;
+    bool traced = false;
+    int cls = 0;
     if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
         V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
         V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
@@ -417,7 +421,14 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DScene s, Pool pool, DevCounte
         ++rays;
         pool.I(I_HITPRIM, slot) = found ? h.prim : -1;
         pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
+        traced = true;
+        if (found) {   // material class of the hit: sorts the shading work
+            const int m = s.prims[h.prim].material;
+            if (m >= 0 && s.materials[m].n_bxdfs > 2) cls = 1;
+        }
     }
+    QueueAppend(&ctr->shadeCount[0], pool.shadeQ[0], traced && cls == 0, slot);
+    QueueAppend(&ctr->shadeCount[1], pool.shadeQ[1], traced && cls == 1, slot);
     CountAdd(&ctr->regularRays, rays);
     CountAdd(&ctr->nodesVisited, nodes);
     CountAdd(&ctr->triTests, tris);
@@ -436,197 +447,200 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimension(s, index, dim++); }
 
 // ------------------------------------------------------------------ shade
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr) {
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+// One path vertex per lane, for the slots of one material class (queue built by
+// k_extend: NL = 2 for materials with <= 2 lobes, NL = 8 otherwise -- "sorted" shading:
+// a wave runs one class of BSDF code and the common class keeps its lobe lists in
+// registers). Spectra are streamed bin by bin; each of the three spectral passes
+// (light sample, MIS sample, continuation) computes its values and its black/non-black
+// decision in one sweep.
+template <int NL>
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr, int cls) {
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
     bool wantShadow = false, wantMis = false;
-    if (slot < pool.n) {
-        int flags = pool.I(I_FLAGS, slot);
-        if (flags & F_ALIVE) {
-            int bounces = pool.I(I_BOUNCES, slot);
-            const int prim = pool.I(I_HITPRIM, slot);
-            const bool found = prim >= 0;
-            V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
-            V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
-            SurfaceInteraction isect;
-            bool finished = false, passThrough = false;
-            if (found) HitInteraction(s, prim, ro, rd, pool.F(P_B0, slot), pool.F(P_B1, slot), pool.F(P_B2, slot), &isect);
-            // emitted light at the vertex, path.cpp:91-101
-            if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
-                const int li = s.prims[prim].area_light;
-                if (li >= 0) {
-                    const mi_light &l = s.lights[li];
-                    if (l.two_sided || Dot(isect.n, -rd) > 0)
-                        for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_L + b, slot) += pool.F(P_BETA + b, slot) * l.L[b];
-                }
+    uint32_t slot = 0;
+    if (qi < ctr->shadeCount[cls]) {
+        slot = pool.shadeQ[cls][qi];
+        const int flags = pool.I(I_FLAGS, slot);
+        const int bounces = pool.I(I_BOUNCES, slot);
+        const int prim = pool.I(I_HITPRIM, slot);
+        const bool found = prim >= 0;
+        V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
+        V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+        SurfaceInteraction isect;
+        bool finished = false, passThrough = false;
+        if (found) HitInteraction(s, prim, ro, rd, pool.F(P_B0, slot), pool.F(P_B1, slot), pool.F(P_B2, slot), &isect);
+        // emitted light at the vertex, path.cpp:91-101
+        if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
+            const int li = s.prims[prim].area_light;
+            if (li >= 0) {
+                const mi_light &l = s.lights[li];
+                if (l.two_sided || Dot(isect.n, -rd) > 0)
+                    for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_L + b, slot) += pool.F(P_BETA + b, slot) * l.L[b];
             }
-            if (!found || bounces >= s.maxDepth) finished = true;
-            int newFlags = 0;
-            if (!finished) {
-                const int matIdx = s.prims[prim].material;
-                if (matIdx < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
-                    Ray r = SpawnRay(isect, rd);
-                    pool.F(P_OX, slot) = r.o.x; pool.F(P_OY, slot) = r.o.y; pool.F(P_OZ, slot) = r.o.z;
-                    pool.F(P_TMAX, slot) = r.tMax;
-                    passThrough = true;  // flags and bounce count stay as they are
-                }
-            }
-            if (!finished && !passThrough) {
-                const int matIdx = s.prims[prim].material;
-                const mi_material *mat = &s.materials[matIdx];
-                BSDFFrame fr;  // BSDF ctor, reflection.h:170-176
-                fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
-                fr.m = mat;
-                uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
-                int dim = pool.I(I_DIM, slot);
-                const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
-                // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
-                if (NumComponents(mat, nonSpec) > 0) {
-                    ++totalPaths;
-                    newFlags |= F_NEE;
-                    if (s.nLights > 0) {
-                        const uint32_t di = LightDistribIndex(s, isect.p);
-                        float selPdf;
-                        const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
-                                                            s.ldFuncInt[di], (int)s.nLights, Get1D(s, index, dim), &selPdf);
-                        if (selPdf != 0) {
-                            float uL0 = Get1D(s, index, dim), uL1 = Get1D(s, index, dim);
-                            float uS0 = Get1D(s, index, dim), uS1 = Get1D(s, index, dim);
-                            const mi_light &light = s.lights[lightNum];
-                            LightSample ls = SampleLi(s, light, isect, uL0, uL1);
-                            float lightPdf = ls.pdf, scatteringPdf = 0;
-                            if (lightPdf > 0 && !ls.black) {
-                                BSDFEval ev;
-                                BSDF_f(fr, isect.wo, ls.wi, nonSpec, &ev);
-                                const float absdot = AbsDot(ls.wi, isect.shN);
-                                scatteringPdf = BSDF_Pdf(fr, isect.wo, ls.wi, nonSpec);
-                                const bool delta = IsDeltaLight(light);
-                                float weight = 1.f;
-                                if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
-                                bool fNonBlack = false, liNonBlack = false, cNonBlack = false;
-                                for (int b = 0; b < MI_NSPEC; ++b) {
-                                    float f = EvalBin(ev, mat->bxdf, b) * absdot;
-                                    float Li = LiBin(light, ls, b);
-                                    fNonBlack |= (f != 0.f);
-                                    liNonBlack |= (Li != 0.f);
-                                    float Ld = delta ? (f * Li) / lightPdf : ((f * Li) * weight) / lightPdf;
-                                    float c = pool.F(P_BETA + b, slot) * (Ld / selPdf);
-                                    cNonBlack |= (c != 0.f);
-                                    pool.F(P_LNEE + b, slot) = c;
-                                }
-                                if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
-                                    Ray sr = SpawnRayTo(isect, ls.pLight);
-                                    pool.F(P_SOX, slot) = sr.o.x; pool.F(P_SOY, slot) = sr.o.y; pool.F(P_SOZ, slot) = sr.o.z;
-                                    pool.F(P_SDX, slot) = sr.d.x; pool.F(P_SDY, slot) = sr.d.y; pool.F(P_SDZ, slot) = sr.d.z;
-                                    newFlags |= F_SHADOW;
-                                    if (!cNonBlack) newFlags |= 0;  // contribution may still be black; resolved in k_shadow
-                                }
-                            }
-                            if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
-                                V3 wi;
-                                float sPdf = 0;
-                                int sampledType = 0;
-                                BSDFEval ev;
-                                bool ok = BSDF_Sample_f(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
-                                if (ok && sPdf > 0) {
-                                    const float absdot = AbsDot(wi, isect.shN);
-                                    bool fNonBlack = false;
-                                    for (int b = 0; b < MI_NSPEC && !fNonBlack; ++b) fNonBlack |= (EvalBin(ev, mat->bxdf, b) * absdot != 0.f);
-                                    if (fNonBlack) {
-                                        float weight = 1;
-                                        bool go = true;
-                                        if (!(sampledType & MI_BSDF_SPECULAR)) {
-                                            float lp = ShapePdf(s, light.shape, light.area, isect, wi);
-                                            if (lp == 0) go = false;
-                                            else { float f = 1 * sPdf, g = 1 * lp; weight = (f * f) / (f * f + g * g); }
-                                        }
-                                        if (go) {
-                                            for (int b = 0; b < MI_NSPEC; ++b) {
-                                                float f = EvalBin(ev, mat->bxdf, b) * absdot;
-                                                float Ld = ((f * light.L[b]) * weight) / sPdf;  // f * Li * Tr(=1) * weight / scatteringPdf
-                                                pool.F(P_LMIS + b, slot) = pool.F(P_BETA + b, slot) * (Ld / selPdf);
-                                            }
-                                            Ray mr = SpawnRay(isect, wi);
-                                            pool.F(P_MOX, slot) = mr.o.x; pool.F(P_MOY, slot) = mr.o.y; pool.F(P_MOZ, slot) = mr.o.z;
-                                            pool.F(P_MDX, slot) = mr.d.x; pool.F(P_MDY, slot) = mr.d.y; pool.F(P_MDZ, slot) = mr.d.z;
-                                            pool.I(I_MISLIGHT, slot) = lightNum;
-                                            newFlags |= F_MIS;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                // ---- sample the BSDF for the next direction, path.cpp:131-150
-                {
-                    V3 wo = -rd, wi;
-                    float pdf = 0;
-                    int sflags = 0;
-                    float u0 = Get1D(s, index, dim), u1 = Get1D(s, index, dim);
-                    BSDFEval ev;
-                    bool ok = BSDF_Sample_f(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
-                    bool fNonBlack = false;
-                    float etaScale = pool.F(P_ETASCALE, slot);
-                    if (ok && pdf != 0.f) {
-                        const float absdot = AbsDot(wi, isect.shN);
-                        for (int b = 0; b < MI_NSPEC && !fNonBlack; ++b) fNonBlack |= (EvalBin(ev, mat->bxdf, b) != 0.f);
-                        if (fNonBlack) {
-                            if ((sflags & MI_BSDF_SPECULAR) && (sflags & MI_BSDF_TRANSMISSION)) {
-                                float eta = mat->eta;
-                                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
-                            }
-                            float maxRR = 0;
+        }
+        if (!found || bounces >= s.maxDepth) finished = true;
+        int newFlags = 0;
+        if (!finished && s.prims[prim].material < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
+            Ray r = SpawnRay(isect, rd);
+            pool.F(P_OX, slot) = r.o.x; pool.F(P_OY, slot) = r.o.y; pool.F(P_OZ, slot) = r.o.z;
+            pool.F(P_TMAX, slot) = r.tMax;
+            passThrough = true;  // flags and bounce count stay as they are
+        }
+        if (!finished && !passThrough) {
+            const mi_material *mat = &s.materials[s.prims[prim].material];
+            BSDFFrame fr;  // BSDF ctor, reflection.h:170-176
+            fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
+            fr.m = mat;
+            const uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
+            int dim = pool.I(I_DIM, slot);
+            const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
+            // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
+            if (NumComponents(mat, nonSpec) > 0) {
+                ++totalPaths;
+                newFlags |= F_NEE;
+                if (s.nLights > 0) {
+                    const uint32_t di = LightDistribIndex(s, isect.p);
+                    float selPdf;
+                    const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
+                                                        s.ldFuncInt[di], (int)s.nLights, Get1D(s, index, dim), &selPdf);
+                    if (selPdf != 0) {
+                        const float uL0 = Get1D(s, index, dim), uL1 = Get1D(s, index, dim);
+                        const float uS0 = Get1D(s, index, dim), uS1 = Get1D(s, index, dim);
+                        const mi_light &light = s.lights[lightNum];
+                        const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
+                        const Divisor selDiv = MakeDivisor(selPdf);
+                        const LightSample ls = SampleLi(s, light, isect, uL0, uL1);
+                        const float lightPdf = ls.pdf;
+                        if (lightPdf > 0 && !ls.black) {
+                            BSDFEvalT<NL> ev;
+                            BSDF_f<NL>(fr, isect.wo, ls.wi, nonSpec, &ev);
+                            const float absdot = AbsDot(ls.wi, isect.shN);
+                            const float scatteringPdf = BSDF_Pdf(fr, isect.wo, ls.wi, nonSpec);
+                            const bool delta = IsDeltaLight(light);
+                            float weight = 1.f;
+                            if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
+                            const Divisor lpDiv = MakeDivisor(lightPdf);
+                            bool fNonBlack = false, liNonBlack = false;
                             for (int b = 0; b < MI_NSPEC; ++b) {
-                                float f = EvalBin(ev, mat->bxdf, b);
-                                float nb = pool.F(P_BETA + b, slot) * ((f * absdot) / pdf);
-                                pool.F(P_BETA + b, slot) = nb;
-                                float rr = nb * etaScale;
-                                maxRR = (b == 0) ? rr : maxf(maxRR, rr);
+                                const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                const float Li = LiBin(light, ls, b);
+                                fNonBlack |= (f != 0.f);
+                                liNonBlack |= (Li != 0.f);
+                                float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
+                                if (!selIsOne) Ld = DivBy(Ld, selDiv);
+                                pool.F(P_LNEE + b, slot) = pool.F(P_BETA + b, slot) * Ld;
                             }
-                            Ray nr = SpawnRay(isect, wi);
-                            // Russian roulette, path.cpp:176-184
-                            bool killed = false;
-                            if (maxRR < s.rrThreshold && bounces > 3) {
-                                float q = maxf(.05f, 1 - maxRR);
-                                if (Get1D(s, index, dim) < q) killed = true;
-                                else {
-                                    const float inv = 1 - q;
-                                    for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_BETA + b, slot) /= inv;
+                            if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
+                                Ray sr = SpawnRayTo(isect, ls.pLight);
+                                pool.F(P_SOX, slot) = sr.o.x; pool.F(P_SOY, slot) = sr.o.y; pool.F(P_SOZ, slot) = sr.o.z;
+                                pool.F(P_SDX, slot) = sr.d.x; pool.F(P_SDY, slot) = sr.d.y; pool.F(P_SDZ, slot) = sr.d.z;
+                                newFlags |= F_SHADOW;
+                            }
+                        }
+                        if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
+                            V3 wi;
+                            float sPdf = 0;
+                            int sampledType = 0;
+                            BSDFEvalT<NL> ev;
+                            const bool ok = BSDF_Sample_f<NL>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
+                            if (ok && sPdf > 0) {
+                                const float absdot = AbsDot(wi, isect.shN);
+                                // Pdf_Li has no side effect: evaluate it before knowing whether f is black
+                                float weight = 1;
+                                bool go = true;
+                                if (!(sampledType & MI_BSDF_SPECULAR)) {
+                                    const float lp = ShapePdf(s, light.shape, light.area, isect, wi);
+                                    if (lp == 0) go = false;
+                                    else { float pf = 1 * sPdf, pg = 1 * lp; weight = (pf * pf) / (pf * pf + pg * pg); }
                                 }
-                            }
-                            if (killed) finished = true;
-                            else {
-                                pool.F(P_OX, slot) = nr.o.x; pool.F(P_OY, slot) = nr.o.y; pool.F(P_OZ, slot) = nr.o.z;
-                                pool.F(P_DX, slot) = nr.d.x; pool.F(P_DY, slot) = nr.d.y; pool.F(P_DZ, slot) = nr.d.z;
-                                pool.F(P_TMAX, slot) = nr.tMax;
-                                pool.F(P_ETASCALE, slot) = etaScale;
-                                if (sflags & MI_BSDF_SPECULAR) newFlags |= F_SPECULAR;
+                                const Divisor spDiv = MakeDivisor(sPdf);
+                                bool fNonBlack = false;
+                                for (int b = 0; b < MI_NSPEC; ++b) {
+                                    const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                    fNonBlack |= (f != 0.f);
+                                    float Ld = DivBy((f * light.L[b]) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
+                                    if (!selIsOne) Ld = DivBy(Ld, selDiv);
+                                    pool.F(P_LMIS + b, slot) = pool.F(P_BETA + b, slot) * Ld;
+                                }
+                                if (fNonBlack && go) {
+                                    Ray mr = SpawnRay(isect, wi);
+                                    pool.F(P_MOX, slot) = mr.o.x; pool.F(P_MOY, slot) = mr.o.y; pool.F(P_MOZ, slot) = mr.o.z;
+                                    pool.F(P_MDX, slot) = mr.d.x; pool.F(P_MDY, slot) = mr.d.y; pool.F(P_MDZ, slot) = mr.d.z;
+                                    pool.I(I_MISLIGHT, slot) = lightNum;
+                                    newFlags |= F_MIS;
+                                }
                             }
                         }
                     }
-                    if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
                 }
-                pool.I(I_DIM, slot) = dim;
             }
-            if (passThrough) {
-                // nothing else changes
-            } else if (finished) {
-                // ReportValue(pathLength, bounces): the loop's ++bounces has not run on break;
-                // a path killed by RR / black f at vertex `bounces` reports `bounces`.
+            // ---- sample the BSDF for the next direction, path.cpp:131-150
+            {
+                V3 wo = -rd, wi;
+                float pdf = 0;
+                int sflags = 0;
+                const float u0 = Get1D(s, index, dim), u1 = Get1D(s, index, dim);
+                BSDFEvalT<NL> ev;
+                const bool ok = BSDF_Sample_f<NL>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
+                bool fNonBlack = false;
+                if (ok && pdf != 0.f) {
+                    const float absdot = AbsDot(wi, isect.shN);
+                    float etaScale = pool.F(P_ETASCALE, slot);
+                    if ((sflags & MI_BSDF_SPECULAR) && (sflags & MI_BSDF_TRANSMISSION)) {
+                        float eta = mat->eta;
+                        etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                    }
+                    const Divisor pdfDiv = MakeDivisor(pdf);
+                    float maxRR = 0;
+                    for (int b = 0; b < MI_NSPEC; ++b) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
+                        const float f = EvalBin<NL>(ev, mat->bxdf, b);
+                        fNonBlack |= (f != 0.f);
+                        const float nb = pool.F(P_BETA + b, slot) * DivBy(f * absdot, pdfDiv);
+                        pool.F(P_BETA + b, slot) = nb;
+                        const float rr = nb * etaScale;
+                        maxRR = (b == 0) ? rr : maxf(maxRR, rr);
+                    }
+                    if (fNonBlack) {
+                        Ray nr = SpawnRay(isect, wi);
+                        // Russian roulette, path.cpp:176-184
+                        bool killed = false;
+                        if (maxRR < s.rrThreshold && bounces > 3) {
+                            float q = maxf(.05f, 1 - maxRR);
+                            if (Get1D(s, index, dim) < q) killed = true;
+                            else {
+                                const Divisor inv = MakeDivisor(1 - q);
+                                for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_BETA + b, slot) = DivBy(pool.F(P_BETA + b, slot), inv);
+                            }
+                        }
+                        if (killed) finished = true;
+                        else {
+                            pool.F(P_OX, slot) = nr.o.x; pool.F(P_OY, slot) = nr.o.y; pool.F(P_OZ, slot) = nr.o.z;
+                            pool.F(P_DX, slot) = nr.d.x; pool.F(P_DY, slot) = nr.d.y; pool.F(P_DZ, slot) = nr.d.z;
+                            pool.F(P_TMAX, slot) = nr.tMax;
+                            pool.F(P_ETASCALE, slot) = etaScale;
+                            if (sflags & MI_BSDF_SPECULAR) newFlags |= F_SPECULAR;
+                        }
+                    }
+                }
+                if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
+            }
+            pool.I(I_DIM, slot) = dim;
+        }
+        if (!passThrough) {
+            if (finished) {
+                // ReportValue(pathLength, bounces): `bounces` at the break of path.cpp's loop
                 pathLen = (unsigned)bounces;
                 newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS)) | F_FINISHED;
             } else {
                 newFlags |= F_ALIVE;
                 pool.I(I_BOUNCES, slot) = bounces + 1;
             }
-            if (!passThrough) {
-                wantShadow = (newFlags & F_SHADOW) != 0;
-                wantMis = (newFlags & F_MIS) != 0;
-                // a direct-lighting estimate with neither ray pending is already known to be black
-                if ((newFlags & F_NEE) && !wantShadow && !wantMis) { ++zeroNow; newFlags &= ~F_NEE; }
-                pool.I(I_FLAGS, slot) = newFlags;
-            }
+            wantShadow = (newFlags & F_SHADOW) != 0;
+            wantMis = (newFlags & F_MIS) != 0;
+            // a direct-lighting estimate with neither ray pending is already known to be black
+            if ((newFlags & F_NEE) && !wantShadow && !wantMis) { ++zeroNow; newFlags &= ~F_NEE; }
+            pool.I(I_FLAGS, slot) = newFlags;
         }
     }
     QueueAppend(&ctr->shadowCount, pool.shadowQ, wantShadow, slot);
@@ -810,6 +824,7 @@ struct mi_pt {
     double lastSeconds[8] = {0};
     unsigned long long lastLaunches[3] = {0, 0, 0};
     bool haveEvents = false;
+    bool haveLargeMaterials = false;  // some material has more than 2 lobes (second shading class)
 };
 
 namespace {
@@ -836,12 +851,16 @@ int EnsurePool(mi_pt *pt, uint32_t n) {
     if (pt->pool.n == n && pt->pool.f) return MI_OK;
     if (pt->pool.f) {
         hipFree(pt->pool.f); hipFree(pt->pool.i); hipFree(pt->pool.shadowQ); hipFree(pt->pool.misQ);
+        hipFree(pt->pool.shadeQ[0]); hipFree(pt->pool.shadeQ[1]);
         pt->pool.f = nullptr; pt->pool.i = nullptr; pt->pool.shadowQ = pt->pool.misQ = nullptr;
+        pt->pool.shadeQ[0] = pt->pool.shadeQ[1] = nullptr;
     }
     HIPCHK(hipMalloc((void **)&pt->pool.f, (size_t)P_COUNT * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&pt->pool.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&pt->pool.shadowQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&pt->pool.misQ, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&pt->pool.shadeQ[0], (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&pt->pool.shadeQ[1], (size_t)n * sizeof(uint32_t)));
     pt->pool.n = n;
     return MI_OK;
 }
@@ -957,6 +976,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     UP(d->meshes, d->n_meshes, s.meshes);
     UP(d->spheres, d->n_spheres, s.spheres);
     UP(d->materials, d->n_materials, s.materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].n_bxdfs > 2) pt->haveLargeMaterials = true;
     UP(d->lights, d->n_lights, s.lights);
     UP(d->sampler.primes, d->sampler.n_dims, s.primes);
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
@@ -1084,7 +1104,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     bool prevFull = false, havePrev = false;
     while (true) {
         hipEvent_t *ev = pt->evIter[set];
-        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 3 * sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 5 * sizeof(unsigned), st));
         HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
         HIPCHK(hipEventRecord(ev[1], st));
@@ -1094,7 +1114,8 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         if (alive == 0) { harvest(set, false); break; }
         hipLaunchKernelGGL(k_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
         HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_shade, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, pt->pool, pt->ctr, 0);
+        if (pt->haveLargeMaterials) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, grid, block, 0, st, s, pt->pool, pt->ctr, 1);
         HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
         HIPCHK(hipEventRecord(ev[4], st));
@@ -1182,6 +1203,8 @@ void mi_pt_destroy(mi_pt *pt) {
     if (pt->pool.i) hipFree(pt->pool.i);
     if (pt->pool.shadowQ) hipFree(pt->pool.shadowQ);
     if (pt->pool.misQ) hipFree(pt->pool.misQ);
+    if (pt->pool.shadeQ[0]) hipFree(pt->pool.shadeQ[0]);
+    if (pt->pool.shadeQ[1]) hipFree(pt->pool.shadeQ[1]);
     if (pt->ctr) hipFree(pt->ctr);
     if (pt->haveEvents) {
         hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop);
