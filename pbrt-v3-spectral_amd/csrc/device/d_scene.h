@@ -18,6 +18,7 @@ namespace dpt {
 
 #define PRIM_FLAG_SPHERE 1u
 #define PRIM_FLAG_DEGENERATE 2u
+#define PRIM_FLAG_LARGE_MAT 4u  /* material with more than 2 lobes: second shading class */
 
 struct DScene {
     const float4 *nodes;

@@ -20,6 +20,7 @@
 // decisions as the CPU reference up to floating-point differences of libm functions.
 // No MFMA: this path is latency/bandwidth bound (traversal) and VALU bound (shading).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -58,7 +59,11 @@ enum : int {
     P_COUNT = P_LMIS + MI_NSPEC
 };
 // ---- int planes
-enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT, I_COUNT };
+enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT,
+             I_NPEND, I_PEND0, I_PEND1, I_PEND2, I_PEND3,  // quadrics postponed by the traversal kernel
+             I_COUNT };
+constexpr int MAX_PEND = 4;
+constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
 // ---- slot flags
 enum : int {
     F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128
@@ -82,7 +87,7 @@ struct DevCounters {
     unsigned int shadowCount;      // entries in Pool::shadowQ        } every iteration
     unsigned int misCount;         // entries in Pool::misQ           }
     unsigned int shadeCount[2];    // entries in Pool::shadeQ[c]      }
-    unsigned int pad;
+    unsigned int travNext[3];      // work cursors of the persistent traversal kernels (extend/shadow/mis) }
 };
 
 struct WorkDesc {
@@ -237,6 +242,293 @@ DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *
         }
     }
     return found;
+}
+
+DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si);
+
+// ------------------------------------------------------------------ persistent traversal
+// One launch traverses every ray of a class (MODE 0: path rays of the alive slots, closest
+// hit; 1: NEE shadow rays of shadowQ, any hit; 2: MIS rays of misQ, closest hit). A fixed
+// grid of waves pulls rays from a device-wide cursor: lanes whose ray finished fetch a new
+// one as soon as fewer than REFILL_BELOW lanes of the wave are still traversing (dynamic
+// fetch), so a long ray no longer idles the other 63 lanes. Per ray the node / primitive
+// order is the reference's (see Traverse above); quadrics are only recorded (I_PEND*),
+// k_resolve_* tests them afterwards at full lane utilisation.
+#ifndef MIPT_TRAV_BLOCKS_PER_CU
+#define MIPT_TRAV_BLOCKS_PER_CU 5
+#endif
+#ifndef MIPT_REFILL_BELOW
+#define MIPT_REFILL_BELOW 32
+#endif
+constexpr int TRAV_BLOCKS_PER_CU = MIPT_TRAV_BLOCKS_PER_CU;
+constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    constexpr bool ANY = (MODE == 1);
+    constexpr int PO = (MODE == 0) ? P_OX : ((MODE == 1) ? P_SOX : P_MOX);
+    const int lane = threadIdx.x;
+    const int wlane = threadIdx.x & 63;
+    const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount : ctr->misCount);
+    const uint32_t *__restrict__ queue = (MODE == 1) ? pool.shadowQ : pool.misQ;
+    const float4 *__restrict__ nodes = s.nodes;
+    const float4 *__restrict__ primTri = s.primTri;
+    const float k = 1 + 2 * gammaf(3);
+    unsigned nodeCount = 0, triCount = 0, rayCount = 0;
+    // per-lane ray state
+    bool has = false;
+    uint32_t slot = 0;
+    float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 0, idx = 0, idy = 0, idz = 0, tMax = 0;
+    bool neg0 = false, neg1 = false, neg2 = false;
+    int sp = 0, cur = -1, nPend = 0, hitPrim = -1;
+    float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
+    int spill[STACK_SPILL];
+    bool exhausted = (s.nNodes == 0 && false);
+    while (true) {
+        // ---- fetch rays for idle lanes
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!has);
+            if (idle) {
+                const int leader = __ffsll((long long)idle) - 1;
+                unsigned base = 0;
+                if (wlane == leader) base = atomicAdd(&ctr->travNext[MODE], (unsigned)__popcll(idle));
+                base = __shfl(base, leader, 64);
+                if (base >= total) exhausted = true;
+                if (!has) {
+                    const unsigned my = base + __popcll(idle & ((1ull << wlane) - 1));
+                    if (my < total) {
+                        bool take = true;
+                        if (MODE == 0) { slot = my; take = (pool.I(I_FLAGS, slot) & F_ALIVE) != 0; }
+                        else slot = queue[my];
+                        if (take) {
+                            rox = pool.F(PO + 0, slot); roy = pool.F(PO + 1, slot); roz = pool.F(PO + 2, slot);
+                            rdx = pool.F(PO + 3, slot); rdy = pool.F(PO + 4, slot); rdz = pool.F(PO + 5, slot);
+                            tMax = (MODE == 0) ? pool.F(P_TMAX, slot) : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
+                            idx = 1.f / rdx; idy = 1.f / rdy; idz = 1.f / rdz;
+                            neg0 = idx < 0; neg1 = idy < 0; neg2 = idz < 0;
+                            sp = 0; cur = (s.nNodes > 0) ? 0 : -1; nPend = 0; hitPrim = -1;
+                            hitT = hitB0 = hitB1 = hitB2 = 0;
+                            has = true;
+                            ++rayCount;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(has)) {
+            if (exhausted) break;
+            continue;  // every fetched slot was dead: fetch again
+        }
+        // ---- traverse until enough lanes have run dry
+        while (true) {
+            int leafOffset = 0, leafCount = 0;
+            if (has) {
+                while (cur >= 0) {  // phase 1: interior nodes
+                    const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
+                    ++nodeCount;
+                    const int offset = __float_as_int(nb.z);
+                    const unsigned meta = __float_as_uint(nb.w);
+                    bool hitBox;
+                    {
+                        float tMin = ((neg0 ? na.w : na.x) - rox) * idx;
+                        float tMx = ((neg0 ? na.x : na.w) - rox) * idx;
+                        float tyMin = ((neg1 ? nb.x : na.y) - roy) * idy;
+                        float tyMax = ((neg1 ? na.y : nb.x) - roy) * idy;
+                        tMx *= k;
+                        tyMax *= k;
+                        hitBox = !(tMin > tyMax || tyMin > tMx);
+                        if (tyMin > tMin) tMin = tyMin;
+                        if (tyMax < tMx) tMx = tyMax;
+                        float tzMin = ((neg2 ? nb.y : na.z) - roz) * idz;
+                        float tzMax = ((neg2 ? na.z : nb.y) - roz) * idz;
+                        tzMax *= k;
+                        hitBox = hitBox && !(tMin > tzMax || tzMin > tMx);
+                        if (tzMin > tMin) tMin = tzMin;
+                        if (tzMax < tMx) tMx = tzMax;
+                        hitBox = hitBox && (tMin < tMax) && (tMx > 0);
+                    }
+                    const int nPrims = meta & 0xffff;
+                    if (hitBox && nPrims == 0) {
+                        const int axis = (meta >> 16) & 0xff;
+                        const bool negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
+                        const int farNode = negAxis ? cur + 1 : offset;
+                        const int nearNode = negAxis ? offset : cur + 1;
+                        if (sp < STACK_LDS) lds[sp][lane] = farNode;
+                        else spill[sp - STACK_LDS] = farNode;
+                        ++sp;
+                        cur = nearNode;
+                        continue;
+                    }
+                    if (sp == 0) cur = -1;
+                    else { --sp; cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS]; }
+                    if (hitBox) { leafOffset = offset; leafCount = nPrims; break; }
+                }
+            }
+            bool finished = has && leafCount == 0;  // stack empty and no leaf left: this ray is done
+            if (has && leafCount > 0) {
+                const V3 ro(rox, roy, roz), rd(rdx, rdy, rdz);
+                for (int i = 0; i < leafCount; ++i) {  // phase 2: leaf primitives
+                    const int prim = leafOffset + i;
+                    const float4 v0 = primTri[3 * prim];
+                    const unsigned pf = __float_as_uint(v0.w);
+                    if (pf & PRIM_FLAG_SPHERE) {
+                        if ((nPend & 0xff) < MAX_PEND) { pool.I(I_PEND0 + (nPend & 0xff), slot) = prim; ++nPend; }
+                        else nPend |= PEND_OVERFLOW;
+                        continue;
+                    }
+                    const float4 v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
+                    ++triCount;
+                    TriHit th;
+                    if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
+                        if (ANY) { hitPrim = prim; finished = true; break; }
+                        if (!(pf & PRIM_FLAG_DEGENERATE)) {
+                            tMax = th.t;
+                            hitPrim = prim; hitT = th.t; hitB0 = th.b0; hitB1 = th.b1; hitB2 = th.b2;
+                        }
+                    }
+                }
+            }
+            if (finished) {
+                pool.I(I_HITPRIM, slot) = hitPrim;
+                pool.I(I_NPEND, slot) = nPend;
+                if (!ANY) { pool.F(P_HIT_T, slot) = hitT; pool.F(P_B0, slot) = hitB0; pool.F(P_B1, slot) = hitB1; pool.F(P_B2, slot) = hitB2; }
+                has = false;
+            }
+            const int active = __popcll(__ballot(has));
+            if (active == 0 || (!exhausted && active < REFILL_BELOW)) break;
+        }
+    }
+    if (MODE == 1) CountAdd(&ctr->shadowRays, rayCount);
+    else CountAdd(&ctr->regularRays, rayCount);
+    CountAdd(&ctr->nodesVisited, nodeCount);
+    CountAdd(&ctr->triTests, triCount);
+    if (MODE == 0) { CountAdd(&ctr->extendNodes, nodeCount); CountAdd(&ctr->extendTris, triCount); CountAdd(&ctr->extendRays, rayCount); }
+}
+
+// Quadrics recorded by k_trav, tested in encounter order against the ray's final tMax
+// (closest hit is order independent). On overflow the ray is re-traversed by the
+// reference-order routine with inline quadric tests.
+template <bool ANY>
+DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
+                         Hit *h, bool foundTri, int (*lds)[BLOCK], unsigned &nodes, unsigned &tris) {
+    const int np = pool.I(I_NPEND, slot);
+    bool found = foundTri;
+    if (np & PEND_OVERFLOW) {
+        Hit h2;
+        h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
+        unsigned n2 = 0, t2 = 0;  // statistics were already counted by k_trav
+        found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, lds, n2, t2);
+        if (found) *h = h2;
+        return found;
+    }
+    float tMax = (!ANY && foundTri) ? h->t : tMaxIn;
+    for (int j = 0; j < (np & 0xff); ++j) {
+        const int prim = pool.I(I_PEND0 + j, slot);
+        const int sph = __float_as_int(s.primTri[3 * prim + 1].w);
+        float t;
+        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+            if (ANY) return true;
+            tMax = t;
+            h->prim = prim; h->t = t; h->b0 = h->b1 = h->b2 = 0;
+            found = true;
+        }
+    }
+    return found;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    bool traced = false;
+    int cls = 0;
+    unsigned nodes = 0, tris = 0;
+    if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
+        traced = true;
+        int prim = pool.I(I_HITPRIM, slot);
+        if (pool.I(I_NPEND, slot) != 0) {
+            V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
+            V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+            Hit h;
+            h.prim = prim; h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
+            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, pool.F(P_TMAX, slot), &h, prim >= 0, lds, nodes, tris);
+            prim = found ? h.prim : -1;
+            pool.I(I_HITPRIM, slot) = prim;
+            pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
+        }
+        if (prim >= 0 && (__float_as_uint(s.primTri[3 * prim].w) & PRIM_FLAG_LARGE_MAT)) cls = 1;
+    }
+    QueueAppend(&ctr->shadeCount[0], pool.shadeQ[0], traced && cls == 0, slot);
+    QueueAppend(&ctr->shadeCount[1], pool.shadeQ[1], traced && cls == 1, slot);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned zero = 0, nodes = 0, tris = 0;
+    if (qi < ctr->shadowCount) {
+        const uint32_t slot = pool.shadowQ[qi];
+        int flags = pool.I(I_FLAGS, slot);
+        bool occluded = pool.I(I_HITPRIM, slot) >= 0;
+        if (!occluded && pool.I(I_NPEND, slot) != 0) {
+            V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
+            V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
+            Hit h;
+            occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, lds, nodes, tris);
+        }
+        bool added = false;
+        if (!occluded) {
+            for (int b = 0; b < MI_NSPEC; ++b) {
+                float c = pool.F(P_LNEE + b, slot);
+                added |= (c != 0.f);
+                pool.F(P_L + b, slot) += c;
+            }
+        }
+        flags &= ~F_SHADOW;
+        if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
+        else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
+        pool.I(I_FLAGS, slot) = flags;
+    }
+    CountAdd(&ctr->zeroRadiancePaths, zero);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
+    __shared__ int lds[STACK_LDS][BLOCK];
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned zero = 0, nodes = 0, tris = 0;
+    if (qi < ctr->misCount) {
+        const uint32_t slot = pool.misQ[qi];
+        const int flags = pool.I(I_FLAGS, slot);
+        V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
+        V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
+        Hit h;
+        h.prim = pool.I(I_HITPRIM, slot); h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
+        bool found = h.prim >= 0;
+        if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, lds, nodes, tris);
+        bool added = false;
+        if (found) {
+            const int lightNum = pool.I(I_MISLIGHT, slot);
+            if (s.prims[h.prim].area_light == lightNum) {
+                const mi_light &l = s.lights[lightNum];
+                bool emit = l.two_sided != 0;
+                if (!emit) {
+                    SurfaceInteraction li;
+                    HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
+                    emit = Dot(li.n, -rd) > 0;
+                }
+                if (emit) {
+                    for (int b = 0; b < MI_NSPEC; ++b) {
+                        float c = pool.F(P_LMIS + b, slot);
+                        added |= (c != 0.f);
+                        pool.F(P_L + b, slot) += c;
+                    }
+                }
+            }
+        }
+        if (!added && !(flags & F_A_ADDED)) ++zero;
+        pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
+    }
+    CountAdd(&ctr->zeroRadiancePaths, zero);
 }
 
 // ------------------------------------------------------------------ generate
@@ -402,39 +694,6 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     if ((threadIdx.x & 63) == 0 && aliveMask) atomicAdd(&ctr->alive, (unsigned)__popcll(aliveMask));
     CountAdd(&ctr->cameraRays, cam);
     CountAdd(&ctr->badSamples, bad);
-}
-
-// ------------------------------------------------------------------ extend
-__global__ void __launch_bounds__(BLOCK) k_extend(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned nodes = 0, tris = 0, rays = 0;
-    bool traced = false;
-    int cls = 0;
-    if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
-        V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
-        V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
-        float tMax = pool.F(P_TMAX, slot);
-        Hit h;
-        h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
-        bool found = Traverse<false>(s, ro, rd, tMax, &h, lds, nodes, tris);
-        ++rays;
-        pool.I(I_HITPRIM, slot) = found ? h.prim : -1;
-        pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
-        traced = true;
-        if (found) {   // material class of the hit: sorts the shading work
-            const int m = s.prims[h.prim].material;
-            if (m >= 0 && s.materials[m].n_bxdfs > 2) cls = 1;
-        }
-    }
-    QueueAppend(&ctr->shadeCount[0], pool.shadeQ[0], traced && cls == 0, slot);
-    QueueAppend(&ctr->shadeCount[1], pool.shadeQ[1], traced && cls == 1, slot);
-    CountAdd(&ctr->regularRays, rays);
-    CountAdd(&ctr->nodesVisited, nodes);
-    CountAdd(&ctr->triTests, tris);
-    CountAdd(&ctr->extendNodes, nodes);
-    CountAdd(&ctr->extendTris, tris);
-    CountAdd(&ctr->extendRays, rays);
 }
 
 // Build the SurfaceInteraction of a recorded hit.
@@ -650,80 +909,6 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
     CountAdd(&ctr->zeroRadiancePaths, zeroNow);
 }
 
-// ------------------------------------------------------------------ shadow rays
-__global__ void __launch_bounds__(BLOCK) k_shadow(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
-    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned nodes = 0, tris = 0, rays = 0, zero = 0;
-    if (qi < ctr->shadowCount) {
-        const uint32_t slot = pool.shadowQ[qi];
-        int flags = pool.I(I_FLAGS, slot);
-        V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
-        V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
-        Hit h;
-        ++rays;
-        bool occluded = Traverse<true>(s, ro, rd, 1 - kShadowEpsilon, &h, lds, nodes, tris);
-        bool added = false;
-        if (!occluded) {
-            for (int b = 0; b < MI_NSPEC; ++b) {
-                float c = pool.F(P_LNEE + b, slot);
-                added |= (c != 0.f);
-                pool.F(P_L + b, slot) += c;
-            }
-        }
-        flags &= ~F_SHADOW;
-        if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_mis closes the estimate
-        else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
-        pool.I(I_FLAGS, slot) = flags;
-    }
-    CountAdd(&ctr->shadowRays, rays);
-    CountAdd(&ctr->nodesVisited, nodes);
-    CountAdd(&ctr->triTests, tris);
-    CountAdd(&ctr->zeroRadiancePaths, zero);
-}
-
-// ------------------------------------------------------------------ MIS rays + NEE bookkeeping
-__global__ void __launch_bounds__(BLOCK) k_mis(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
-    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned nodes = 0, tris = 0, rays = 0, zero = 0;
-    if (qi < ctr->misCount) {
-        const uint32_t slot = pool.misQ[qi];
-        int flags = pool.I(I_FLAGS, slot);
-        V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
-        V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
-        Hit h;
-        h.prim = -1;
-        ++rays;
-        bool added = false;
-        if (Traverse<false>(s, ro, rd, kInfinity, &h, lds, nodes, tris)) {
-            const int lightNum = pool.I(I_MISLIGHT, slot);
-            if (s.prims[h.prim].area_light == lightNum) {
-                const mi_light &l = s.lights[lightNum];
-                bool emit = l.two_sided != 0;
-                if (!emit) {
-                    SurfaceInteraction li;
-                    HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
-                    emit = Dot(li.n, -rd) > 0;
-                }
-                if (emit) {
-                    for (int b = 0; b < MI_NSPEC; ++b) {
-                        float c = pool.F(P_LMIS + b, slot);
-                        added |= (c != 0.f);
-                        pool.F(P_L + b, slot) += c;
-                    }
-                }
-            }
-        }
-        if (!added && !(flags & F_A_ADDED)) ++zero;
-        pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
-    }
-    CountAdd(&ctr->regularRays, rays);
-    CountAdd(&ctr->nodesVisited, nodes);
-    CountAdd(&ctr->triTests, tris);
-    CountAdd(&ctr->zeroRadiancePaths, zero);
-}
-
 // ------------------------------------------------------------------ spatial light distribution (create time)
 __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcInt, uint32_t nVox) {
     const uint32_t vox = blockIdx.x * blockDim.x + threadIdx.x;
@@ -825,6 +1010,7 @@ struct mi_pt {
     unsigned long long lastLaunches[3] = {0, 0, 0};
     bool haveEvents = false;
     bool haveLargeMaterials = false;  // some material has more than 2 lobes (second shading class)
+    int numCUs = 256;
 };
 
 namespace {
@@ -898,6 +1084,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     HIPCHK(hipSetDevice(device_ordinal));
     mi_pt *pt = new mi_pt();
     pt->device = device_ordinal;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) pt->numCUs = prop.multiProcessorCount;
+    }
     DScene &s = pt->scene;
     int rc;
 #define UP(src, count, dst) if ((rc = Upload(pt, src, count, &dst)) != MI_OK) { mi_pt_destroy(pt); return rc; }
@@ -959,6 +1149,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
             }
+            if (p.material >= 0 && d->materials[p.material].n_bxdfs > 2) flags |= PRIM_FLAG_LARGE_MAT;
             memcpy(&a.w, &flags, 4);
             memcpy(&b.w, &shapeIdx, 4);
             pt3[3 * i] = a; pt3[3 * i + 1] = b; pt3[3 * i + 2] = c;
@@ -1085,6 +1276,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     HIPCHK(hipMemsetAsync(pt->pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
     HIPCHK(hipMemsetAsync(pt->ctr, 0, sizeof(DevCounters), st));
     const dim3 grid((poolN + BLOCK - 1) / BLOCK), block(BLOCK);
+    const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
     HIPCHK(hipEventRecord(pt->evStart, st));
     unsigned alive = 1;
     unsigned long long iterations = 0;
@@ -1104,7 +1296,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     bool prevFull = false, havePrev = false;
     while (true) {
         hipEvent_t *ev = pt->evIter[set];
-        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 5 * sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 8 * sizeof(unsigned), st));
         HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
         HIPCHK(hipEventRecord(ev[1], st));
@@ -1112,14 +1304,17 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         HIPCHK(hipStreamSynchronize(st));
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
-        hipLaunchKernelGGL(k_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_trav<0>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, pt->pool, pt->ctr, 0);
         if (pt->haveLargeMaterials) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, grid, block, 0, st, s, pt->pool, pt->ctr, 1);
         HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
         HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_mis, grid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_trav<2>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
+        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, pt->pool, pt->ctr);
         HIPCHK(hipEventRecord(ev[5], st));
         havePrev = true; prevFull = true;
         set ^= 1;
