@@ -3,8 +3,12 @@
 // interval arithmetic, surface-interaction construction and area sampling.
 //
 // HBM layout (all read-only after mi_pt_create):
-//   nodes    32 B/node, read as two 16-B loads: {bmin.xyz,bmax.x} {bmax.yz,offset,meta}
-//            meta = n_prims | axis<<16 (same bytes as LinearBVHNode, bvh.cpp:95-104)
+//   nodes    32 B/node = LinearBVHNode bytes (bvh.cpp:95-104), kept for reference/debug
+//   wnodes   64 B per INTERIOR node, four 16-B loads: the boxes of both children
+//            {Lmin.xyz,Lmax.x} {Lmax.yz,Rmin.xy} {Rmin.z,Rmax.xyz} and
+//            {childL, childR, nPrimsL|axis<<16, nPrimsR}; child = interior index, or first
+//            primitive when nPrims > 0. One fetch yields both child tests, halving the
+//            dependent-load chain of a ray; leaves are never fetched as nodes.
 //   primTri  48 B/primitive in BVH leaf order: p0|flags, p1|shape, p2|0  (positions are
 //            pre-gathered so a leaf test is three coalescable 16-B loads, no index chase)
 //   the indexed mesh (tri_indices, P, N, UV), spheres, materials, lights as in mi_pt.h
@@ -22,6 +26,7 @@ namespace dpt {
 
 struct DScene {
     const float4 *nodes;
+    const float4 *wnodes;  // 64 B per interior node: both children's boxes + child links (see pt_kernels.hip)
     const float4 *primTri;
     const mi_prim *prims;
     const int32_t *triIndices;

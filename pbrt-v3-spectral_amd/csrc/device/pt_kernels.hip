@@ -42,8 +42,8 @@ thread_local std::string g_err;
     } while (0)
 
 constexpr int BLOCK = 256;
-constexpr int STACK_LDS = 24;    // traversal stack entries staged in LDS per lane
-constexpr int STACK_SPILL = 40;  // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
+constexpr int STACK_LDS = 12;    // traversal stack entries (node, meta, tMin) staged in LDS per lane
+constexpr int STACK_SPILL = 52;  // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
 
 // ---- float planes
 enum : int {
@@ -125,77 +125,161 @@ struct Hit {
 };
 
 // BVHAccel::Intersect / IntersectP (bvh.cpp:662-738) with Bounds3::IntersectP
-// (geometry.h:1420-1447). Per ray the nodes are visited and the leaf primitives tested in
-// the reference's order (near child first), so equal-t ties resolve identically; the
-// SIMT schedule is "while-while": every lane first walks interior nodes until it holds a
-// leaf (cheap iterations, all lanes busy), then the wave tests leaves together (the
-// expensive part runs at high lane utilisation). Quadric (sphere) primitives are
-// postponed to the end of the ray's traversal and tested against the final tMax --
-// the closest hit is order-independent -- so the interval-arithmetic sphere code runs
-// once per wave instead of once per lane-iteration.
+// (geometry.h:1420-1447) over the "wide" node array: an interior node carries the boxes
+// of both children, so one 64-B fetch decides both child visits and the ray's chain of
+// dependent loads is halved. The visit semantics are the reference's:
+//   * near child (by dirIsNeg[axis]) first; the far child is pushed only if its box is
+//     hit, together with its entry distance tMin;
+//   * when popped, the far child is re-validated with `tMin < tMax` -- the only part of
+//     the reference's box test that depends on the (shrinking) ray tMax -- so exactly the
+//     nodes the reference would enter are entered, and leaf primitives are tested in the
+//     same order against the same tMax: equal-t ties resolve identically.
+// SIMT schedule: "while-while" (walk interior nodes until the lane holds a leaf, then the
+// wave tests leaves together). Quadric primitives are postponed: recorded in encounter
+// order and tested after the triangles against the final tMax (closest hit is order
+// independent), so the interval-arithmetic sphere code runs at full lane utilisation.
+struct TravLds {
+    int node[STACK_LDS][BLOCK];
+    int meta[STACK_LDS][BLOCK];
+    float tmin[STACK_LDS][BLOCK];
+};
+// The block's traversal stack lives in one LDS object reached by name (no generic pointers).
+DEV TravLds &TravStack() {
+    __shared__ TravLds stack;
+    return stack;
+}
+struct TravSpill {
+    int node[STACK_SPILL];
+    int meta[STACK_SPILL];
+    float tmin[STACK_SPILL];
+};
+struct RayCtx {  // per-lane ray constants
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    bool n0, n1, n2;
+};
+DEV void InitRayCtx(RayCtx &r, float ox, float oy, float oz, float dx, float dy, float dz) {
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.f / dx; r.iy = 1.f / dy; r.iz = 1.f / dz;
+    r.n0 = r.ix < 0; r.n1 = r.iy < 0; r.n2 = r.iz < 0;
+}
+// Bounds3::IntersectP(ray, invDir, dirIsNeg); also returns the final tMin.
+DEV bool BoxTest(const RayCtx &r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tMaxRay, float *tMinOut) {
+    const float k = 1 + 2 * gammaf(3);
+    float tMin = ((r.n0 ? mxx : mnx) - r.ox) * r.ix;
+    float tMx = ((r.n0 ? mnx : mxx) - r.ox) * r.ix;
+    float tyMin = ((r.n1 ? mxy : mny) - r.oy) * r.iy;
+    float tyMax = ((r.n1 ? mny : mxy) - r.oy) * r.iy;
+    tMx *= k;
+    tyMax *= k;
+    bool hit = !(tMin > tyMax || tyMin > tMx);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMx) tMx = tyMax;
+    float tzMin = ((r.n2 ? mxz : mnz) - r.oz) * r.iz;
+    float tzMax = ((r.n2 ? mnz : mxz) - r.oz) * r.iz;
+    tzMax *= k;
+    hit = hit && !(tMin > tzMax || tzMin > tMx);
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMx) tMx = tzMax;
+    *tMinOut = tMin;
+    return hit && (tMin < tMaxRay) && (tMx > 0);
+}
+
+// One traversal state machine step set, shared by the persistent kernel and the plain
+// per-ray routine. cur >= 0: interior node to open; -2: take the next stack entry; -1: done.
+struct TravState {
+    int cur, sp;
+};
+DEV void StackPush(TravSpill &sp, int lane, int &n, int node, int meta, float tmin) {
+    TravLds &lds = TravStack();
+    if (n < STACK_LDS) { lds.node[n][lane] = node; lds.meta[n][lane] = meta; lds.tmin[n][lane] = tmin; }
+    else {
+        // keep the LDS and the scratch path apart: merged into one store through a selected
+        // generic pointer, hipcc 7.2 emits an illegal address-space test for gfx950
+        sp.node[n - STACK_LDS] = node; sp.meta[n - STACK_LDS] = meta; sp.tmin[n - STACK_LDS] = tmin;
+        asm volatile("" ::: "memory");
+    }
+    ++n;
+}
+DEV void StackPop(TravSpill &sp, int lane, int &n, int *node, int *meta, float *tmin) {
+    TravLds &lds = TravStack();
+    --n;
+    if (n < STACK_LDS) { *node = lds.node[n][lane]; *meta = lds.meta[n][lane]; *tmin = lds.tmin[n][lane]; }
+    else {
+        int nd = sp.node[n - STACK_LDS], mt = sp.meta[n - STACK_LDS];
+        float tm = sp.tmin[n - STACK_LDS];
+        asm volatile("" : "+v"(nd), "+v"(mt), "+v"(tm));  // pins the scratch loads in this branch
+        *node = nd; *meta = mt; *tmin = tm;
+    }
+}
+// Advance until the lane holds a leaf (returns true with leafOffset/leafCount) or the
+// traversal is finished (returns false, st.cur == -1).
+DEV bool NextLeaf(const float4 *__restrict__ wnodes, const RayCtx &r, float tMax, TravState &st, TravSpill &spill,
+                  int lane, int *leafOffset, int *leafCount, unsigned &nodeCount) {
+    while (st.cur != -1) {
+        int tkChild = 0, tkMeta = 0;
+        bool got = false;
+        if (st.cur >= 0) {
+            const float4 a = wnodes[4 * st.cur], b = wnodes[4 * st.cur + 1], c = wnodes[4 * st.cur + 2];
+            const float4 dd = wnodes[4 * st.cur + 3];
+            const int childL = __float_as_int(dd.x), childR = __float_as_int(dd.y);
+            const int metaL = __float_as_int(dd.z), metaR = __float_as_int(dd.w);
+            const bool haveR = (metaR & 0xffff) != 0xffff;
+            float tL, tR = 0;
+            const bool hitL = BoxTest(r, a.x, a.y, a.z, a.w, b.x, b.y, tMax, &tL);
+            const bool hitR = haveR && BoxTest(r, b.z, b.w, c.x, c.y, c.z, c.w, tMax, &tR);
+            nodeCount += haveR ? 2 : 0;
+            const int axis = (metaL >> 16) & 0xff;
+            const bool negAxis = (axis == 0) ? r.n0 : ((axis == 1) ? r.n1 : r.n2);
+            // near child first (bvh.cpp:686-692): left unless the ray runs against the split axis
+            const bool hitF = negAxis ? hitR : hitL, hitS = negAxis ? hitL : hitR;
+            const int chF = negAxis ? childR : childL, chS = negAxis ? childL : childR;
+            const int mtF = (negAxis ? metaR : metaL) & 0xffff, mtS = (negAxis ? metaL : metaR) & 0xffff;
+            const float tS = negAxis ? tL : tR;
+            if (hitF) {
+                tkChild = chF; tkMeta = mtF; got = true;
+                if (hitS) StackPush(spill, lane, st.sp, chS, mtS, tS);
+            } else if (hitS) {
+                tkChild = chS; tkMeta = mtS; got = true;
+            }
+        }
+        while (!got && st.sp > 0) {  // a popped node is entered only if still in front of tMax
+            float t;
+            StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
+            got = t < tMax;
+        }
+        if (!got) { st.cur = -1; return false; }
+        if (tkMeta > 0) { *leafOffset = tkChild; *leafCount = tkMeta; st.cur = -2; return true; }
+        st.cur = tkChild;
+    }
+    return false;
+}
+DEV void StartTraversal(const DScene &s, const RayCtx &r, float tMax, TravState &st, unsigned &nodeCount) {
+    st.sp = 0;
+    st.cur = -1;
+    if (s.nNodes == 0) return;
+    float t;
+    ++nodeCount;
+    if (BoxTest(r, s.wbMin[0], s.wbMin[1], s.wbMin[2], s.wbMax[0], s.wbMax[1], s.wbMax[2], tMax, &t)) st.cur = 0;
+}
+
 constexpr int MAX_PENDING_SPHERES = 3;
 
+// Plain per-ray traversal with inline quadric tests (mi_pt_trace and the overflow path
+// of ResolveQuadrics).
 template <bool ANY>
-DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, int (*lds)[BLOCK],
-                  unsigned &nodeCount, unsigned &triCount) {
-    if (s.nNodes == 0) return false;
+DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
     const int lane = threadIdx.x;
-    const float idx = 1.f / rd.x, idy = 1.f / rd.y, idz = 1.f / rd.z;
-    const bool neg0 = idx < 0, neg1 = idy < 0, neg2 = idz < 0;
-    int spill[STACK_SPILL];
-    int sp = 0, cur = 0;
+    RayCtx r;
+    InitRayCtx(r, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+    TravSpill spill;
+    TravState st;
+    StartTraversal(s, r, tMax, st, nodeCount);
     bool found = false;
     int pend[MAX_PENDING_SPHERES];
     int nPend = 0;
-    const float k = 1 + 2 * gammaf(3);
-    const float4 *__restrict__ nodes = s.nodes;
     const float4 *__restrict__ primTri = s.primTri;
-    while (true) {
-        int leafOffset = 0, leafCount = 0;
-        // ---- phase 1: interior nodes
-        while (cur >= 0) {
-            const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
-            ++nodeCount;
-            const int offset = __float_as_int(nb.z);
-            const unsigned meta = __float_as_uint(nb.w);
-            bool hitBox;
-            {
-                float tMin = ((neg0 ? na.w : na.x) - ro.x) * idx;
-                float tMx = ((neg0 ? na.x : na.w) - ro.x) * idx;
-                float tyMin = ((neg1 ? nb.x : na.y) - ro.y) * idy;
-                float tyMax = ((neg1 ? na.y : nb.x) - ro.y) * idy;
-                tMx *= k;
-                tyMax *= k;
-                hitBox = !(tMin > tyMax || tyMin > tMx);
-                if (tyMin > tMin) tMin = tyMin;
-                if (tyMax < tMx) tMx = tyMax;
-                float tzMin = ((neg2 ? nb.y : na.z) - ro.z) * idz;
-                float tzMax = ((neg2 ? na.z : nb.y) - ro.z) * idz;
-                tzMax *= k;
-                hitBox = hitBox && !(tMin > tzMax || tzMin > tMx);
-                if (tzMin > tMin) tMin = tzMin;
-                if (tzMax < tMx) tMx = tzMax;
-                hitBox = hitBox && (tMin < tMax) && (tMx > 0);
-            }
-            const int nPrims = meta & 0xffff;
-            if (hitBox && nPrims == 0) {
-                const int axis = (meta >> 16) & 0xff;
-                const bool negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
-                const int farNode = negAxis ? cur + 1 : offset;
-                const int nearNode = negAxis ? offset : cur + 1;
-                if (sp < STACK_LDS) lds[sp][lane] = farNode;
-                else spill[sp - STACK_LDS] = farNode;
-                ++sp;
-                cur = nearNode;
-                continue;
-            }
-            // leaf or miss: the next node comes from the stack either way
-            if (sp == 0) cur = -1;
-            else { --sp; cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS]; }
-            if (hitBox) { leafOffset = offset; leafCount = nPrims; break; }
-        }
-        if (leafCount == 0) break;
-        // ---- phase 2: leaf primitives, in order, against the ray's current tMax
+    int leafOffset = 0, leafCount = 0;
+    while (NextLeaf(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount)) {
         for (int i = 0; i < leafCount; ++i) {
             const int prim = leafOffset + i;
             const float4 v0 = primTri[3 * prim];
@@ -227,18 +311,15 @@ DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *
             }
         }
     }
-    // ---- postponed quadrics
     for (int j = 0; j < nPend; ++j) {
-        {
-            const int prim = (j == 0) ? pend[0] : ((j == 1) ? pend[1] : pend[2]);
-            const int sph = __float_as_int(primTri[3 * prim + 1].w);
-            float t;
-            if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
-                if (ANY) return true;
-                tMax = t;
-                hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
-                found = true;
-            }
+        const int prim = (j == 0) ? pend[0] : ((j == 1) ? pend[1] : pend[2]);
+        const int sph = __float_as_int(primTri[3 * prim + 1].w);
+        float t;
+        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+            if (ANY) return true;
+            tMax = t;
+            hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+            found = true;
         }
     }
     return found;
@@ -251,11 +332,10 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 // hit; 1: NEE shadow rays of shadowQ, any hit; 2: MIS rays of misQ, closest hit). A fixed
 // grid of waves pulls rays from a device-wide cursor: lanes whose ray finished fetch a new
 // one as soon as fewer than REFILL_BELOW lanes of the wave are still traversing (dynamic
-// fetch), so a long ray no longer idles the other 63 lanes. Per ray the node / primitive
-// order is the reference's (see Traverse above); quadrics are only recorded (I_PEND*),
-// k_resolve_* tests them afterwards at full lane utilisation.
+// fetch), so a long ray no longer idles the other 63 lanes. Quadrics are only recorded
+// (I_PEND*); k_resolve_* tests them afterwards at full lane utilisation.
 #ifndef MIPT_TRAV_BLOCKS_PER_CU
-#define MIPT_TRAV_BLOCKS_PER_CU 5
+#define MIPT_TRAV_BLOCKS_PER_CU 4
 #endif
 #ifndef MIPT_REFILL_BELOW
 #define MIPT_REFILL_BELOW 32
@@ -265,26 +345,25 @@ constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
 
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
     constexpr bool ANY = (MODE == 1);
     constexpr int PO = (MODE == 0) ? P_OX : ((MODE == 1) ? P_SOX : P_MOX);
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
     const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount : ctr->misCount);
     const uint32_t *__restrict__ queue = (MODE == 1) ? pool.shadowQ : pool.misQ;
-    const float4 *__restrict__ nodes = s.nodes;
     const float4 *__restrict__ primTri = s.primTri;
-    const float k = 1 + 2 * gammaf(3);
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
-    // per-lane ray state
     bool has = false;
     uint32_t slot = 0;
-    float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 0, idx = 0, idy = 0, idz = 0, tMax = 0;
-    bool neg0 = false, neg1 = false, neg2 = false;
-    int sp = 0, cur = -1, nPend = 0, hitPrim = -1;
+    RayCtx r;
+    InitRayCtx(r, 0, 0, 0, 1, 1, 1);
+    float tMax = 0;
+    TravState st;
+    st.cur = -1; st.sp = 0;
+    TravSpill spill;
+    int nPend = 0, hitPrim = -1;
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
-    int spill[STACK_SPILL];
-    bool exhausted = (s.nNodes == 0 && false);
+    bool exhausted = false;
     while (true) {
         // ---- fetch rays for idle lanes
         if (!exhausted) {
@@ -302,12 +381,11 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
                         if (MODE == 0) { slot = my; take = (pool.I(I_FLAGS, slot) & F_ALIVE) != 0; }
                         else slot = queue[my];
                         if (take) {
-                            rox = pool.F(PO + 0, slot); roy = pool.F(PO + 1, slot); roz = pool.F(PO + 2, slot);
-                            rdx = pool.F(PO + 3, slot); rdy = pool.F(PO + 4, slot); rdz = pool.F(PO + 5, slot);
+                            InitRayCtx(r, pool.F(PO + 0, slot), pool.F(PO + 1, slot), pool.F(PO + 2, slot), pool.F(PO + 3, slot),
+                                       pool.F(PO + 4, slot), pool.F(PO + 5, slot));
                             tMax = (MODE == 0) ? pool.F(P_TMAX, slot) : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
-                            idx = 1.f / rdx; idy = 1.f / rdy; idz = 1.f / rdz;
-                            neg0 = idx < 0; neg1 = idy < 0; neg2 = idz < 0;
-                            sp = 0; cur = (s.nNodes > 0) ? 0 : -1; nPend = 0; hitPrim = -1;
+                            StartTraversal(s, r, tMax, st, nodeCount);
+                            nPend = 0; hitPrim = -1;
                             hitT = hitB0 = hitB1 = hitB2 = 0;
                             has = true;
                             ++rayCount;
@@ -323,52 +401,15 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
         // ---- traverse until enough lanes have run dry
         while (true) {
             int leafOffset = 0, leafCount = 0;
+            bool finished = false;
             if (has) {
-                while (cur >= 0) {  // phase 1: interior nodes
-                    const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
-                    ++nodeCount;
-                    const int offset = __float_as_int(nb.z);
-                    const unsigned meta = __float_as_uint(nb.w);
-                    bool hitBox;
-                    {
-                        float tMin = ((neg0 ? na.w : na.x) - rox) * idx;
-                        float tMx = ((neg0 ? na.x : na.w) - rox) * idx;
-                        float tyMin = ((neg1 ? nb.x : na.y) - roy) * idy;
-                        float tyMax = ((neg1 ? na.y : nb.x) - roy) * idy;
-                        tMx *= k;
-                        tyMax *= k;
-                        hitBox = !(tMin > tyMax || tyMin > tMx);
-                        if (tyMin > tMin) tMin = tyMin;
-                        if (tyMax < tMx) tMx = tyMax;
-                        float tzMin = ((neg2 ? nb.y : na.z) - roz) * idz;
-                        float tzMax = ((neg2 ? na.z : nb.y) - roz) * idz;
-                        tzMax *= k;
-                        hitBox = hitBox && !(tMin > tzMax || tzMin > tMx);
-                        if (tzMin > tMin) tMin = tzMin;
-                        if (tzMax < tMx) tMx = tzMax;
-                        hitBox = hitBox && (tMin < tMax) && (tMx > 0);
-                    }
-                    const int nPrims = meta & 0xffff;
-                    if (hitBox && nPrims == 0) {
-                        const int axis = (meta >> 16) & 0xff;
-                        const bool negAxis = (axis == 0) ? neg0 : ((axis == 1) ? neg1 : neg2);
-                        const int farNode = negAxis ? cur + 1 : offset;
-                        const int nearNode = negAxis ? offset : cur + 1;
-                        if (sp < STACK_LDS) lds[sp][lane] = farNode;
-                        else spill[sp - STACK_LDS] = farNode;
-                        ++sp;
-                        cur = nearNode;
-                        continue;
-                    }
-                    if (sp == 0) cur = -1;
-                    else { --sp; cur = (sp < STACK_LDS) ? lds[sp][lane] : spill[sp - STACK_LDS]; }
-                    if (hitBox) { leafOffset = offset; leafCount = nPrims; break; }
-                }
+                const bool leaf = NextLeaf(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount);
+                finished = !leaf;
+                if (!leaf) leafCount = 0;
             }
-            bool finished = has && leafCount == 0;  // stack empty and no leaf left: this ray is done
             if (has && leafCount > 0) {
-                const V3 ro(rox, roy, roz), rd(rdx, rdy, rdz);
-                for (int i = 0; i < leafCount; ++i) {  // phase 2: leaf primitives
+                const V3 ro(r.ox, r.oy, r.oz), rd(r.dx, r.dy, r.dz);
+                for (int i = 0; i < leafCount; ++i) {  // leaf primitives, in order, against the current tMax
                     const int prim = leafOffset + i;
                     const float4 v0 = primTri[3 * prim];
                     const unsigned pf = __float_as_uint(v0.w);
@@ -411,14 +452,14 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
 // reference-order routine with inline quadric tests.
 template <bool ANY>
 DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
-                         Hit *h, bool foundTri, int (*lds)[BLOCK], unsigned &nodes, unsigned &tris) {
+                         Hit *h, bool foundTri, unsigned &nodes, unsigned &tris) {
     const int np = pool.I(I_NPEND, slot);
     bool found = foundTri;
     if (np & PEND_OVERFLOW) {
         Hit h2;
         h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
         unsigned n2 = 0, t2 = 0;  // statistics were already counted by k_trav
-        found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, lds, n2, t2);
+        found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, n2, t2);
         if (found) *h = h2;
         return found;
     }
@@ -438,7 +479,6 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
 }
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     bool traced = false;
     int cls = 0;
@@ -451,7 +491,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
             V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
             Hit h;
             h.prim = prim; h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
-            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, pool.F(P_TMAX, slot), &h, prim >= 0, lds, nodes, tris);
+            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, pool.F(P_TMAX, slot), &h, prim >= 0, nodes, tris);
             prim = found ? h.prim : -1;
             pool.I(I_HITPRIM, slot) = prim;
             pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
@@ -463,7 +503,6 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
 }
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
     if (qi < ctr->shadowCount) {
@@ -474,7 +513,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
             V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
             V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
             Hit h;
-            occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, lds, nodes, tris);
+            occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
         }
         bool added = false;
         if (!occluded) {
@@ -493,7 +532,6 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
 }
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
-    __shared__ int lds[STACK_LDS][BLOCK];
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
     if (qi < ctr->misCount) {
@@ -504,7 +542,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
         Hit h;
         h.prim = pool.I(I_HITPRIM, slot); h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
         bool found = h.prim >= 0;
-        if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, lds, nodes, tris);
+        if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris);
         bool added = false;
         if (found) {
             const int lightNum = pool.I(I_MISLIGHT, slot);
@@ -960,7 +998,6 @@ __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcIn
 
 // ------------------------------------------------------------------ standalone traversal (mi_pt_trace)
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, uint32_t n, int anyHit, float *hits) {
-    __shared__ int lds[STACK_LDS][BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *r = rays + (size_t)i * 7;
@@ -969,8 +1006,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, ui
     Hit h;
     h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
     int prim;
-    if (anyHit) prim = Traverse<true>(s, ro, rd, r[6], &h, lds, nodes, tris) ? 0 : -1;
-    else prim = Traverse<false>(s, ro, rd, r[6], &h, lds, nodes, tris) ? h.prim : -1;
+    if (anyHit) prim = Traverse<true>(s, ro, rd, r[6], &h, nodes, tris) ? 0 : -1;
+    else prim = Traverse<false>(s, ro, rd, r[6], &h, nodes, tris) ? h.prim : -1;
     float *o = hits + (size_t)i * 4;
     o[0] = __int_as_float(prim);
     o[1] = (prim >= 0 && !anyHit) ? h.t : 0.f;
@@ -1095,6 +1132,45 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         const float4 *nodes;
         UP((const float4 *)d->nodes, (size_t)d->n_nodes * 2, nodes);
         s.nodes = nodes;
+    }
+    {   // wide nodes: one 64-B record per interior node with both children's boxes
+        const uint32_t nN = d->n_nodes;
+        std::vector<int32_t> widx(nN, -1);
+        uint32_t nInterior = 0;
+        for (uint32_t i = 0; i < nN; ++i) if (d->nodes[i].n_prims == 0) widx[i] = (int32_t)nInterior++;
+        const bool rootLeaf = nN > 0 && d->nodes[0].n_prims > 0;
+        std::vector<float4> w((size_t)std::max<uint32_t>(nInterior, 1) * 4, float4{0, 0, 0, 0});
+        auto putChild = [&](float4 *rec, int which, uint32_t child, int axis) {
+            const mi_bvh_node &c = d->nodes[child];
+            int link, meta;
+            if (c.n_prims > 0) { link = c.offset; meta = c.n_prims; }
+            else { link = widx[child]; meta = 0; }
+            if (which == 0) {
+                rec[0] = float4{c.bmin[0], c.bmin[1], c.bmin[2], c.bmax[0]};
+                rec[1].x = c.bmax[1]; rec[1].y = c.bmax[2];
+                meta |= axis << 16;
+                memcpy(&rec[3].x, &link, 4); memcpy(&rec[3].z, &meta, 4);
+            } else {
+                rec[1].z = c.bmin[0]; rec[1].w = c.bmin[1];
+                rec[2] = float4{c.bmin[2], c.bmax[0], c.bmax[1], c.bmax[2]};
+                memcpy(&rec[3].y, &link, 4); memcpy(&rec[3].w, &meta, 4);
+            }
+        };
+        if (rootLeaf) {  // single-leaf tree: the root itself is the left "child", no right child
+            putChild(&w[0], 0, 0, 0);
+            const int absent = 0xffff;
+            memcpy(&w[3].w, &absent, 4);
+        } else {
+            for (uint32_t i = 0; i < nN; ++i) {
+                if (d->nodes[i].n_prims != 0) continue;
+                float4 *rec = &w[(size_t)widx[i] * 4];
+                putChild(rec, 0, i + 1, d->nodes[i].axis);
+                putChild(rec, 1, (uint32_t)d->nodes[i].offset, d->nodes[i].axis);
+            }
+        }
+        const float4 *dev;
+        UP(w.data(), w.size(), dev);
+        s.wnodes = dev;
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
     {
