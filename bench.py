@@ -65,6 +65,8 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    n_dev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, n_dev)   # rehearsal on a 1-GPU box: ranks share device 0
     torch.cuda.set_device(local_rank)
 
     total_spp = a.steps * a.spp_per_step

@@ -21,7 +21,10 @@
 // No MFMA: this path is latency/bandwidth bound (traversal) and VALU bound (shading).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -598,6 +601,8 @@ DEV void CameraRay(const DScene &s, float pFilmX, float pFilmY, float lensU, flo
 // atomics) instead of 64 rows.
 __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *film, DevCounters *ctr, WorkDesc wd) {
     __shared__ float sL[BLOCK * 33];
+    __shared__ float sFilter[256];  // the 16x16 filter table, one LDS copy per block
+    sFilter[threadIdx.x] = s.filterTable[threadIdx.x];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = slot < pool.n;
     int flags = valid ? pool.I(I_FLAGS, slot) : 0;
@@ -662,7 +667,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                     for (int x2 = p0x; x2 < p1x; ++x2) {
                         float fx = absf((x2 - dx) * invRx * filterTableSize);
                         int ix = min((int)floorf(fx), filterTableSize - 1);
-                        float fw = s.filterTable[iy * filterTableSize + ix];
+                        float fw = sFilter[iy * filterTableSize + ix];
                         size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
                         float *dst = film + pix * 32 + bin;
                         if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
@@ -1030,6 +1035,16 @@ __global__ void k_film_split(const float *film32, float *filmSum, float *weightS
 // =============================================================================
 // C ABI
 // =============================================================================
+struct SubRenderer {
+    Pool pool{};
+    DevCounters *ctr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evIter[2][6] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
+    double t[6] = {0};
+    unsigned long long iterations = 0;
+    DevCounters result{};
+};
+
 struct mi_pt {
     int device = 0;
     DScene scene{};
@@ -1038,14 +1053,8 @@ struct mi_pt {
     size_t nPix = 0;
     int filmW = 0, filmH = 0;
     long long spp = 0;
-    Pool pool{};
-    DevCounters *ctr = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
-    hipEvent_t evIter[2][6] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
+    std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
-    unsigned long long lastLaunches[3] = {0, 0, 0};
-    bool haveEvents = false;
     bool haveLargeMaterials = false;  // some material has more than 2 lobes (second shading class)
     int numCUs = 256;
 };
@@ -1070,21 +1079,20 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
     return MI_OK;
 }
 
-int EnsurePool(mi_pt *pt, uint32_t n) {
-    if (pt->pool.n == n && pt->pool.f) return MI_OK;
-    if (pt->pool.f) {
-        hipFree(pt->pool.f); hipFree(pt->pool.i); hipFree(pt->pool.shadowQ); hipFree(pt->pool.misQ);
-        hipFree(pt->pool.shadeQ[0]); hipFree(pt->pool.shadeQ[1]);
-        pt->pool.f = nullptr; pt->pool.i = nullptr; pt->pool.shadowQ = pt->pool.misQ = nullptr;
-        pt->pool.shadeQ[0] = pt->pool.shadeQ[1] = nullptr;
+int EnsurePool(SubRenderer &sub, uint32_t n) {
+    Pool &p = sub.pool;
+    if (p.n == n && p.f) return MI_OK;
+    if (p.f) {
+        hipFree(p.f); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ[0]); hipFree(p.shadeQ[1]);
+        p.f = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ[0] = p.shadeQ[1] = nullptr;
     }
-    HIPCHK(hipMalloc((void **)&pt->pool.f, (size_t)P_COUNT * n * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&pt->pool.i, (size_t)I_COUNT * n * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&pt->pool.shadowQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&pt->pool.misQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&pt->pool.shadeQ[0], (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&pt->pool.shadeQ[1], (size_t)n * sizeof(uint32_t)));
-    pt->pool.n = n;
+    HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&p.shadeQ[0], (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&p.shadeQ[1], (size_t)n * sizeof(uint32_t)));
+    p.n = n;
     return MI_OK;
 }
 
@@ -1319,12 +1327,96 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     pt->nPix = (size_t)pt->filmW * pt->filmH;
     if (hipMalloc((void **)&pt->film, pt->nPix * 32 * sizeof(float)) != hipSuccess) { g_err = "hipMalloc(film) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
     hipMemset(pt->film, 0, pt->nPix * 32 * sizeof(float));
-    if (hipMalloc((void **)&pt->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
-    hipEventCreate(&pt->evStart);
-    hipEventCreate(&pt->evStop);
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventCreate(&pt->evIter[a][b]);
-    pt->haveEvents = true;
+    {
+        int nSub = 2;  // concurrent sub-renderers (MIPT_STREAMS overrides, 1..4)
+        if (const char *e = getenv("MIPT_STREAMS")) nSub = std::max(1, std::min(4, atoi(e)));
+        pt->subs.resize(nSub);
+        for (SubRenderer &sub : pt->subs) {
+            if (hipMalloc((void **)&sub.ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
+            if (hipStreamCreateWithFlags(&sub.stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventCreate(&sub.evIter[a][b]);
+        }
+    }
     *out = pt;
+    return MI_OK;
+}
+
+// One sub-renderer = one path pool with its queues and counters on its own HIP stream.
+// mi_pt_render splits its tile shard over pt->subs.size() sub-renderers that run
+// concurrently (one host thread each): while one pool is in a traversal kernel's tail
+// the other pool's kernels fill the idle CUs, which a single dependent chain of launches
+// cannot do.
+static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, int subIndex, int subCount) {
+    HIPCHK(hipSetDevice(pt->device));
+    hipStream_t st = sub.stream;
+    const DScene &s = pt->scene;
+    WorkDesc wd{};
+    wd.nTilesX = (s.sampleBounds[2] - s.sampleBounds[0] + 15) / 16;
+    wd.nTilesY = (s.sampleBounds[3] - s.sampleBounds[1] + 15) / 16;
+    const int nTiles = wd.nTilesX * wd.nTilesY;
+    wd.shardIndex = rp->shard_index + rp->shard_count * subIndex;
+    wd.shardCount = rp->shard_count * subCount;
+    wd.nTilesShard = (wd.shardIndex < nTiles) ? (nTiles - wd.shardIndex + wd.shardCount - 1) / wd.shardCount : 0;
+    wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
+    wd.sampleBegin = rp->sample_begin;
+    wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
+    sub.iterations = 0;
+    for (double &t : sub.t) t = 0;
+    sub.result = DevCounters{};
+    if (wd.totalWork == 0) return MI_OK;
+    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 21);
+    poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
+    if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
+    if (poolN < BLOCK) poolN = BLOCK;
+    int rc = EnsurePool(sub, poolN);
+    if (rc != MI_OK) return rc;
+    HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));
+    const dim3 grid((poolN + BLOCK - 1) / BLOCK), block(BLOCK);
+    const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
+    unsigned alive = 1;
+    // Per-kernel-class time: HIP events at the kernel boundaries of every iteration,
+    // read back after the per-iteration sync that the alive counter needs anyway.
+    auto harvest = [&](int set, bool full) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, sub.evIter[set][0], sub.evIter[set][1]); sub.t[1] += ms * 1e-3;
+        if (!full) return;
+        hipEventElapsedTime(&ms, sub.evIter[set][1], sub.evIter[set][2]); sub.t[2] += ms * 1e-3;
+        hipEventElapsedTime(&ms, sub.evIter[set][2], sub.evIter[set][3]); sub.t[3] += ms * 1e-3;
+        hipEventElapsedTime(&ms, sub.evIter[set][3], sub.evIter[set][4]); sub.t[4] += ms * 1e-3;
+        hipEventElapsedTime(&ms, sub.evIter[set][4], sub.evIter[set][5]); sub.t[5] += ms * 1e-3;
+    };
+    int set = 0;
+    bool prevFull = false, havePrev = false;
+    while (true) {
+        hipEvent_t *ev = sub.evIter[set];
+        HIPCHK(hipMemsetAsync(&sub.ctr->alive, 0, 8 * sizeof(unsigned), st));
+        HIPCHK(hipEventRecord(ev[0], st));
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, sub.pool, pt->film, sub.ctr, wd);
+        HIPCHK(hipEventRecord(ev[1], st));
+        HIPCHK(hipMemcpyAsync(&alive, &sub.ctr->alive, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (havePrev) harvest(set ^ 1, prevFull);
+        if (alive == 0) { harvest(set, false); break; }
+        hipLaunchKernelGGL(k_trav<0>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipEventRecord(ev[2], st));
+        hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, sub.pool, sub.ctr, 0);
+        if (pt->haveLargeMaterials) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, grid, block, 0, st, s, sub.pool, sub.ctr, 1);
+        HIPCHK(hipEventRecord(ev[3], st));
+        hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipEventRecord(ev[4], st));
+        hipLaunchKernelGGL(k_trav<2>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipEventRecord(ev[5], st));
+        havePrev = true; prevFull = true;
+        set ^= 1;
+        if (++sub.iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(&sub.result, sub.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 
@@ -1333,80 +1425,36 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     if (rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) { g_err = "bad shard"; return MI_ERR_INVALID; }
     HIPCHK(hipSetDevice(pt->device));
     hipStream_t st = (hipStream_t)rp->stream;
-    const DScene &s = pt->scene;
-    WorkDesc wd{};
-    wd.nTilesX = (s.sampleBounds[2] - s.sampleBounds[0] + 15) / 16;
-    wd.nTilesY = (s.sampleBounds[3] - s.sampleBounds[1] + 15) / 16;
-    const int nTiles = wd.nTilesX * wd.nTilesY;
-    wd.shardIndex = rp->shard_index; wd.shardCount = rp->shard_count;
-    wd.nTilesShard = (nTiles - rp->shard_index + rp->shard_count - 1) / rp->shard_count;
-    wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
-    wd.sampleBegin = rp->sample_begin;
-    wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
-    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 21);
-    if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
-    if (poolN < BLOCK) poolN = BLOCK;
-    int rc = EnsurePool(pt, poolN);
-    if (rc != MI_OK) return rc;
     if (!(rp->flags & MI_RENDER_ACCUMULATE)) HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(pt->pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(pt->ctr, 0, sizeof(DevCounters), st));
-    const dim3 grid((poolN + BLOCK - 1) / BLOCK), block(BLOCK);
-    const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
-    HIPCHK(hipEventRecord(pt->evStart, st));
-    unsigned alive = 1;
-    unsigned long long iterations = 0;
-    double tGen = 0, tExt = 0, tShade = 0, tShadow = 0, tMis = 0;
-    // Per-kernel-class time: HIP events at the kernel boundaries of every iteration,
-    // read back after the per-iteration sync that the alive counter needs anyway.
-    auto harvest = [&](int set, bool full) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, pt->evIter[set][0], pt->evIter[set][1]); tGen += ms;
-        if (!full) return;
-        hipEventElapsedTime(&ms, pt->evIter[set][1], pt->evIter[set][2]); tExt += ms;
-        hipEventElapsedTime(&ms, pt->evIter[set][2], pt->evIter[set][3]); tShade += ms;
-        hipEventElapsedTime(&ms, pt->evIter[set][3], pt->evIter[set][4]); tShadow += ms;
-        hipEventElapsedTime(&ms, pt->evIter[set][4], pt->evIter[set][5]); tMis += ms;
-    };
-    int set = 0;
-    bool prevFull = false, havePrev = false;
-    while (true) {
-        hipEvent_t *ev = pt->evIter[set];
-        HIPCHK(hipMemsetAsync(&pt->ctr->alive, 0, 8 * sizeof(unsigned), st));
-        HIPCHK(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, pt->pool, pt->film, pt->ctr, wd);
-        HIPCHK(hipEventRecord(ev[1], st));
-        HIPCHK(hipMemcpyAsync(&alive, &pt->ctr->alive, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (havePrev) harvest(set ^ 1, prevFull);
-        if (alive == 0) { harvest(set, false); break; }
-        hipLaunchKernelGGL(k_trav<0>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
-        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, pt->pool, pt->ctr);
-        HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, pt->pool, pt->ctr, 0);
-        if (pt->haveLargeMaterials) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, grid, block, 0, st, s, pt->pool, pt->ctr, 1);
-        HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
-        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, pt->pool, pt->ctr);
-        HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_trav<2>, travGrid, block, 0, st, s, pt->pool, pt->ctr);
-        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, pt->pool, pt->ctr);
-        HIPCHK(hipEventRecord(ev[5], st));
-        havePrev = true; prevFull = true;
-        set ^= 1;
-        if (++iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; }
-    }
-    HIPCHK(hipEventRecord(pt->evStop, st));
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    float ms = 0;
-    hipEventElapsedTime(&ms, pt->evStart, pt->evStop);
-    pt->lastSeconds[0] = ms * 1e-3;
-    pt->lastSeconds[1] = tGen * 1e-3; pt->lastSeconds[2] = tExt * 1e-3; pt->lastSeconds[3] = tShade * 1e-3;
-    pt->lastSeconds[4] = tShadow * 1e-3; pt->lastSeconds[5] = tMis * 1e-3;
+    const int nSub = (int)pt->subs.size();
+    std::vector<int> rcs(nSub, MI_OK);
+    std::vector<std::string> errs(nSub);
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> threads;
+        for (int k = 1; k < nSub; ++k)
+            threads.emplace_back([&, k] { rcs[k] = RenderSub(pt, pt->subs[k], rp, k, nSub); errs[k] = g_err; });
+        rcs[0] = RenderSub(pt, pt->subs[0], rp, 0, nSub);
+        errs[0] = g_err;
+        for (auto &t : threads) t.join();
+    }
+    for (int k = 0; k < nSub; ++k) if (rcs[k] != MI_OK) { g_err = errs[k]; return rcs[k]; }
+    HIPCHK(hipDeviceSynchronize());
+    pt->lastSeconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    unsigned long long iterations = 0;
+    DevCounters c{};
+    for (int i = 1; i < 6; ++i) pt->lastSeconds[i] = 0;
+    for (const SubRenderer &sub : pt->subs) {
+        for (int i = 1; i < 6; ++i) pt->lastSeconds[i] += sub.t[i];
+        iterations += sub.iterations;
+        const DevCounters &r = sub.result;
+        c.cameraRays += r.cameraRays; c.regularRays += r.regularRays; c.shadowRays += r.shadowRays;
+        c.totalPaths += r.totalPaths; c.zeroRadiancePaths += r.zeroRadiancePaths; c.pathLengthSum += r.pathLengthSum;
+        c.nodesVisited += r.nodesVisited; c.triTests += r.triTests; c.badSamples += r.badSamples;
+        c.extendNodes += r.extendNodes; c.extendTris += r.extendTris; c.extendRays += r.extendRays;
+    }
     if (counters) {
-        DevCounters c;
-        HIPCHK(hipMemcpy(&c, pt->ctr, sizeof(c), hipMemcpyDeviceToHost));
         *counters = mi_counters{};
         counters->camera_rays = c.cameraRays; counters->regular_rays = c.regularRays; counters->shadow_rays = c.shadowRays;
         counters->total_paths = c.totalPaths; counters->zero_radiance_paths = c.zeroRadiancePaths;
@@ -1468,18 +1516,20 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
 void mi_pt_destroy(mi_pt *pt) {
     if (!pt) return;
     hipSetDevice(pt->device);
+    hipDeviceSynchronize();
     for (void *p : pt->allocs) hipFree(p);
     if (pt->film) hipFree(pt->film);
-    if (pt->pool.f) hipFree(pt->pool.f);
-    if (pt->pool.i) hipFree(pt->pool.i);
-    if (pt->pool.shadowQ) hipFree(pt->pool.shadowQ);
-    if (pt->pool.misQ) hipFree(pt->pool.misQ);
-    if (pt->pool.shadeQ[0]) hipFree(pt->pool.shadeQ[0]);
-    if (pt->pool.shadeQ[1]) hipFree(pt->pool.shadeQ[1]);
-    if (pt->ctr) hipFree(pt->ctr);
-    if (pt->haveEvents) {
-        hipEventDestroy(pt->evStart); hipEventDestroy(pt->evStop);
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventDestroy(pt->evIter[a][b]);
+    for (SubRenderer &sub : pt->subs) {
+        Pool &p = sub.pool;
+        if (p.f) hipFree(p.f);
+        if (p.i) hipFree(p.i);
+        if (p.shadowQ) hipFree(p.shadowQ);
+        if (p.misQ) hipFree(p.misQ);
+        if (p.shadeQ[0]) hipFree(p.shadeQ[0]);
+        if (p.shadeQ[1]) hipFree(p.shadeQ[1]);
+        if (sub.ctr) hipFree(sub.ctr);
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
+        if (sub.stream) hipStreamDestroy(sub.stream);
     }
     delete pt;
 }

@@ -21,7 +21,7 @@ def init_from_env(backend=None):
             os.environ.setdefault("MASTER_PORT", "29533")
             if backend is None:
                 import torch
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("MIPT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -36,6 +36,14 @@ def reduce_film(film, weight=None, dst=0):
     by exactly one rank when the filter radius is 0.5, so the sum is exact (x + 0)."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
+        return film, weight
+    if dist.get_backend() == "gloo" and film.is_cuda:
+        # rehearsal mode (several ranks sharing one GPU, MIPT_DIST_BACKEND=gloo): reduce on the host
+        for t in (film, weight):
+            if t is not None:
+                h = t.cpu()
+                dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
+                t.copy_(h)
         return film, weight
     dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     if weight is not None:
