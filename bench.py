@@ -5,23 +5,25 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): killeroo-simple.pbrt, 700x700, PathIntegrator maxdepth 5,
-Halton, box filter, SampledSpectrum-31 -- BASELINE.json configs[1] (1024 spp on one
-MI355X). A *step* is one pass of the wavefront pipeline over the whole film for a block
-of `--spp-per-step` (64) consecutive Halton sample numbers; K = 16 steps accumulate the
-1024-spp film of configs[1]. The scene (BVH, meshes, tables) and the film are resident
-in HBM before the timed region starts; nothing crosses PCIe inside it.
+Halton, box filter, SampledSpectrum-31, 1024 spp -- BASELINE.json configs[1]. A *step*
+is one complete render of that frame (all 1024 samples of every pixel through the
+wavefront pipeline, film accumulated on the device); K steps render the frame K times.
+The scene (BVH, meshes, tables) and the film are resident in HBM before the timed region
+starts; nothing crosses PCIe inside it.
 
 With N > 1 the film's 16x16 tiles are sharded over the ranks (tile_id % N == rank, same
 Halton indices as the 1-GPU render), each rank accumulates into its own device film and
-one RCCL sum-reduce of the film closes the timed region (strong scaling: total work is
-the fixed 1024-spp frame). A ray = one Scene::Intersect or Scene::IntersectP call
+one RCCL sum-reduce of the film closes every step (strong scaling: total work is the
+fixed 1024-spp frame). A ray = one Scene::Intersect or Scene::IntersectP call
 (src/core/scene.cpp:40-55), counted on the device.
 
 The JSON line also carries
-  roofline:      closest-hit traversal kernel (k_extend), algorithmic bytes
+  roofline:      closest-hit traversal (k_trav<0>), algorithmic bytes
                  B_ray = 32*N_node + 48*N_tri + 64 with N_node/N_tri counted by the kernel,
-                 divided by the kernel's average launch duration (HIP events on the
-                 render stream, inside mi_pt_render), against the 8 TB/s HBM peak
+                 divided by the kernel's average launch duration (HIP events on the stream
+                 each launch goes to, inside mi_pt_render), against the 8 TB/s HBM peak.
+                 The render runs MIPT_STREAMS sub-renderers concurrently, so a launch
+                 shares the CUs with the other streams' kernels while it is timed.
   cpu_baseline:  the CPU oracle (a port of the reference algorithm, oracle/) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -41,17 +43,22 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (configs[1]: 1024)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--pool", type=int, default=0, help="resident path slots (0 = library default)")
-    ap.add_argument("--cpu-samples", type=int, default=24_000_000,
+    ap.add_argument("--cpu-samples", type=int, default=80_000_000,
                     help="camera samples the CPU oracle renders for cpu_baseline (0 = skip)")
+    ap.add_argument("--exclusive-spp", type=int, default=64,
+                    help="spp of the extra one-stream pass that times the traversal kernel alone (0 = skip)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per k_extend launch from a separate rocprofv3 --pmc pass")
     a = ap.parse_args()
 
+    # four sub-renderer streams need their own hardware queues (HIP maps streams onto 4 by default)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("MIPT_STREAMS", "4")
     import torch
     import pbrt_v3_spectral_amd as pt
     import importlib.util
@@ -69,7 +76,7 @@ def main():
     local_rank = local_rank % max(1, n_dev)   # rehearsal on a 1-GPU box: ranks share device 0
     torch.cuda.set_device(local_rank)
 
-    total_spp = a.steps * a.spp_per_step
+    total_spp = a.spp
     scene = pt.Scene(a.scene, spp=total_spp)
     integ = pt.CreatePathIntegrator(scene, local_rank)
     w, h = scene.film_size
@@ -77,40 +84,29 @@ def main():
     weight = torch.zeros((h, w), dtype=torch.float32, device="cuda")
     si, sc = ptdist.shard_of(rank, world)
 
-    def step(k, accumulate, out=False):
-        integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=k * a.spp_per_step,
-                     path_pool=a.pool, accumulate=accumulate, download=False,
-                     film_out=film.data_ptr() if out else None, weight_out=weight.data_ptr() if out else None)
+    def step():
+        integ.Render(shard_index=si, shard_count=sc, path_pool=a.pool,
+                     film_out=film.data_ptr(), weight_out=weight.data_ptr())
+        ptdist.reduce_film(film, weight, dst=0)   # RCCL sum over xGMI (no-op for N = 1)
 
-    # untimed warm-up steps (discarded: the first timed step clears the film)
     for k in range(a.warmup):
-        if k == 0:
-            integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=0, path_pool=a.pool,
-                         download=False)
-        else:
-            step(k, True)
+        step()
 
     keys = ("camera_rays", "regular_rays", "shadow_rays", "extend_rays", "extend_nodes", "extend_tri_tests",
             "iterations", "bvh_nodes_visited", "tri_tests")
     acc = dict.fromkeys(keys, 0)
-    t_kernel = [0.0] * 6
+    t_kernel = [0.0] * 7
     ptdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        last = (k == a.steps - 1)
-        if last:
-            integ.Render(shard_index=si, shard_count=sc, spp=a.spp_per_step, sample_begin=k * a.spp_per_step,
-                         path_pool=a.pool, accumulate=(k > 0), film_out=film.data_ptr(), weight_out=weight.data_ptr())
-        else:
-            step(k, k > 0)
+        step()
         c = integ.counters.as_dict()
         for key in keys:
             acc[key] += c[key]
         tk = integ.timings()
-        for i in range(6):
+        for i in range(7):
             t_kernel[i] += tk[i]
-    ptdist.reduce_film(film, weight, dst=0)   # RCCL sum over xGMI (no-op for N = 1)
     ptdist.barrier()
     torch.cuda.synchronize()
     dt = ptdist.max_over_ranks(time.perf_counter() - t0)
@@ -128,16 +124,44 @@ def main():
     n_tri = acc["extend_tri_tests"] / ext_rays
     b_ray = 32.0 * n_node + 48.0 * n_tri + 64.0
     bytes_per_launch = b_ray * ext_rays / n_launch
-    avg_launch_s = t_kernel[2] / n_launch
+    avg_launch_s = t_kernel[6] / n_launch
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": a.pmc_traffic,
+    traffic = a.pmc_traffic
+    if traffic is None:   # HBM bytes per k_trav<0> launch from the committed rocprofv3 --pmc passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                tr = json.load(fh)
+            if tr.get("workload_spp") == a.spp and tr.get("streams") == int(os.environ.get("MIPT_STREAMS", "0")) \
+                    and world == 1 and a.pool == 0:
+                traffic = tr["k_trav0_hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_trav<0>", "concurrent_streams": int(os.environ.get("MIPT_STREAMS", "2")), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tri_tests_per_ray": round(n_tri, 2),
                 "rays_per_launch": round(ext_rays / n_launch), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "launches": n_launch,
-                "kernel_time_s": {"generate": round(t_kernel[1], 4), "extend": round(t_kernel[2], 4),
+                "kernel_time_s": {"generate": round(t_kernel[1], 4), "trav0": round(t_kernel[6], 4), "extend": round(t_kernel[2], 4),
                                   "shade": round(t_kernel[3], 4), "shadow": round(t_kernel[4], 4),
                                   "mis": round(t_kernel[5], 4), "render_loop": round(t_kernel[0], 4)}}
+
+    # The same kernel with the GPU to itself: one untimed 64-spp pass through a one-stream
+    # integrator (rank 0, N = 1), so the concurrent-launch figure above has its reference.
+    if rank == 0 and world == 1 and a.exclusive_spp > 0:
+        os.environ["MIPT_STREAMS"] = "1"
+        solo = pt.CreatePathIntegrator(scene, local_rank)
+        os.environ["MIPT_STREAMS"] = str(roofline["concurrent_streams"])
+        for _ in range(2):   # first pass allocates the pool
+            solo.Render(spp=a.exclusive_spp, path_pool=1 << 21, download=False)
+        sc_, st_ = solo.counters.as_dict(), solo.timings()
+        s_rays = max(1, sc_["extend_rays"])
+        s_bray = 32.0 * sc_["extend_nodes"] / s_rays + 48.0 * sc_["extend_tri_tests"] / s_rays + 64.0
+        s_gbs = s_bray * s_rays / st_[6] / 1e9
+        roofline["exclusive"] = {"streams": 1, "achieved": round(s_gbs, 1), "frac": round(s_gbs / HBM_PEAK_GBS, 4),
+                                 "avg_launch_ms": round(st_[6] / max(1, sc_["iterations"]) * 1e3, 4),
+                                 "launches": sc_["iterations"], "sample": "%d spp pass, 2M-slot pool" % a.exclusive_spp,
+                                 "mray_per_s": round((sc_["regular_rays"] + sc_["shadow_rays"]) / st_[0] / 1e6, 1)}
+        del solo
 
     cpu_baseline = None
     if rank == 0 and world == 1 and a.cpu_samples > 0:
@@ -161,8 +185,8 @@ def main():
             "value": round(mrays, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic: bundled killeroo-simple.pbrt scene, Halton samples",
-            "config": {"workload": "killeroo-simple.pbrt 700x700, %d spp = %d steps x %d spp, film tiles sharded over %d GPU(s)"
-                                   % (total_spp, a.steps, a.spp_per_step, world),
+            "config": {"workload": "killeroo-simple.pbrt 700x700, %d spp per step (one full frame), film tiles sharded over %d GPU(s)"
+                                   % (total_spp, world),
                        "spp": total_spp, "resolution": [w, h], "max_depth": int(scene.desc.integrator.max_depth)},
             "msamples_per_s": round(msamples, 2), "rays": int(rays), "camera_samples": int(tot["camera_rays"]),
             "seconds": round(dt, 4),

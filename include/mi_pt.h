@@ -265,9 +265,11 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *params, float *film_sum,
 /* Device pointer of the resident film (layout [H*W][32]: 31 bins + weight) so a
  * collective can reduce in place; element count returned through n_floats. */
 int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats);
-/* Seconds of the last mi_pt_render measured with HIP events on the render stream:
- * [0]=whole render loop, then the sum over launches per kernel class: [1]=generate,
- * [2]=extend, [3]=shade, [4]=shadow, [5]=mis. */
+/* Seconds of the last mi_pt_render: [0] = wall time of the whole render loop; then, from
+ * HIP events recorded on the stream each launch goes to, the sum over launches per kernel
+ * class: [1]=generate, [2]=extend (closest-hit traversal + its resolve), [3]=shade,
+ * [4]=shadow, [5]=mis, [6]=closest-hit traversal kernel alone. The sub-renderers of one
+ * render run concurrently, so [1..6] add up to more than [0]. */
 int mi_pt_last_timings(mi_pt *pt, double *seconds, int n);
 void mi_pt_destroy(mi_pt *pt);
 const char *mi_pt_last_error(void);

@@ -35,6 +35,11 @@ using namespace dpt;
 namespace {
 
 thread_local std::string g_err;
+
+// Four sub-renderer streams want four hardware queues of their own; the HIP runtime maps
+// streams onto GPU_MAX_HW_QUEUES (default 4, shared with the null stream) when it
+// initialises, which happens at the first HIP call -- after this library is loaded.
+struct QueueEnv { QueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queueEnv;
 #define HIPCHK(x)                                                                         \
     do {                                                                                  \
         hipError_t e_ = (x);                                                              \
@@ -1039,8 +1044,8 @@ struct SubRenderer {
     Pool pool{};
     DevCounters *ctr = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t evIter[2][6] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
-    double t[6] = {0};
+    hipEvent_t evIter[2][7] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
+    double t[7] = {0};
     unsigned long long iterations = 0;
     DevCounters result{};
 };
@@ -1328,13 +1333,13 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     if (hipMalloc((void **)&pt->film, pt->nPix * 32 * sizeof(float)) != hipSuccess) { g_err = "hipMalloc(film) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
     hipMemset(pt->film, 0, pt->nPix * 32 * sizeof(float));
     {
-        int nSub = 2;  // concurrent sub-renderers (MIPT_STREAMS overrides, 1..4)
-        if (const char *e = getenv("MIPT_STREAMS")) nSub = std::max(1, std::min(4, atoi(e)));
+        int nSub = 4;  // concurrent sub-renderers (MIPT_STREAMS overrides, 1..8)
+        if (const char *e = getenv("MIPT_STREAMS")) nSub = std::max(1, std::min(8, atoi(e)));
         pt->subs.resize(nSub);
         for (SubRenderer &sub : pt->subs) {
             if (hipMalloc((void **)&sub.ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
             if (hipStreamCreateWithFlags(&sub.stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
-            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) hipEventCreate(&sub.evIter[a][b]);
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 7; ++b) hipEventCreate(&sub.evIter[a][b]);
         }
     }
     *out = pt;
@@ -1364,7 +1369,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
-    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 21);
+    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 24);  // ~11 GB of path state at 16M slots
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
@@ -1385,6 +1390,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipEventElapsedTime(&ms, sub.evIter[set][2], sub.evIter[set][3]); sub.t[3] += ms * 1e-3;
         hipEventElapsedTime(&ms, sub.evIter[set][3], sub.evIter[set][4]); sub.t[4] += ms * 1e-3;
         hipEventElapsedTime(&ms, sub.evIter[set][4], sub.evIter[set][5]); sub.t[5] += ms * 1e-3;
+        hipEventElapsedTime(&ms, sub.evIter[set][1], sub.evIter[set][6]); sub.t[6] += ms * 1e-3;
     };
     int set = 0;
     bool prevFull = false, havePrev = false;
@@ -1399,6 +1405,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
         hipLaunchKernelGGL(k_trav<0>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, sub.pool, sub.ctr, 0);
@@ -1444,9 +1451,9 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     pt->lastSeconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long iterations = 0;
     DevCounters c{};
-    for (int i = 1; i < 6; ++i) pt->lastSeconds[i] = 0;
+    for (int i = 1; i < 7; ++i) pt->lastSeconds[i] = 0;
     for (const SubRenderer &sub : pt->subs) {
-        for (int i = 1; i < 6; ++i) pt->lastSeconds[i] += sub.t[i];
+        for (int i = 1; i < 7; ++i) pt->lastSeconds[i] += sub.t[i];
         iterations += sub.iterations;
         const DevCounters &r = sub.result;
         c.cameraRays += r.cameraRays; c.regularRays += r.regularRays; c.shadowRays += r.shadowRays;
@@ -1528,7 +1535,7 @@ void mi_pt_destroy(mi_pt *pt) {
         if (p.shadeQ[0]) hipFree(p.shadeQ[0]);
         if (p.shadeQ[1]) hipFree(p.shadeQ[1]);
         if (sub.ctr) hipFree(sub.ctr);
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 7; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
         if (sub.stream) hipStreamDestroy(sub.stream);
     }
     delete pt;
