@@ -133,7 +133,7 @@ RENDER_FILM_ON_DEVICE = 1
 RENDER_ACCUMULATE = 2
 
 HOST_LIB = os.path.join(_HERE, "libmipt_host.so")
-HIP_LIB = os.path.join(_HERE, "libmipt_hip.so")
+HIP_LIB = os.environ.get("MIPT_HIP_LIB") or os.path.join(_HERE, "libmipt_hip.so")   # override: kernel tuning builds
 
 _host = None
 _hip = None

@@ -50,8 +50,11 @@ struct QueueEnv { QueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queueE
     } while (0)
 
 constexpr int BLOCK = 256;
-constexpr int STACK_LDS = 12;    // traversal stack entries (node, meta, tMin) staged in LDS per lane
-constexpr int STACK_SPILL = 52;  // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
+#ifndef MIPT_STACK_LDS
+#define MIPT_STACK_LDS 12
+#endif
+constexpr int STACK_LDS = MIPT_STACK_LDS;       // traversal stack entries (node, meta, tMin) staged in LDS per lane
+constexpr int STACK_SPILL = 64 - STACK_LDS;     // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
 
 // ---- float planes
 enum : int {
@@ -346,13 +349,20 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 #define MIPT_TRAV_BLOCKS_PER_CU 4
 #endif
 #ifndef MIPT_REFILL_BELOW
-#define MIPT_REFILL_BELOW 32
+#define MIPT_REFILL_BELOW 24
 #endif
 constexpr int TRAV_BLOCKS_PER_CU = MIPT_TRAV_BLOCKS_PER_CU;
 constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
+#ifndef MIPT_TRI_BATCH
+#define MIPT_TRI_BATCH 8
+#endif
+constexpr int TRI_BATCH = MIPT_TRI_BATCH;
 
+#ifndef MIPT_TRAV_WAVES_PER_EU
+#define MIPT_TRAV_WAVES_PER_EU 4
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters *ctr) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
     constexpr int PO = (MODE == 0) ? P_OX : ((MODE == 1) ? P_SOX : P_MOX);
     const int lane = threadIdx.x;
@@ -371,6 +381,7 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
     TravSpill spill;
     int nPend = 0, hitPrim = -1;
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
+    int leafOff = 0, leafCnt = 0;
     bool exhausted = false;
     while (true) {
         // ---- fetch rays for idle lanes
@@ -395,8 +406,14 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
                             StartTraversal(s, r, tMax, st, nodeCount);
                             nPend = 0; hitPrim = -1;
                             hitT = hitB0 = hitB1 = hitB2 = 0;
-                            has = true;
+                            leafCnt = 0;
                             ++rayCount;
+                            if (st.cur >= 0) has = true;
+                            else {  // the ray misses the world bound: nothing to traverse
+                                pool.I(I_HITPRIM, slot) = -1;
+                                pool.I(I_NPEND, slot) = 0;
+                                if (!ANY) { pool.F(P_HIT_T, slot) = 0; pool.F(P_B0, slot) = 0; pool.F(P_B1, slot) = 0; pool.F(P_B2, slot) = 0; }
+                            }
                         }
                     }
                 }
@@ -406,43 +423,84 @@ __global__ void __launch_bounds__(BLOCK) k_trav(DScene s, Pool pool, DevCounters
             if (exhausted) break;
             continue;  // every fetched slot was dead: fetch again
         }
-        // ---- traverse until enough lanes have run dry
+        // ---- step the lanes until enough of them have run dry. Every pass opens one
+        // interior node in each lane that holds one; lanes that reached a leaf wait, and
+        // one primitive per waiting lane is tested once TRI_BATCH lanes wait (or nobody is
+        // left walking), so both the box code and the triangle code run on well-filled waves.
+        // Per lane the sequence of node visits, pops and primitive tests is unchanged.
         while (true) {
-            int leafOffset = 0, leafCount = 0;
-            bool finished = false;
-            if (has) {
-                const bool leaf = NextLeaf(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount);
-                finished = !leaf;
-                if (!leaf) leafCount = 0;
+            const bool walking = has && st.cur >= 0;
+            const bool inLeaf = has && leafCnt > 0;
+            const int nLeaf = __popcll(__ballot(inLeaf));
+            const bool anyWalk = __any(walking);
+            bool needPop = false, got = false, finished = false;
+            int tkChild = 0, tkMeta = 0;
+            if (walking) {
+                const float4 a = s.wnodes[4 * st.cur], b = s.wnodes[4 * st.cur + 1], c = s.wnodes[4 * st.cur + 2];
+                const float4 dd = s.wnodes[4 * st.cur + 3];
+                const int childL = __float_as_int(dd.x), childR = __float_as_int(dd.y);
+                const int metaL = __float_as_int(dd.z), metaR = __float_as_int(dd.w);
+                const bool haveR = (metaR & 0xffff) != 0xffff;
+                float tL, tR = 0;
+                const bool hitL = BoxTest(r, a.x, a.y, a.z, a.w, b.x, b.y, tMax, &tL);
+                const bool hitR = haveR && BoxTest(r, b.z, b.w, c.x, c.y, c.z, c.w, tMax, &tR);
+                nodeCount += haveR ? 2 : 0;
+                const int axis = (metaL >> 16) & 0xff;
+                const bool negAxis = (axis == 0) ? r.n0 : ((axis == 1) ? r.n1 : r.n2);
+                const bool hitF = negAxis ? hitR : hitL, hitS = negAxis ? hitL : hitR;
+                const int chF = negAxis ? childR : childL, chS = negAxis ? childL : childR;
+                const int mtF = (negAxis ? metaR : metaL) & 0xffff, mtS = (negAxis ? metaL : metaR) & 0xffff;
+                const float tS = negAxis ? tL : tR;
+                if (hitF) {
+                    tkChild = chF; tkMeta = mtF; got = true;
+                    if (hitS) StackPush(spill, lane, st.sp, chS, mtS, tS);
+                } else if (hitS) {
+                    tkChild = chS; tkMeta = mtS; got = true;
+                }
+                needPop = !got;
+                st.cur = -1;
             }
-            if (has && leafCount > 0) {
-                const V3 ro(r.ox, r.oy, r.oz), rd(r.dx, r.dy, r.dz);
-                for (int i = 0; i < leafCount; ++i) {  // leaf primitives, in order, against the current tMax
-                    const int prim = leafOffset + i;
-                    const float4 v0 = primTri[3 * prim];
-                    const unsigned pf = __float_as_uint(v0.w);
-                    if (pf & PRIM_FLAG_SPHERE) {
-                        if ((nPend & 0xff) < MAX_PEND) { pool.I(I_PEND0 + (nPend & 0xff), slot) = prim; ++nPend; }
-                        else nPend |= PEND_OVERFLOW;
-                        continue;
-                    }
+            if (inLeaf && (nLeaf >= TRI_BATCH || !anyWalk)) {
+                const int prim = leafOff;
+                ++leafOff; --leafCnt;
+                const float4 v0 = primTri[3 * prim];
+                const unsigned pf = __float_as_uint(v0.w);
+                if (pf & PRIM_FLAG_SPHERE) {
+                    if ((nPend & 0xff) < MAX_PEND) { pool.I(I_PEND0 + (nPend & 0xff), slot) = prim; ++nPend; }
+                    else nPend |= PEND_OVERFLOW;
+                } else {
                     const float4 v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
                     ++triCount;
                     TriHit th;
-                    if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
-                        if (ANY) { hitPrim = prim; finished = true; break; }
-                        if (!(pf & PRIM_FLAG_DEGENERATE)) {
+                    if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), V3(r.ox, r.oy, r.oz),
+                                V3(r.dx, r.dy, r.dz), tMax, &th)) {
+                        if (ANY) { hitPrim = prim; finished = true; }
+                        else if (!(pf & PRIM_FLAG_DEGENERATE)) {
                             tMax = th.t;
                             hitPrim = prim; hitT = th.t; hitB0 = th.b0; hitB1 = th.b1; hitB2 = th.b2;
                         }
                     }
                 }
+                needPop = !finished && leafCnt == 0;
+            }
+            if (needPop) {  // a popped node is entered only if still in front of tMax
+                while (!got && st.sp > 0) {
+                    float t;
+                    StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
+                    got = t < tMax;
+                }
+                finished = !got;
+            }
+            if (got) {
+                if (tkMeta > 0) { leafOff = tkChild; leafCnt = tkMeta; }
+                else st.cur = tkChild;
             }
             if (finished) {
                 pool.I(I_HITPRIM, slot) = hitPrim;
                 pool.I(I_NPEND, slot) = nPend;
                 if (!ANY) { pool.F(P_HIT_T, slot) = hitT; pool.F(P_B0, slot) = hitB0; pool.F(P_B1, slot) = hitB1; pool.F(P_B2, slot) = hitB2; }
                 has = false;
+                leafCnt = 0;
             }
             const int active = __popcll(__ballot(has));
             if (active == 0 || (!exhausted && active < REFILL_BELOW)) break;
