@@ -22,7 +22,7 @@ namespace dpt {
 
 #define PRIM_FLAG_SPHERE 1u
 #define PRIM_FLAG_DEGENERATE 2u
-#define PRIM_FLAG_LARGE_MAT 4u  /* material with more than 2 lobes: second shading class */
+#define PRIM_CLASS_SHIFT 2      /* bits 2-4: shading class of the primitive's material (7 = no BSDF) */
 
 struct DScene {
     const float4 *nodes;
@@ -37,6 +37,7 @@ struct DScene {
     const mi_material *materials;
     const mi_light *lights;
     uint32_t nNodes, nPrims, nLights, nMaterials;
+    uint32_t classMask;  // shading classes present in the scene (bit c), see pt_kernels.hip
     // light distribution: distribution d at func[d*nLights], cdf[d*(nLights+1)], funcInt[d]
     int ldType;
     int nVoxels[3];

@@ -80,26 +80,46 @@ enum : int {
     F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128
 };
 
+// Shading classes: materials with the same lobe-type list share a class (ids in order of
+// first appearance, the 7th and later share class 6); class 7 holds the vertices without a
+// BSDF (escaped rays, interface primitives). A wave of k_shade works on one class only.
+constexpr int MAX_CLASSES = 8;
+constexpr int MISS_CLASS = 7;
+
 struct Pool {
     float *f;
     int *i;
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
-    uint32_t *shadeQ[2];       // slots to shade, per material class (0: <= 2 lobes, 1: more)
+    uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
 };
 
-struct DevCounters {
+// Statistics are striped: STAT_STRIPES copies, each on its own 128-B line, picked by block
+// index, so the per-wave atomics of a launch do not all serialise on one L2 line; the host
+// adds the stripes up. The queue cursors cannot be striped (they hand out consecutive
+// positions); they are bumped once per block instead (BlockReserve) and sit on lines of
+// their own.
+constexpr int STAT_STRIPES = 64;
+struct alignas(128) DevStats {
     unsigned long long cameraRays, regularRays, shadowRays, totalPaths, zeroRadiancePaths, pathLengthSum, nodesVisited,
         triTests, badSamples, extendNodes, extendTris, extendRays;
-    unsigned long long nextWork;   // global work counter
-    unsigned int alive;            // slots alive after generate     } cleared together
-    unsigned int shadowCount;      // entries in Pool::shadowQ        } every iteration
-    unsigned int misCount;         // entries in Pool::misQ           }
-    unsigned int shadeCount[2];    // entries in Pool::shadeQ[c]      }
-    unsigned int travNext[3];      // work cursors of the persistent traversal kernels (extend/shadow/mis) }
 };
+struct alignas(128) DevCursor {
+    unsigned int v;
+};
+struct DevCounters {
+    DevStats stats[STAT_STRIPES];
+    alignas(128) unsigned long long nextWork;   // global work counter
+    // cleared together every iteration:
+    DevCursor alive;                    // slots alive after generate
+    DevCursor shadowCount, misCount;    // entries in Pool::shadowQ / misQ
+    DevCursor shadeCount[MAX_CLASSES];  // entries in shading queue c
+    DevCursor travNext[3];              // work cursors of the persistent traversal kernels (extend/shadow/mis)
+};
+constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (3 + MAX_CLASSES + 3);
+DEV DevStats &Stats(DevCounters *ctr) { return ctr->stats[blockIdx.x & (STAT_STRIPES - 1)]; }
 
 struct WorkDesc {
     unsigned long long totalWork;
@@ -127,6 +147,24 @@ DEV void QueueAppend(unsigned *counter, uint32_t *queue, bool pred, uint32_t val
     if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
     base = __shfl(base, leader, 64);
     if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1))] = value;
+}
+
+// Block-level compaction: every thread of the block calls this (it synchronises); threads
+// with pred get consecutive positions from ONE atomicAdd per block. `scratch` is 5 words of
+// LDS that no other call of the same kernel uses.
+DEV unsigned BlockReserve(unsigned *counter, bool pred, unsigned *scratch) {
+    const unsigned long long mask = __ballot(pred);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) scratch[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        scratch[4] = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    unsigned base = scratch[4];
+    for (int w = 0; w < wave; ++w) base += scratch[w];
+    return base + (unsigned)__popcll(mask & ((1ull << lane) - 1));
 }
 
 // ------------------------------------------------------------------ traversal
@@ -367,7 +405,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     constexpr int PO = (MODE == 0) ? P_OX : ((MODE == 1) ? P_SOX : P_MOX);
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
-    const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount : ctr->misCount);
+    const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
     const uint32_t *__restrict__ queue = (MODE == 1) ? pool.shadowQ : pool.misQ;
     const float4 *__restrict__ primTri = s.primTri;
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
@@ -390,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (idle) {
                 const int leader = __ffsll((long long)idle) - 1;
                 unsigned base = 0;
-                if (wlane == leader) base = atomicAdd(&ctr->travNext[MODE], (unsigned)__popcll(idle));
+                if (wlane == leader) base = atomicAdd(&ctr->travNext[MODE].v, (unsigned)__popcll(idle));
                 base = __shfl(base, leader, 64);
                 if (base >= total) exhausted = true;
                 if (!has) {
@@ -506,11 +544,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (active == 0 || (!exhausted && active < REFILL_BELOW)) break;
         }
     }
-    if (MODE == 1) CountAdd(&ctr->shadowRays, rayCount);
-    else CountAdd(&ctr->regularRays, rayCount);
-    CountAdd(&ctr->nodesVisited, nodeCount);
-    CountAdd(&ctr->triTests, triCount);
-    if (MODE == 0) { CountAdd(&ctr->extendNodes, nodeCount); CountAdd(&ctr->extendTris, triCount); CountAdd(&ctr->extendRays, rayCount); }
+    DevStats &st8 = Stats(ctr);
+    if (MODE == 1) CountAdd(&st8.shadowRays, rayCount);
+    else CountAdd(&st8.regularRays, rayCount);
+    CountAdd(&st8.nodesVisited, nodeCount);
+    CountAdd(&st8.triTests, triCount);
+    if (MODE == 0) { CountAdd(&st8.extendNodes, nodeCount); CountAdd(&st8.extendTris, triCount); CountAdd(&st8.extendRays, rayCount); }
 }
 
 // Quadrics recorded by k_trav, tested in encounter order against the ray's final tMax
@@ -547,7 +586,7 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
 __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     bool traced = false;
-    int cls = 0;
+    int cls = MISS_CLASS;
     unsigned nodes = 0, tris = 0;
     if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
         traced = true;
@@ -562,16 +601,36 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
             pool.I(I_HITPRIM, slot) = prim;
             pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
         }
-        if (prim >= 0 && (__float_as_uint(s.primTri[3 * prim].w) & PRIM_FLAG_LARGE_MAT)) cls = 1;
+        cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
     }
-    QueueAppend(&ctr->shadeCount[0], pool.shadeQ[0], traced && cls == 0, slot);
-    QueueAppend(&ctr->shadeCount[1], pool.shadeQ[1], traced && cls == 1, slot);
+    // append to the class queues: one atomic per class and block
+    __shared__ unsigned sCnt[BLOCK / 64][MAX_CLASSES], sBase[MAX_CLASSES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned rank = 0;
+    for (int c = 0; c < MAX_CLASSES; ++c) {
+        if (!((s.classMask >> c) & 1)) continue;
+        const unsigned long long m = __ballot(traced && cls == c);
+        if (lane == 0) sCnt[wave][c] = (unsigned)__popcll(m);
+        if (cls == c) rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_CLASSES && ((s.classMask >> threadIdx.x) & 1)) {
+        const int c = threadIdx.x;
+        const unsigned tot = sCnt[0][c] + sCnt[1][c] + sCnt[2][c] + sCnt[3][c];
+        sBase[c] = tot ? atomicAdd(&ctr->shadeCount[c].v, tot) : 0;
+    }
+    __syncthreads();
+    if (traced) {
+        unsigned pos = sBase[cls] + rank;
+        for (int w = 0; w < wave; ++w) pos += sCnt[w][cls];
+        pool.shadeQ[(size_t)cls * pool.n + pos] = slot;
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
-    if (qi < ctr->shadowCount) {
+    if (qi < ctr->shadowCount.v) {
         const uint32_t slot = pool.shadowQ[qi];
         int flags = pool.I(I_FLAGS, slot);
         bool occluded = pool.I(I_HITPRIM, slot) >= 0;
@@ -594,13 +653,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
         else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
         pool.I(I_FLAGS, slot) = flags;
     }
-    CountAdd(&ctr->zeroRadiancePaths, zero);
+    CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
-    if (qi < ctr->misCount) {
+    if (qi < ctr->misCount.v) {
         const uint32_t slot = pool.misQ[qi];
         const int flags = pool.I(I_FLAGS, slot);
         V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
@@ -632,7 +691,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
         if (!added && !(flags & F_A_ADDED)) ++zero;
         pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
     }
-    CountAdd(&ctr->zeroRadiancePaths, zero);
+    CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
 
 // ------------------------------------------------------------------ generate
@@ -745,15 +804,24 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     bool got = false;
     int px = 0, py = 0;
     long long sampleNum = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        unsigned long long mask = __ballot(need && !got);
-        if (mask == 0) break;
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == (__ffsll((long long)mask) - 1)) base = atomicAdd(&ctr->nextWork, (unsigned long long)__popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-        if (need && !got) {
-            unsigned long long w = base + __popcll(mask & ((1ull << lane) - 1));
+    __shared__ unsigned sWork[4][5];
+    __shared__ unsigned long long sWorkBase[4];
+    for (int attempt = 0; attempt < 4; ++attempt) {  // one work-counter atomic per block and attempt
+        const bool want = need && !got;
+        const unsigned long long mask = __ballot(want);
+        const int wave = threadIdx.x >> 6;
+        if (lane == 0) sWork[attempt][wave] = (unsigned)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = sWork[attempt][0] + sWork[attempt][1] + sWork[attempt][2] + sWork[attempt][3];
+            sWork[attempt][4] = tot;
+            sWorkBase[attempt] = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        if (sWork[attempt][4] == 0) break;
+        if (want) {
+            unsigned long long w = sWorkBase[attempt] + __popcll(mask & ((1ull << lane) - 1));
+            for (int k = 0; k < wave; ++k) w += sWork[attempt][k];
             if (w >= wd.totalWork) { need = false; }
             else {
                 const unsigned long long perSample = (unsigned long long)wd.nTilesShard * 256ull;
@@ -796,10 +864,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         flags = F_ALIVE;
     }
     if (valid) pool.I(I_FLAGS, slot) = flags;
-    unsigned long long aliveMask = __ballot(valid && (flags & F_ALIVE));
-    if ((threadIdx.x & 63) == 0 && aliveMask) atomicAdd(&ctr->alive, (unsigned)__popcll(aliveMask));
-    CountAdd(&ctr->cameraRays, cam);
-    CountAdd(&ctr->badSamples, bad);
+    __shared__ unsigned sAlive[5];
+    BlockReserve(&ctr->alive.v, valid && (flags & F_ALIVE), sAlive);
+    CountAdd(&Stats(ctr).cameraRays, cam);
+    CountAdd(&Stats(ctr).badSamples, bad);
 }
 
 // Build the SurfaceInteraction of a recorded hit.
@@ -819,13 +887,22 @@ DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimens
 // (light sample, MIS sample, continuation) computes its values and its black/non-black
 // decision in one sweep.
 template <int NL>
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr, int cls) {
-    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
+    // the grid covers the queues of `classes` back to back, each padded to whole blocks
+    unsigned blk = blockIdx.x, count = 0;
+    int cls = -1;
+    for (int c = 0; c < MAX_CLASSES; ++c) {
+        if (!((classes >> c) & 1)) continue;
+        const unsigned n = ctr->shadeCount[c].v, nb = (n + BLOCK - 1) / BLOCK;
+        if (blk < nb) { cls = c; count = n; break; }
+        blk -= nb;
+    }
+    const uint32_t qi = blk * BLOCK + threadIdx.x;
     unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
     bool wantShadow = false, wantMis = false;
     uint32_t slot = 0;
-    if (qi < ctr->shadeCount[cls]) {
-        slot = pool.shadeQ[cls][qi];
+    if (cls >= 0 && qi < count) {
+        slot = pool.shadeQ[(size_t)cls * pool.n + qi];
         const int flags = pool.I(I_FLAGS, slot);
         const int bounces = pool.I(I_BOUNCES, slot);
         const int prim = pool.I(I_HITPRIM, slot);
@@ -841,6 +918,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
             if (li >= 0) {
                 const mi_light &l = s.lights[li];
                 if (l.two_sided || Dot(isect.n, -rd) > 0)
+#pragma unroll 1
                     for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_L + b, slot) += pool.F(P_BETA + b, slot) * l.L[b];
             }
         }
@@ -887,6 +965,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
                             const Divisor lpDiv = MakeDivisor(lightPdf);
                             bool fNonBlack = false, liNonBlack = false;
+#pragma unroll 1
                             for (int b = 0; b < MI_NSPEC; ++b) {
                                 const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
                                 const float Li = LiBin(light, ls, b);
@@ -921,6 +1000,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                                 }
                                 const Divisor spDiv = MakeDivisor(sPdf);
                                 bool fNonBlack = false;
+#pragma unroll 1
                                 for (int b = 0; b < MI_NSPEC; ++b) {
                                     const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
                                     fNonBlack |= (f != 0.f);
@@ -958,6 +1038,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                     }
                     const Divisor pdfDiv = MakeDivisor(pdf);
                     float maxRR = 0;
+#pragma unroll 1
                     for (int b = 0; b < MI_NSPEC; ++b) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
                         const float f = EvalBin<NL>(ev, mat->bxdf, b);
                         fNonBlack |= (f != 0.f);
@@ -975,6 +1056,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                             if (Get1D(s, index, dim) < q) killed = true;
                             else {
                                 const Divisor inv = MakeDivisor(1 - q);
+#pragma unroll 1
                                 for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_BETA + b, slot) = DivBy(pool.F(P_BETA + b, slot), inv);
                             }
                         }
@@ -1008,11 +1090,14 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
             pool.I(I_FLAGS, slot) = newFlags;
         }
     }
-    QueueAppend(&ctr->shadowCount, pool.shadowQ, wantShadow, slot);
-    QueueAppend(&ctr->misCount, pool.misQ, wantMis, slot);
-    CountAdd(&ctr->totalPaths, totalPaths);
-    CountAdd(&ctr->pathLengthSum, pathLen);
-    CountAdd(&ctr->zeroRadiancePaths, zeroNow);
+    __shared__ unsigned sShadow[5], sMis[5];
+    const unsigned posS = BlockReserve(&ctr->shadowCount.v, wantShadow, sShadow);
+    const unsigned posM = BlockReserve(&ctr->misCount.v, wantMis, sMis);
+    if (wantShadow) pool.shadowQ[posS] = slot;
+    if (wantMis) pool.misQ[posM] = slot;
+    CountAdd(&Stats(ctr).totalPaths, totalPaths);
+    CountAdd(&Stats(ctr).pathLengthSum, pathLen);
+    CountAdd(&Stats(ctr).zeroRadiancePaths, zeroNow);
 }
 
 // ------------------------------------------------------------------ spatial light distribution (create time)
@@ -1118,7 +1203,7 @@ struct mi_pt {
     long long spp = 0;
     std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
-    bool haveLargeMaterials = false;  // some material has more than 2 lobes (second shading class)
+    unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
     int numCUs = 256;
 };
 
@@ -1146,15 +1231,14 @@ int EnsurePool(SubRenderer &sub, uint32_t n) {
     Pool &p = sub.pool;
     if (p.n == n && p.f) return MI_OK;
     if (p.f) {
-        hipFree(p.f); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ[0]); hipFree(p.shadeQ[1]);
-        p.f = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ[0] = p.shadeQ[1] = nullptr;
+        hipFree(p.f); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
+        p.f = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
     }
     HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&p.shadeQ[0], (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&p.shadeQ[1], (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&p.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)));
     p.n = n;
     return MI_OK;
 }
@@ -1243,6 +1327,24 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         UP(w.data(), w.size(), dev);
         s.wnodes = dev;
     }
+    // shading classes: one per distinct lobe-type list, in order of first appearance
+    std::vector<int> matClass(d->n_materials, 0);
+    {
+        std::vector<std::vector<int>> signatures;
+        for (uint32_t i = 0; i < d->n_materials; ++i) {
+            const mi_material &m = d->materials[i];
+            std::vector<int> sig;
+            for (int j = 0; j < m.n_bxdfs; ++j) { sig.push_back(m.bxdf[j].type); sig.push_back(m.bxdf[j].fresnel); }
+            size_t c = 0;
+            while (c < signatures.size() && signatures[c] != sig) ++c;
+            if (c == signatures.size()) signatures.push_back(sig);
+            matClass[i] = (int)std::min<size_t>(c, MISS_CLASS - 1);
+            ((m.n_bxdfs > 2 || c >= (size_t)MISS_CLASS - 1) ? pt->largeClasses : pt->smallClasses) |= 1u << matClass[i];
+        }
+        pt->smallClasses &= ~pt->largeClasses;   // a shared overflow class runs the 8-lobe kernel
+        pt->smallClasses |= 1u << MISS_CLASS;
+        s.classMask = pt->smallClasses | pt->largeClasses;
+    }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
     {
         std::vector<float4> pt3((size_t)d->n_prims * 3);
@@ -1296,7 +1398,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
             }
-            if (p.material >= 0 && d->materials[p.material].n_bxdfs > 2) flags |= PRIM_FLAG_LARGE_MAT;
+            flags |= (unsigned)(p.material >= 0 ? matClass[p.material] : MISS_CLASS) << PRIM_CLASS_SHIFT;
             memcpy(&a.w, &flags, 4);
             memcpy(&b.w, &shapeIdx, 4);
             pt3[3 * i] = a; pt3[3 * i + 1] = b; pt3[3 * i + 2] = c;
@@ -1314,7 +1416,6 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     UP(d->meshes, d->n_meshes, s.meshes);
     UP(d->spheres, d->n_spheres, s.spheres);
     UP(d->materials, d->n_materials, s.materials);
-    for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].n_bxdfs > 2) pt->haveLargeMaterials = true;
     UP(d->lights, d->n_lights, s.lights);
     UP(d->sampler.primes, d->sampler.n_dims, s.primes);
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
@@ -1454,11 +1555,11 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     bool prevFull = false, havePrev = false;
     while (true) {
         hipEvent_t *ev = sub.evIter[set];
-        HIPCHK(hipMemsetAsync(&sub.ctr->alive, 0, 8 * sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(&sub.ctr->alive, 0, ITER_CLEAR_BYTES, st));
         HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, sub.pool, pt->film, sub.ctr, wd);
         HIPCHK(hipEventRecord(ev[1], st));
-        HIPCHK(hipMemcpyAsync(&alive, &sub.ctr->alive, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&alive, &sub.ctr->alive.v, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
@@ -1466,8 +1567,9 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, s, sub.pool, sub.ctr, 0);
-        if (pt->haveLargeMaterials) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, grid, block, 0, st, s, sub.pool, sub.ctr, 1);
+        const dim3 shadeGrid(grid.x + MAX_CLASSES);
+        hipLaunchKernelGGL(k_shade<2>, shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+        if (pt->largeClasses) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
         HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
@@ -1508,16 +1610,17 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     HIPCHK(hipDeviceSynchronize());
     pt->lastSeconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long iterations = 0;
-    DevCounters c{};
+    DevStats c{};
     for (int i = 1; i < 7; ++i) pt->lastSeconds[i] = 0;
     for (const SubRenderer &sub : pt->subs) {
         for (int i = 1; i < 7; ++i) pt->lastSeconds[i] += sub.t[i];
         iterations += sub.iterations;
-        const DevCounters &r = sub.result;
-        c.cameraRays += r.cameraRays; c.regularRays += r.regularRays; c.shadowRays += r.shadowRays;
-        c.totalPaths += r.totalPaths; c.zeroRadiancePaths += r.zeroRadiancePaths; c.pathLengthSum += r.pathLengthSum;
-        c.nodesVisited += r.nodesVisited; c.triTests += r.triTests; c.badSamples += r.badSamples;
-        c.extendNodes += r.extendNodes; c.extendTris += r.extendTris; c.extendRays += r.extendRays;
+        for (const DevStats &r : sub.result.stats) {
+            c.cameraRays += r.cameraRays; c.regularRays += r.regularRays; c.shadowRays += r.shadowRays;
+            c.totalPaths += r.totalPaths; c.zeroRadiancePaths += r.zeroRadiancePaths; c.pathLengthSum += r.pathLengthSum;
+            c.nodesVisited += r.nodesVisited; c.triTests += r.triTests; c.badSamples += r.badSamples;
+            c.extendNodes += r.extendNodes; c.extendTris += r.extendTris; c.extendRays += r.extendRays;
+        }
     }
     if (counters) {
         *counters = mi_counters{};
@@ -1590,8 +1693,7 @@ void mi_pt_destroy(mi_pt *pt) {
         if (p.i) hipFree(p.i);
         if (p.shadowQ) hipFree(p.shadowQ);
         if (p.misQ) hipFree(p.misQ);
-        if (p.shadeQ[0]) hipFree(p.shadeQ[0]);
-        if (p.shadeQ[1]) hipFree(p.shadeQ[1]);
+        if (p.shadeQ) hipFree(p.shadeQ);
         if (sub.ctr) hipFree(sub.ctr);
         for (int a = 0; a < 2; ++a) for (int b = 0; b < 7; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
         if (sub.stream) hipStreamDestroy(sub.stream);
