@@ -395,6 +395,10 @@ constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
 #define MIPT_TRI_BATCH 8
 #endif
 constexpr int TRI_BATCH = MIPT_TRI_BATCH;
+#ifndef MIPT_TRAV_CHUNK
+#define MIPT_TRAV_CHUNK 128
+#endif
+constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserves per cursor atomic
 
 #ifndef MIPT_TRAV_WAVES_PER_EU
 #define MIPT_TRAV_WAVES_PER_EU 4
@@ -421,19 +425,25 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
     int leafOff = 0, leafCnt = 0;
     bool exhausted = false;
+    unsigned chunkNext = 0, chunkEnd = 0;  // wave-uniform: the range of the work list this wave reserved
     while (true) {
         // ---- fetch rays for idle lanes
         if (!exhausted) {
             const unsigned long long idle = __ballot(!has);
             if (idle) {
-                const int leader = __ffsll((long long)idle) - 1;
-                unsigned base = 0;
-                if (wlane == leader) base = atomicAdd(&ctr->travNext[MODE].v, (unsigned)__popcll(idle));
-                base = __shfl(base, leader, 64);
-                if (base >= total) exhausted = true;
+                if (chunkNext == chunkEnd) {  // the wave's private range is used up: reserve TRAV_CHUNK more
+                    unsigned base = 0;
+                    if (wlane == 0) base = atomicAdd(&ctr->travNext[MODE].v, (unsigned)TRAV_CHUNK);
+                    base = __shfl(base, 0, 64);
+                    chunkNext = min(base, total);
+                    chunkEnd = min(base + (unsigned)TRAV_CHUNK, total);
+                    if (base >= total) exhausted = true;
+                }
+                const unsigned first = chunkNext;
+                chunkNext = min(chunkNext + (unsigned)__popcll(idle), chunkEnd);
                 if (!has) {
-                    const unsigned my = base + __popcll(idle & ((1ull << wlane) - 1));
-                    if (my < total) {
+                    const unsigned my = first + __popcll(idle & ((1ull << wlane) - 1));
+                    if (my < chunkEnd) {
                         bool take = true;
                         if (MODE == 0) { slot = my; take = (pool.I(I_FLAGS, slot) & F_ALIVE) != 0; }
                         else slot = queue[my];
@@ -1528,7 +1538,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
-    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 24);  // ~11 GB of path state at 16M slots
+    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 25);  // ~22 GB of path state at 32M slots
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
