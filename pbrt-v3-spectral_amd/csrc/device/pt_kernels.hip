@@ -896,8 +896,21 @@ DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimens
 // registers). Spectra are streamed bin by bin; each of the three spectral passes
 // (light sample, MIS sample, continuation) computes its values and its black/non-black
 // decision in one sweep.
+// timing experiments only (results are wrong when set)
+#ifndef MIPT_X_SKIP_NEE
+#define MIPT_X_SKIP_NEE 0
+#endif
+#ifndef MIPT_X_SKIP_MIS
+#define MIPT_X_SKIP_MIS 0
+#endif
+#ifndef MIPT_X_SKIP_DIRECT
+#define MIPT_X_SKIP_DIRECT 0
+#endif
+#ifndef MIPT_SHADE_WAVES_PER_EU
+#define MIPT_SHADE_WAVES_PER_EU 4
+#endif
 template <int NL>
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_SHADE_WAVES_PER_EU, 8))) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
     // the grid covers the queues of `classes` back to back, each padded to whole blocks
     unsigned blk = blockIdx.x, count = 0;
     int cls = -1;
@@ -949,7 +962,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
             int dim = pool.I(I_DIM, slot);
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
             // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
-            if (NumComponents(mat, nonSpec) > 0) {
+            if (NumComponents(mat, nonSpec) > 0 && !MIPT_X_SKIP_DIRECT) {
                 ++totalPaths;
                 newFlags |= F_NEE;
                 if (s.nLights > 0) {
@@ -965,7 +978,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                         const Divisor selDiv = MakeDivisor(selPdf);
                         const LightSample ls = SampleLi(s, light, isect, uL0, uL1);
                         const float lightPdf = ls.pdf;
-                        if (lightPdf > 0 && !ls.black) {
+                        if (lightPdf > 0 && !ls.black && !MIPT_X_SKIP_NEE) {
                             BSDFEvalT<NL> ev;
                             BSDF_f<NL>(fr, isect.wo, ls.wi, nonSpec, &ev);
                             const float absdot = AbsDot(ls.wi, isect.shN);
@@ -992,7 +1005,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DScene s, Pool pool, DevCounter
                                 newFlags |= F_SHADOW;
                             }
                         }
-                        if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
+                        if (!IsDeltaLight(light) && !MIPT_X_SKIP_MIS) {  // BSDF sampling with MIS, integrator.cpp:167-213
                             V3 wi;
                             float sPdf = 0;
                             int sampledType = 0;

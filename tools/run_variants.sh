@@ -1,9 +1,9 @@
 #!/bin/bash
-# Short benches of every build_variants/lib_*.so (one stream @256 spp and default streams @1024 spp).
+# Short benches of every build_variants/lib_*.so (one stream @256 spp, 8M pool, and default streams @1024 spp).
 for f in build_variants/lib_*.so; do
   n=$(basename $f .so)
-  MIPT_HIP_LIB=$PWD/$f MIPT_STREAMS=1 timeout -k 10 200 python bench.py --steps 1 --warmup 1 --spp 256 --pool 2097152 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v1.json 2> gpurun_out/v1.err
-  MIPT_HIP_LIB=$PWD/$f timeout -k 10 200 python bench.py --steps 1 --warmup 1 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v4.json 2> gpurun_out/v4.err
+  MIPT_HIP_LIB=$PWD/$f MIPT_STREAMS=1 timeout -k 10 200 python bench.py --steps 1 --warmup 1 --spp 256 --pool 8388608 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v1.json 2> gpurun_out/v1.err
+  if [ -z "$ONLY_K1" ]; then MIPT_HIP_LIB=$PWD/$f timeout -k 10 200 python bench.py --steps 1 --warmup 1 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v4.json 2> gpurun_out/v4.err; else rm -f gpurun_out/v4.json; fi
   python - <<PY
 import json
 out=["$n"]
@@ -11,7 +11,7 @@ for f in ("v1","v4"):
     try:
         d=json.load(open("gpurun_out/%s.json"%f)); r=d["roofline"]["kernel_time_s"]
         out.append("%s %.1f (g %.3f t0 %.3f e %.3f sh %.3f s %.3f m %.3f) mean %.6f"%(f,d["value"],r["generate"],r["trav0"],r["extend"],r["shade"],r["shadow"],r["mis"],d["film_mean_per_sample"]))
-    except Exception as e: out.append(f+" failed")
+    except Exception as e: out.append(f+" -")
 print(" | ".join(out))
 PY
 done
