@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (configs[1]: 1024)")
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "killeroo-simple.pbrt"))
+    ap.add_argument("--procedural-tris", type=int, default=0,
+                    help="render the seeded procedural scene of tools/make_procedural_scene.py with this many "
+                         "triangles instead of --scene (BASELINE configs 4/5 stand-in)")
     ap.add_argument("--pool", type=int, default=0, help="resident path slots (0 = library default)")
     ap.add_argument("--cpu-samples", type=int, default=80_000_000,
                     help="camera samples the CPU oracle renders for cpu_baseline (0 = skip)")
@@ -77,7 +80,16 @@ def main():
     torch.cuda.set_device(local_rank)
 
     total_spp = a.spp
+    if a.procedural_tris > 0:   # every rank writes its own copy of the same seeded scene
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_procedural_scene as mps
+        a.scene = os.path.join(os.environ.get("TMPDIR", "/tmp"), "procedural_%d_r%d.pbrt" % (a.procedural_tris, rank))
+        with open(a.scene, "w") as fh:
+            mps.write_scene(fh, a.procedural_tris, 700, total_spp, 7, 5)
+    t_load = time.perf_counter()
     scene = pt.Scene(a.scene, spp=total_spp)
+    t_load = time.perf_counter() - t_load
+    workload = ("procedural-%dtris" % a.procedural_tris) if a.procedural_tris > 0 else os.path.basename(a.scene)
     integ = pt.CreatePathIntegrator(scene, local_rank)
     w, h = scene.film_size
     film = torch.zeros((h, w, pt.NSPEC), dtype=torch.float32, device="cuda")
@@ -132,7 +144,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 tr = json.load(fh)
             if tr.get("workload_spp") == a.spp and tr.get("streams") == int(os.environ.get("MIPT_STREAMS", "0")) \
-                    and world == 1 and a.pool == 0:
+                    and world == 1 and a.pool == 0 and workload == "killeroo-simple.pbrt":
                 traffic = tr["k_trav0_hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -181,12 +193,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mray/s (killeroo-simple, PathIntegrator maxdepth 5, Halton, SampledSpectrum-31, %d spp)" % total_spp,
+            "metric": "Mray/s (%s, PathIntegrator maxdepth %d, Halton, SampledSpectrum-31, %d spp)"
+                      % (workload.replace(".pbrt", ""), int(scene.desc.integrator.max_depth), total_spp),
             "value": round(mrays, 1), "unit": "Mray/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic: bundled killeroo-simple.pbrt scene, Halton samples",
-            "config": {"workload": "killeroo-simple.pbrt 700x700, %d spp per step (one full frame), film tiles sharded over %d GPU(s)"
-                                   % (total_spp, world),
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic: %s scene, Halton samples" % ("seeded procedural" if a.procedural_tris > 0 else "bundled"),
+            "config": {"workload": "%s %dx%d, %d spp per step (one full frame), film tiles sharded over %d GPU(s)"
+                                   % (workload, w, h, total_spp, world),
+                       "triangles": int(scene.stats["n_triangles"]), "scene_load_s": round(t_load, 2),
                        "spp": total_spp, "resolution": [w, h], "max_depth": int(scene.desc.integrator.max_depth)},
             "msamples_per_s": round(msamples, 2), "rays": int(rays), "camera_samples": int(tot["camera_rays"]),
             "seconds": round(dt, 4),

@@ -194,3 +194,61 @@ def test_create_rejects_malformed_descriptions(pt):
     assert pt.hip_lib().mi_pt_create(C.byref(d), 0, C.byref(h)) == -1
     assert b"ABI" in pt.hip_lib().mi_pt_last_error()
     assert pt.hip_lib().mi_pt_create(s.desc_ptr, 12345, C.byref(h)) == -2
+
+
+def test_killeroo_64spp_full_frame_reproduces_the_reference_counters(pt):
+    """BASELINE config 1 at full size: the reference's own deterministic statistics for
+    killeroo-simple at 64 spp (31 360 000 camera rays, 134 988 455 regular and
+    49 247 871 shadow ray tests, mean path length 1.640, 15.93 % zero-radiance paths).
+    Integer work: exact up to the few paths whose libm rounding flips a decision."""
+    s = pt.Scene(KILLEROO, spp=64)
+    integ = pt.CreatePathIntegrator(s)
+    integ.Render(download=False)
+    c = integ.counters.as_dict()
+    assert c["camera_rays"] == 31_360_000
+    assert abs(c["regular_rays"] - 134_988_455) <= 2e-5 * 134_988_455
+    assert abs(c["shadow_rays"] - 49_247_871) <= 2e-5 * 49_247_871
+    assert abs(c["path_length_sum"] / c["camera_rays"] - 1.640) < 1e-3
+    assert abs(c["zero_radiance_paths"] / c["total_paths"] - 0.1593) < 1e-4
+    assert c["bad_samples"] == 0
+
+
+def test_result_does_not_depend_on_the_number_of_sub_renderers(pt, monkeypatch):
+    """MIPT_STREAMS only changes how tiles are spread over concurrent path pools: the
+    statistics are identical and the films differ by accumulation order alone."""
+    s = pt.Scene(KILLEROO, spp=8, xres=200, yres=200)
+    out = []
+    for k in ("1", "3", "4"):
+        monkeypatch.setenv("MIPT_STREAMS", k)
+        integ = pt.CreatePathIntegrator(s)
+        film, weight = integ.Render()
+        out.append((film, weight, integ.counters.as_dict()))
+    for film, weight, c in out[1:]:
+        assert np.array_equal(weight, out[0][1])
+        assert _rel_l2(film, out[0][0]) < 1e-6
+        for k in ("camera_rays", "regular_rays", "shadow_rays", "total_paths", "zero_radiance_paths", "path_length_sum",
+                  "bvh_nodes_visited", "tri_tests"):
+            assert c[k] == out[0][2][k], k
+
+
+def test_procedural_many_mesh_scene_against_oracle(pt, ob, tmp_path):
+    """The BASELINE config 4/5 stand-in (tools/make_procedural_scene.py) at test size:
+    626 small meshes, 8 named materials in 4 shading classes (matte, Oren-Nayar, plastic,
+    uber), a distant light and 4 spherical area lights, spatial light sampling."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_procedural_scene as mps
+    path = tmp_path / "proc.pbrt"
+    with open(path, "w") as fh:
+        mps.write_scene(fh, 200_000, 96, 16, 7, 5)
+    s = pt.Scene(str(path))
+    assert s.stats["n_triangles"] == 200_002 and s.stats["n_lights"] == 5
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=5e-4)
+    assert np.array_equal(weight, oweight)
+    assert _rel_l2(film, ofilm) < 1e-3
+    l2 = _pixel_l2(film, ofilm, 16)
+    assert np.median(l2) < 1e-6 * ofilm.mean() / 16
