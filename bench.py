@@ -184,12 +184,14 @@ def main():
         except Exception:
             pass
         cores = min(cores, 16)   # a 1-GPU box gives this job a 16-core CPU share
-        ofilm, oweight, oc, secs = ob.render(scene, n_threads=cores, max_samples=a.cpu_samples)
+        # a bounded, unbiased sample of the frame: every S-th film tile with all its samples
+        n_shards = max(1, round(w * h * total_spp / a.cpu_samples))
+        ofilm, oweight, oc, secs = ob.render(scene, n_threads=cores, shard_index=0, shard_count=n_shards)
         orays = oc.regular_rays + oc.shadow_rays
         cpu_baseline = {"value": round(orays / secs / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
                         "msamples_per_s": round(oc.camera_rays / secs / 1e6, 3),
-                        "sample": "%d camera samples (whole 16x16 tiles, all %d spp per pixel) of the same scene, %.1f s"
-                                  % (oc.camera_rays, total_spp, secs)}
+                        "sample": "every %d-th 16x16 film tile of the same frame with all %d spp: %d camera samples, %.1f s"
+                                  % (n_shards, total_spp, oc.camera_rays, secs)}
 
     if rank == 0:
         line = {
