@@ -8,7 +8,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude
 HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Iinclude -Wno-unused-result -Wno-unused-value
 
-all: host hip cli
+all: host hip cli oracle
 
 host: $(PKG)/libmipt_host.so
 hip: $(PKG)/libmipt_hip.so

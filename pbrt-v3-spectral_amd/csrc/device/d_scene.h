@@ -82,19 +82,32 @@ DEV Ray SpawnRayTo(const Interaction &a, const Interaction &b) {  // interaction
 // ------------------------------------------------------------------ triangles
 struct TriHit { float t, b0, b1, b2; };
 
-DEV V3 Permute(const V3 &v, int x, int y, int z) { return V3(v[x], v[y], v[z]); }
-
-// triangle.cpp:199-291 / 437-526
-DEV bool TriTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const V3 &rd, float tMax, TriHit *hit) {
-    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    int kz = MaxDimension(Abs(rd));
-    int kx = kz + 1; if (kx == 3) kx = 0;
+// triangle.cpp:199-291 / 437-526. The permutation and the shear depend on the ray alone:
+// TriRay holds them (same expressions, evaluated once per ray instead of once per test).
+struct TriRay {
+    int kz;
+    float Sx, Sy, Sz;
+};
+DEV TriRay MakeTriRay(const V3 &rd) {
+    TriRay tr;
+    tr.kz = MaxDimension(Abs(rd));
+    int kx = tr.kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
-    V3 d = Permute(rd, kx, ky, kz);
-    p0t = Permute(p0t, kx, ky, kz);
-    p1t = Permute(p1t, kx, ky, kz);
-    p2t = Permute(p2t, kx, ky, kz);
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    V3 d = V3(rd[kx], rd[ky], rd[tr.kz]);
+    tr.Sx = -d.x / d.z; tr.Sy = -d.y / d.z; tr.Sz = 1.f / d.z;
+    return tr;
+}
+DEV V3 PermuteZ(const V3 &v, int kz) {  // (v[kx], v[ky], v[kz]) with kx = kz+1, ky = kz+2 (mod 3)
+    // written as scalar selects so that it compiles to v_cndmask instead of branches
+    const bool k0 = kz == 0, k1 = kz == 1;
+    const float x = k0 ? v.y : (k1 ? v.z : v.x);
+    const float y = k0 ? v.z : (k1 ? v.x : v.y);
+    const float z = k0 ? v.x : (k1 ? v.y : v.z);
+    return V3(x, y, z);
+}
+DEV bool TriTestRay(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const TriRay &tr, float tMax, TriHit *hit) {
+    V3 p0t = PermuteZ(p0 - ro, tr.kz), p1t = PermuteZ(p1 - ro, tr.kz), p2t = PermuteZ(p2 - ro, tr.kz);
+    const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -134,6 +147,10 @@ DEV bool TriTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const V
     if (t <= deltaT) return false;
     hit->t = t; hit->b0 = b0; hit->b1 = b1; hit->b2 = b2;
     return true;
+}
+
+DEV bool TriTest(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const V3 &rd, float tMax, TriHit *hit) {
+    return TriTestRay(p0, p1, p2, ro, MakeTriRay(rd), tMax, hit);
 }
 
 DEV V3 LoadV3(const float *a, int i) { return V3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }

@@ -424,6 +424,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     int nPend = 0, hitPrim = -1;
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
     int leafOff = 0, leafCnt = 0;
+    TriRay triRay;
+    triRay.kz = 2; triRay.Sx = triRay.Sy = 0; triRay.Sz = 1;
     bool exhausted = false;
     unsigned chunkNext = 0, chunkEnd = 0;  // wave-uniform: the range of the work list this wave reserved
     while (true) {
@@ -452,6 +454,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                        pool.F(PO + 4, slot), pool.F(PO + 5, slot));
                             tMax = (MODE == 0) ? pool.F(P_TMAX, slot) : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
                             StartTraversal(s, r, tMax, st, nodeCount);
+                            triRay = MakeTriRay(V3(r.dx, r.dy, r.dz));
                             nPend = 0; hitPrim = -1;
                             hitT = hitB0 = hitB1 = hitB2 = 0;
                             leafCnt = 0;
@@ -520,8 +523,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const float4 v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
                     ++triCount;
                     TriHit th;
-                    if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), V3(r.ox, r.oy, r.oz),
-                                V3(r.dx, r.dy, r.dz), tMax, &th)) {
+                    if (TriTestRay(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), V3(r.ox, r.oy, r.oz),
+                                   triRay, tMax, &th)) {
                         if (ANY) { hitPrim = prim; finished = true; }
                         else if (!(pf & PRIM_FLAG_DEGENERATE)) {
                             tMax = th.t;
