@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -200,6 +200,10 @@ typedef struct mi_integrator {
     int32_t max_depth;        /* CreatePathIntegrator, src/integrators/path.cpp:193 */
     float rr_threshold;
     int32_t pixel_bounds[4];  /* x0,y0,x1,y1 */
+    int32_t n_ca_bands;       /* 1: Integrator "path". >1: Integrator "spectralpath" numCABands -- that many
+                               * paths per camera sample on consecutive sampler dimensions, band s supplying
+                               * spectrum bins [round(31/n)*s, min(round(31/n)*(s+1), 31))
+                               * (src/integrators/spectralpath.cpp:258-318, 366) */
 } mi_integrator;
 
 typedef struct mi_scene_desc {

@@ -682,12 +682,23 @@ struct RenderJob {
                     Float pFilm[2] = {(Float)px + u[0], (Float)py + u[1]};
                     (void)sampler.Get1D();  // time
                     sampler.Get2D(pLens);
-                    Ray ray = GenerateRay(d, pFilm, pLens);
-                    ++c.cameraRays;
-                    Spec L = Li(scene, lightDistrib, ray, sampler, c);
-                    if (L.HasNaNs()) { L = Spec(0.f); ++c.badSamples; }
-                    else if (SpecY(d, L) < -1e-5) { L = Spec(0.f); ++c.badSamples; }
-                    else if (std::isinf(SpecY(d, L))) { L = Spec(0.f); ++c.badSamples; }
+                    // SamplerIntegrator::Render (integrator.cpp:264-328) is the nBands == 1 case of
+                    // SpectralPathIntegrator::Render (spectralpath.cpp:258-318): one path per band from
+                    // the same camera sample, the sampler's dimension running on, band s supplying the
+                    // bins [deltaIndex*s, min(deltaIndex*(s+1), nSpectralSamples)).
+                    const int nBands = std::max(1, (int)d.integrator.n_ca_bands);
+                    const int deltaIndex = (int)std::round((float)NS / (float)nBands);
+                    Spec L(0.f);
+                    for (int band = 0; band < nBands; ++band) {
+                        Ray ray = GenerateRay(d, pFilm, pLens);
+                        ++c.cameraRays;
+                        Spec Ls = Li(scene, lightDistrib, ray, sampler, c);
+                        if (Ls.HasNaNs()) { Ls = Spec(0.f); ++c.badSamples; }
+                        else if (SpecY(d, Ls) < -1e-5) { Ls = Spec(0.f); ++c.badSamples; }
+                        else if (std::isinf(SpecY(d, Ls))) { Ls = Spec(0.f); ++c.badSamples; }
+                        const int lo = deltaIndex * band, hi = std::min(deltaIndex * (band + 1), NS);
+                        for (int k = lo; k < hi; ++k) L.c[k] = Ls.c[k];
+                    }
                     ft.AddSample(d, pFilm, L, 1.f);
                 }
             }

@@ -84,7 +84,8 @@ class Sampler(C.Structure):
 
 
 class Integrator(C.Structure):
-    _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4)]
+    _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("pixel_bounds", C.c_int32 * 4),
+                ("n_ca_bands", C.c_int32)]
 
 
 class SceneDesc(C.Structure):

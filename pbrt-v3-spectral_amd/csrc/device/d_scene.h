@@ -60,6 +60,7 @@ struct DScene {
     // integrator
     int maxDepth;
     float rrThreshold;
+    int nBands, bandDelta;  // spectralpath: paths per camera sample, bins per band (1, 31 for "path")
 };
 
 struct Interaction {

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -67,11 +68,13 @@ enum : int {
     P_BETA = P_L + MI_NSPEC,
     P_LNEE = P_BETA + MI_NSPEC,
     P_LMIS = P_LNEE + MI_NSPEC,
-    P_COUNT = P_LMIS + MI_NSPEC
+    P_COUNT = P_LMIS + MI_NSPEC,
+    P_LCA = P_COUNT   // 31 more planes, allocated for Integrator "spectralpath" only: the sample's stitched bands
 };
 // ---- int planes
 enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT,
              I_NPEND, I_PEND0, I_PEND1, I_PEND2, I_PEND3,  // quadrics postponed by the traversal kernel
+             I_BAND,                                       // spectralpath: band (path number) of the camera sample
              I_COUNT };
 constexpr int MAX_PEND = 4;
 constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
@@ -747,7 +750,14 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     const bool fin = valid && (flags & F_FINISHED);
     float myFx = 0, myFy = 0;
     int myZero = 0;
+    // Integrator "spectralpath" (spectralpath.cpp:258-318): nBands paths per camera sample; a finished
+    // path hands its bins to the sample's stitched spectrum and the slot restarts on the same camera ray
+    // with the sampler dimension running on; the last band flushes the stitched spectrum.
+    const int nBands = s.nBands;
+    bool restart = false;
+    int band = 0;
     if (fin) {
+        if (nBands > 1) band = pool.I(I_BAND, slot);
         // guards of SamplerIntegrator::Render, integrator.cpp:295-316
         float yy = 0.f;
         bool hasNaN = false;
@@ -764,7 +774,22 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         else if ((double)y < -1e-5) zero = true;
         else if (isinff(y)) zero = true;
         if (zero) ++bad;
-        else if (y > s.maxSampleLuminance) {  // FilmTile::AddSample clamp, film.h:126-127
+        if (nBands > 1) {
+            const int lo = s.bandDelta * band, hi = min(s.bandDelta * (band + 1), MI_NSPEC);
+            for (int b = lo; b < hi; ++b) pool.F(P_LCA + b, slot) = zero ? 0.f : row[b];
+            zero = false;
+            if (band + 1 < nBands) restart = true;
+            else {
+                yy = 0.f;
+                for (int b = 0; b < MI_NSPEC; ++b) {
+                    const float v = pool.F(P_LCA + b, slot);
+                    yy += s.cieY[b] * v;
+                    row[b] = v;
+                }
+                y = YScale(yy);
+            }
+        }
+        if (!zero && !restart && y > s.maxSampleLuminance) {  // FilmTile::AddSample clamp, film.h:126-127
             const float scaleL = s.maxSampleLuminance / y;
             for (int b = 0; b < MI_NSPEC; ++b) row[b] *= scaleL;
         }
@@ -775,7 +800,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     }
     __syncthreads();
     {
-        unsigned long long mask = __ballot(fin);
+        unsigned long long mask = __ballot(fin && !restart);
         const int half = lane >> 5, bin = lane & 31;
         const int filterTableSize = 16;
         const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
@@ -813,10 +838,16 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         }
     }
     // refill: up to 4 tries to draw a work item that maps inside the sample / pixel bounds
-    bool need = valid && flags == 0;
+    bool need = valid && flags == 0 && !restart;
     bool got = false;
     int px = 0, py = 0;
     long long sampleNum = 0;
+    if (restart) {  // next band of the same camera sample
+        const int pix = pool.I(I_PIXEL, slot);
+        px = (int)(short)(pix & 0xffff); py = pix >> 16;
+        sampleNum = pool.I(I_SAMPLE, slot);
+        got = true;
+    }
     __shared__ unsigned sWork[4][5];
     __shared__ unsigned long long sWorkBase[4];
     for (int attempt = 0; attempt < 4; ++attempt) {  // one work-counter atomic per block and attempt
@@ -872,7 +903,11 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         pool.I(I_SAMPLE, slot) = (int)sampleNum;
         pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
         pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
-        pool.I(I_DIM, slot) = 5;
+        if (!restart) pool.I(I_DIM, slot) = 5;
+        if (nBands > 1) {
+            pool.I(I_BAND, slot) = restart ? band + 1 : 0;
+            if (!restart) for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_LCA + b, slot) = 0.f;
+        }
         pool.I(I_BOUNCES, slot) = 0;
         flags = F_ALIVE;
     }
@@ -1253,14 +1288,14 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
     return MI_OK;
 }
 
-int EnsurePool(SubRenderer &sub, uint32_t n) {
+int EnsurePool(SubRenderer &sub, uint32_t n, int nFloatPlanes) {
     Pool &p = sub.pool;
     if (p.n == n && p.f) return MI_OK;
     if (p.f) {
         hipFree(p.f); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
         p.f = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
     }
-    HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&p.f, (size_t)nFloatPlanes * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
@@ -1297,7 +1332,11 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (d->tri_indices[i] < 0 || (uint32_t)d->tri_indices[i] >= d->n_verts) { g_err = "triangle vertex index out of range"; return MI_ERR_INVALID; }
     for (uint32_t i = 0; i < d->n_materials; ++i)
         if (d->materials[i].n_bxdfs < 0 || d->materials[i].n_bxdfs > MI_MAX_BXDFS) { g_err = "material lobe count out of range"; return MI_ERR_INVALID; }
-    if (d->sampler.n_dims < 6 + 8 * d->integrator.max_depth) { g_err = "Halton tables cover too few dimensions for max_depth"; return MI_ERR_INVALID; }
+    if (d->integrator.n_ca_bands < 1 || d->integrator.n_ca_bands > MI_NSPEC) { g_err = "n_ca_bands must be in [1, 31]"; return MI_ERR_INVALID; }
+    if (d->sampler.n_dims < 6 + 8 * d->integrator.max_depth * d->integrator.n_ca_bands) {
+        g_err = "Halton tables cover too few dimensions for max_depth x n_ca_bands (the reference's prime table ends at 1000)";
+        return MI_ERR_INVALID;
+    }
 
     HIPCHK(hipSetDevice(device_ordinal));
     mi_pt *pt = new mi_pt();
@@ -1487,6 +1526,8 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     s.sampleAtPixelCenter = d->sampler.sample_at_pixel_center;
     s.maxDepth = d->integrator.max_depth;
     s.rrThreshold = d->integrator.rr_threshold;
+    s.nBands = d->integrator.n_ca_bands;
+    s.bandDelta = (int)std::round((float)MI_NSPEC / (float)s.nBands);  // spectralpath.cpp:258
     pt->spp = d->sampler.samples_per_pixel;
     if (d->n_nodes) for (int i = 0; i < 3; ++i) { s.wbMin[i] = d->nodes[0].bmin[i]; s.wbMax[i] = d->nodes[0].bmax[i]; }
     // light-selection distributions
@@ -1558,7 +1599,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
-    int rc = EnsurePool(sub, poolN);
+    int rc = EnsurePool(sub, poolN, P_COUNT + (s.nBands > 1 ? MI_NSPEC : 0));
     if (rc != MI_OK) return rc;
     HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
     HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));

@@ -600,9 +600,17 @@ void Api::WorldEnd() {
     // ---- integrator (CreatePathIntegrator, path.cpp:190-213)
     {
         scene->integratorName = integratorName;
-        if (integratorName != "path")
+        if (integratorName != "path" && integratorName != "spectralpath")
             Err("Integrator \"" + integratorName + "\" is outside the hot-path scope (SURVEY 2 row 7); using path.");
         mi_integrator &it = d.integrator;
+        it.n_ca_bands = 1;
+        if (integratorName == "spectralpath") {  // CreateSpectralPathIntegrator, spectralpath.cpp:342-376
+            it.n_ca_bands = integratorParams.FindOneInt("numCABands", 4);
+            if (it.n_ca_bands < 1) { Err("\"numCABands\" must be at least 1."); it.n_ca_bands = 1; }
+            if (it.n_ca_bands != 1)
+                Warn("Using spectral rendering. For every pixel sample we will trace " + std::to_string(it.n_ca_bands) +
+                     "x more rays. Rendering will be " + std::to_string(it.n_ca_bands) + " times slower.");
+        }
         it.max_depth = integratorParams.FindOneInt("maxdepth", 5);
         if (ov.maxDepth >= 0) it.max_depth = ov.maxDepth;
         for (int i = 0; i < 4; ++i) it.pixel_bounds[i] = d.film.sample_bounds[i];
@@ -622,9 +630,9 @@ void Api::WorldEnd() {
         scene->lightStrategy = integratorParams.FindOneString("lightsamplestrategy", "spatial");
         if (!ov.lightStrategy.empty()) scene->lightStrategy = ov.lightStrategy;
     }
-    // Halton tables: 5 camera dims + per bounce 7 (+1 RR) for bounces 0..maxDepth-1
+    // Halton tables: 5 camera dims + per path and bounce 7 (+1 RR) for bounces 0..maxDepth-1
     {
-        int nDims = 5 + 8 * (d.integrator.max_depth + 1) + 8;
+        int nDims = 5 + d.integrator.n_ca_bands * 8 * (d.integrator.max_depth + 1) + 8;
         nDims = std::max(64, std::min(nDims, 1000));  // PrimeTableSize = 1000
         ComputeHaltonTables(nDims, &scene->primes, &scene->primeSums, &scene->perms);
         d.sampler.n_dims = nDims;

@@ -224,3 +224,19 @@ def test_procedural_scene_generator_is_deterministic_and_loads(pt, tmp_path):
     s = pt.Scene(text=texts[0])
     assert s.stats["n_triangles"] == 6402 and s.stats["n_meshes"] == 21 and s.stats["n_spheres"] == 4
     assert s.stats["n_errors"] == 0
+
+
+def test_spectralpath_integrator_is_parsed(pt):
+    """Integrator "spectralpath" "integer numCABands" (spectralpath.cpp:342-376): default 4, the
+    reference's warning, Halton tables sized for all bands."""
+    import os
+    from conftest import KILLEROO
+    base = open(KILLEROO).read()
+    for repl, want in (('Integrator "spectralpath"', 4), ('Integrator "spectralpath" "integer numCABands" [2]', 2),
+                       ('Integrator "path"', 1)):
+        s = pt.Scene(text=base.replace('Integrator "path"', repl), base_dir=os.path.dirname(KILLEROO), xres=32, yres=32)
+        assert s.desc.integrator.n_ca_bands == want
+        assert s.desc.sampler.n_dims >= 6 + 8 * 5 * want
+        warned = any("spectral rendering" in m for m in s.warnings)
+        assert warned == (want > 1)
+        assert s.stats["n_errors"] == 0

@@ -252,3 +252,37 @@ def test_procedural_many_mesh_scene_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(film, ofilm) < 1e-3
     l2 = _pixel_l2(film, ofilm, 16)
     assert np.median(l2) < 1e-6 * ofilm.mean() / 16
+
+
+def _killeroo_spectralpath(pt, n_bands, **kw):
+    import os
+    text = open(KILLEROO).read().replace('Integrator "path"',
+                                         'Integrator "spectralpath" "integer numCABands" [%d]' % n_bands)
+    return pt.Scene(text=text, base_dir=os.path.dirname(KILLEROO), **kw)
+
+
+@pytest.mark.parametrize("n_bands", [4, 3])
+def test_spectralpath_bands_against_oracle(pt, ob, n_bands):
+    """Integrator "spectralpath" (spectralpath.cpp:258-318): numCABands paths per camera sample on
+    consecutive Halton dimensions, band s supplying bins [round(31/n)*s, min(round(31/n)*(s+1), 31))."""
+    s = _killeroo_spectralpath(pt, n_bands, spp=8, xres=96, yres=96)
+    assert s.desc.integrator.n_ca_bands == n_bands
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    c = integ.counters.as_dict()
+    assert c["camera_rays"] == 96 * 96 * 8 * n_bands      # one camera ray per band
+    _check_counters(c, oc.as_dict(), tol=5e-4)
+    assert np.array_equal(weight, oweight)                 # one film sample per camera sample
+    assert _rel_l2(film, ofilm) < 1e-4
+    if n_bands == 3:                                       # round(31/3) = 10: bin 30 is never assigned
+        assert not film[..., 30].any() and film[..., 29].any()
+
+
+def test_spectralpath_with_one_band_is_the_path_integrator(pt):
+    """numCABands = 1 stitches bins [0, 31) of the only path: identical to Integrator "path"."""
+    a = pt.Scene(KILLEROO, spp=4, xres=96, yres=96)
+    b = _killeroo_spectralpath(pt, 1, spp=4, xres=96, yres=96)
+    fa, wa = pt.CreatePathIntegrator(a).Render()
+    fb, wb = pt.CreatePathIntegrator(b).Render()
+    assert np.array_equal(wa, wb) and _rel_l2(fb, fa) < 1e-6
