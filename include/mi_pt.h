@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -93,13 +93,15 @@ typedef enum mi_bxdf_type {
     MI_BXDF_DISNEY_FAKE_SS,            /* R, p[0]=roughness */
     MI_BXDF_DISNEY_RETRO,              /* R, p[0]=roughness */
     MI_BXDF_DISNEY_SHEEN,              /* R */
-    MI_BXDF_DISNEY_CLEARCOAT           /* p[0]=weight, p[1]=gloss */
+    MI_BXDF_DISNEY_CLEARCOAT,          /* p[0]=weight, p[1]=gloss */
+    MI_BXDF_FRESNEL_BLEND              /* R(=Rd), S(=Rs), p[0]=alphax, p[1]=alphay (reflection.cpp:279-298,450-475) */
 } mi_bxdf_type;
 
 typedef enum mi_fresnel_type {
     MI_FRESNEL_NOOP = 0,
     MI_FRESNEL_DIELECTRIC, /* p[2]=etaI, p[3]=etaT */
-    MI_FRESNEL_DISNEY      /* S=R0, p[2]=metallic, p[3]=eta */
+    MI_FRESNEL_DISNEY,     /* S=R0, p[2]=metallic, p[3]=eta */
+    MI_FRESNEL_CONDUCTOR   /* etaI = 1, S=etaT, K=k per bin (FrConductor, reflection.cpp:71-94) */
 } mi_fresnel_type;
 
 /* BxDFType bits, src/core/reflection.h:153-161 */
@@ -114,16 +116,18 @@ typedef struct mi_bxdf {
     int32_t type;    /* mi_bxdf_type */
     int32_t flags;   /* BxDFType bits */
     int32_t fresnel; /* mi_fresnel_type (reflection lobes) */
-    int32_t pad;
+    int32_t scaled;  /* != 0: the lobe is wrapped in a ScaledBxDF (mix material): f = scale * f (reflection.cpp:96-107) */
     float p[8];
     float R[MI_NSPEC];
     float S[MI_NSPEC];
+    float K[MI_NSPEC];     /* conductor absorption k */
+    float scale[MI_NSPEC]; /* ScaledBxDF::scale */
 } mi_bxdf;
 
 typedef struct mi_material {
     int32_t n_bxdfs;
     float eta; /* BSDF::eta, src/core/reflection.h:189 */
-    int32_t kind; /* informational: 0 matte 1 plastic 2 glass 3 uber 4 disney */
+    int32_t kind; /* informational: 0 matte 1 plastic 2 glass 3 uber 4 disney 5 mirror 6 metal 7 substrate 8 translucent 9 mix */
     int32_t pad;
     mi_bxdf bxdf[MI_MAX_BXDFS];
 } mi_material;

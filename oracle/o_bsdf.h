@@ -152,24 +152,69 @@ inline Float smithG_GGX(Float cosTheta, Float alpha) {
     return 1 / (cosTheta + (Float)std::sqrt((double)(alpha2 + cosTheta2 - alpha2 * cosTheta2)));
 }
 
+// reflection.cpp:71-94
+inline Spec FrConductor(Float cosThetaI, const Spec &etai, const Spec &etat, const Spec &k) {
+    cosThetaI = Clamp(cosThetaI, -1, 1);
+    Spec eta = etat / etai;
+    Spec etak = k / etai;
+    Float cosThetaI2 = cosThetaI * cosThetaI;
+    Float sinThetaI2 = 1. - cosThetaI2;
+    Spec eta2 = eta * eta;
+    Spec etak2 = etak * etak;
+    Spec t0 = eta2 - etak2 - Spec(sinThetaI2);
+    Spec a2plusb2 = Sqrt(t0 * t0 + 4 * eta2 * etak2);
+    Spec t1 = a2plusb2 + Spec(cosThetaI2);
+    Spec a = Sqrt(0.5f * (a2plusb2 + t0));
+    Spec t2 = (Float)2 * cosThetaI * a;
+    Spec Rs = (t1 - t2) / (t1 + t2);
+    Spec t3 = cosThetaI2 * a2plusb2 + Spec(sinThetaI2 * sinThetaI2);
+    Spec t4 = t2 * sinThetaI2;
+    Spec Rp = Rs * (t3 - t4) / (t3 + t4);
+    return 0.5 * (Rp + Rs);
+}
+
 struct BxDF {
     const mi_bxdf *b;
     Spec R() const { return Spec::From(b->R); }
     Spec S() const { return Spec::From(b->S); }
+    Spec K() const { return Spec::From(b->K); }
+    Spec Scale() const { return Spec::From(b->scale); }
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
     TRDist Dist() const { return TRDist{b->p[0], b->p[1], b->p[5] != 0.f}; }
 
     Spec Fresnel(Float cosI) const {
         switch (b->fresnel) {
         case MI_FRESNEL_DIELECTRIC: return Spec(FrDielectric(cosI, b->p[2], b->p[3]));
+        case MI_FRESNEL_CONDUCTOR:  // FresnelConductor::Evaluate, reflection.cpp:119-121 (etaI = 1, metal.cpp:75)
+            return FrConductor(std::abs(cosI), Spec(1.), S(), K());
         case MI_FRESNEL_DISNEY:  // disney.cpp:324-343
             return Lerp(b->p[2], Spec(FrDielectric(cosI, 1, b->p[3])), FrSchlick(S(), cosI));
         default: return Spec(1.);
         }
     }
 
-    Spec f(const V3 &wo, const V3 &wi) const {
+    // ScaledBxDF (mix material), reflection.cpp:96-111
+    Spec f(const V3 &wo, const V3 &wi) const { return b->scaled ? Scale() * fInner(wo, wi) : fInner(wo, wi); }
+    Spec Sample_f(const V3 &wo, V3 *wi, const Float u[2], Float *pdf, int *sampledType) const {
+        if (!b->scaled) return Sample_fInner(wo, wi, u, pdf, sampledType);
+        Spec v = Sample_fInner(wo, wi, u, pdf, sampledType);
+        return Scale() * v;
+    }
+
+    Spec fInner(const V3 &wo, const V3 &wi) const {
         switch (b->type) {
+        case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:285-298, reflection.h:485-488
+            auto pow5 = [](Float v) { return (v * v) * (v * v) * v; };
+            const Spec Rd = R(), Rs = S();
+            Spec diffuse = (28.f / (23.f * Pi)) * Rd * (Spec(1.f) - Rs) * (1 - pow5(1 - .5f * AbsCosTheta(wi))) *
+                           (1 - pow5(1 - .5f * AbsCosTheta(wo)));
+            V3 wh = wi + wo;
+            if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0);
+            wh = Normalize(wh);
+            Spec schlick = Rs + pow5(1 - Dot(wi, wh)) * (Spec(1.) - Rs);
+            Spec specular = Dist().D(wh) / (4 * AbsDot(wi, wh) * std::max(AbsCosTheta(wi), AbsCosTheta(wo))) * schlick;
+            return diffuse + specular;
+        }
         case MI_BXDF_LAMBERTIAN_REFLECTION: return R() * InvPi;
         case MI_BXDF_LAMBERTIAN_TRANSMISSION: return R() * InvPi;
         case MI_BXDF_OREN_NAYAR: {  // reflection.cpp:178-200
@@ -258,6 +303,12 @@ struct BxDF {
 
     Float Pdf(const V3 &wo, const V3 &wi) const {
         switch (b->type) {
+        case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:470-475
+            if (!SameHemisphere(wo, wi)) return 0;
+            V3 wh = Normalize(wo + wi);
+            Float pdf_wh = Dist().Pdf(wo, wh);
+            return .5f * (AbsCosTheta(wi) * InvPi + pdf_wh / (4 * Dot(wo, wh)));
+        }
         case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR:
             return 0;
         case MI_BXDF_LAMBERTIAN_TRANSMISSION: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;
@@ -289,8 +340,23 @@ struct BxDF {
     }
 
     // Returns f; *pdf stays untouched when the reference leaves it untouched.
-    Spec Sample_f(const V3 &wo, V3 *wi, const Float u[2], Float *pdf, int *sampledType) const {
+    Spec Sample_fInner(const V3 &wo, V3 *wi, const Float u[2], Float *pdf, int *sampledType) const {
         switch (b->type) {
+        case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:450-468
+            Float uu[2] = {u[0], u[1]};
+            if (uu[0] < .5) {
+                uu[0] = std::min(2 * uu[0], OneMinusEpsilon);
+                *wi = CosineSampleHemisphere(uu);
+                if (wo.z < 0) wi->z *= -1;
+            } else {
+                uu[0] = std::min(2 * (uu[0] - .5f), OneMinusEpsilon);
+                V3 wh = Dist().Sample_wh(wo, uu);
+                *wi = Reflect(wo, wh);
+                if (!SameHemisphere(wo, *wi)) return Spec(0.f);
+            }
+            *pdf = Pdf(wo, *wi);
+            return fInner(wo, *wi);
+        }
         case MI_BXDF_SPECULAR_REFLECTION: {  // reflection.cpp:127-134
             *wi = V3(-wo.x, -wo.y, wo.z);
             *pdf = 1;
@@ -331,7 +397,7 @@ struct BxDF {
             *wi = CosineSampleHemisphere(u);
             if (wo.z > 0) wi->z *= -1;
             *pdf = Pdf(wo, *wi);
-            return f(wo, *wi);
+            return fInner(wo, *wi);
         }
         case MI_BXDF_MICROFACET_REFLECTION: {  // reflection.cpp:399-412
             if (wo.z == 0) return Spec(0.);
@@ -339,7 +405,7 @@ struct BxDF {
             *wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, *wi)) return Spec(0.f);
             *pdf = Dist().Pdf(wo, wh) / (4 * Dot(wo, wh));
-            return f(wo, *wi);
+            return fInner(wo, *wi);
         }
         case MI_BXDF_MICROFACET_TRANSMISSION: {  // reflection.cpp:420-430
             if (wo.z == 0) return Spec(0.);
@@ -347,7 +413,7 @@ struct BxDF {
             Float eta = CosTheta(wo) > 0 ? (b->p[2] / b->p[3]) : (b->p[3] / b->p[2]);
             if (!Refract(wo, wh, eta, wi)) return Spec(0);
             *pdf = Pdf(wo, *wi);
-            return f(wo, *wi);
+            return fInner(wo, *wi);
         }
         case MI_BXDF_DISNEY_CLEARCOAT: {  // disney.cpp:280-303
             if (wo.z == 0) return Spec(0.);
@@ -360,13 +426,13 @@ struct BxDF {
             *wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, *wi)) return Spec(0.f);
             *pdf = Pdf(wo, *wi);
-            return f(wo, *wi);
+            return fInner(wo, *wi);
         }
         default: {  // BxDF::Sample_f, reflection.cpp:371-379
             *wi = CosineSampleHemisphere(u);
             if (wo.z < 0) wi->z *= -1;
             *pdf = Pdf(wo, *wi);
-            return f(wo, *wi);
+            return fInner(wo, *wi);
         }
         }
     }

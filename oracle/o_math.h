@@ -130,12 +130,14 @@ struct Spec {
     Spec operator*(Float a) const { Spec r = *this; for (int i = 0; i < NS; ++i) r.c[i] *= a; return r; }
     Spec &operator*=(Float a) { for (int i = 0; i < NS; ++i) c[i] *= a; return *this; }
     Spec operator/(Float a) const { Spec r = *this; for (int i = 0; i < NS; ++i) r.c[i] /= a; return r; }
+    Spec operator/(const Spec &s) const { Spec r = *this; for (int i = 0; i < NS; ++i) r.c[i] /= s.c[i]; return r; }
     Spec &operator/=(Float a) { for (int i = 0; i < NS; ++i) c[i] /= a; return *this; }
     bool IsBlack() const { for (int i = 0; i < NS; ++i) if (c[i] != 0.) return false; return true; }
     Float MaxComponentValue() const { Float m = c[0]; for (int i = 1; i < NS; ++i) m = std::max(m, c[i]); return m; }
     bool HasNaNs() const { for (int i = 0; i < NS; ++i) if (std::isnan(c[i])) return true; return false; }
 };
 inline Spec operator*(Float a, const Spec &s) { return s * a; }
+inline Spec Sqrt(const Spec &s) { Spec r; for (int i = 0; i < NS; ++i) r.c[i] = std::sqrt(s.c[i]); return r; }
 inline Spec Lerp(Float t, const Spec &s1, const Spec &s2) { return (1 - t) * s1 + t * s2; }
 
 }  // namespace orc

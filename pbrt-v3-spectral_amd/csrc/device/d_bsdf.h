@@ -157,7 +157,9 @@ enum LobeKind : int {
     LK_MUL2_DIV,  // ((R*a)*b)/d
     LK_MICRO_DISNEY,  // (((R*a)*b)*F[bin])/d, F = lerp(c, FrDielectric=e, FrSchlick(S[bin], w=f))
     LK_MTRANS,    // ((1-a)*R)*b
-    LK_CONST      // a
+    LK_CONST,     // a
+    LK_MICRO_CONDUCTOR,  // (((R*a)*b)*F[bin])/d, F = FrConductor(cos, 1, S[bin], K[bin]); c=cos^2, e=sin^2, f=2cos
+    LK_FBLEND     // FresnelBlend: (((R*f)*(1-S))*a)*b + (S + (1-S)*c)*e
 };
 struct LobeEval {
     int kind;  // LobeKind | LK_FASTDIV when DivBy's fast form applies to d
@@ -178,10 +180,37 @@ DEV float LobeDiv(float x, const LobeEval &le) {
     return DivBy(x, v);
 }
 
-DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
+// One bin of FrConductor(cosThetaI, Spectrum(1), etaT, k) (reflection.cpp:71-94) in the reference's
+// operator order; cos2 = cos^2, sin2 = (Float)(1. - cos2), twoCos = 2 * cos.
+DEV float FrConductorBin(float cos2, float sin2, float twoCos, float etaT, float k) {
+    const float eta = etaT / 1.f, etak = k / 1.f;
+    const float eta2 = eta * eta, etak2 = etak * etak;
+    const float t0 = (eta2 - etak2) - sin2;
+    const float a2plusb2 = __builtin_sqrtf(t0 * t0 + (eta2 * 4.f) * etak2);
+    const float t1 = a2plusb2 + cos2;
+    const float a = __builtin_sqrtf((a2plusb2 + t0) * 0.5f);
+    const float t2 = a * twoCos;
+    const float Rs = (t1 - t2) / (t1 + t2);
+    const float t3 = a2plusb2 * cos2 + sin2 * sin2;
+    const float t4 = t2 * sin2;
+    const float Rp = (Rs * (t3 - t4)) / (t3 + t4);
+    return (Rp + Rs) * 0.5f;
+}
+
+DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
     const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
     float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
     switch (le.kind & 0xff) {
+    case LK_MICRO_CONDUCTOR: {
+        const float F = FrConductorBin(le.c, le.e, le.f, bx[li].S[bin], bx[li].K[bin]);
+        return LobeDiv(((R * le.a) * le.b) * F, le);
+    }
+    case LK_FBLEND: {
+        const float Rs = bx[li].S[bin];
+        const float diffuse = (((R * le.f) * (1.f - Rs)) * le.a) * le.b;
+        const float specular = (Rs + (1.f - Rs) * le.c) * le.e;
+        return diffuse + specular;
+    }
     case LK_MUL1: return R * le.a;
     case LK_MUL2: return (R * le.a) * le.b;
     case LK_MUL3: return ((R * le.a) * le.b) * le.c;
@@ -199,6 +228,11 @@ DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
     case LK_CONST: return le.a;
     default: return 0.f;
     }
+}
+// bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
+DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
+    const float v = LobeValueInner(le, bx, bin);
+    return (le.lobe & 0x200) ? bx[le.lobe & 0xff].scale[bin] * v : v;
 }
 
 struct BSDFFrame {
@@ -221,8 +255,21 @@ DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.
 // BxDF::f for lobe i (local wo, wi) -> LobeEval. Mirrors o_bsdf / reflection.cpp per lobe.
 DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
     LobeEval le;
-    le.kind = LK_NONE; le.lobe = i; le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
+    le.kind = LK_NONE; le.lobe = i | (b.scaled ? 0x200 : 0); le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
     switch (b.type) {
+    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:285-298
+        V3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
+        wh = Normalize(wh);
+        const float hi = 1 - .5f * AbsCosTheta(wi), ho = 1 - .5f * AbsCosTheta(wo), hc = 1 - Dot(wi, wh);
+        le.kind = LK_FBLEND;
+        le.f = (28.f / (23.f * kPi));
+        le.a = (1 - (hi * hi) * (hi * hi) * hi);
+        le.b = (1 - (ho * ho) * (ho * ho) * ho);
+        le.c = (hc * hc) * (hc * hc) * hc;
+        le.e = DistOf(b).D(wh) / (4 * AbsDot(wi, wh) * maxf(AbsCosTheta(wi), AbsCosTheta(wo)));
+        break;
+    }
     case MI_BXDF_LAMBERTIAN_REFLECTION:
     case MI_BXDF_LAMBERTIAN_TRANSMISSION:
         le.kind = LK_MUL1; le.a = kInvPi; break;
@@ -251,7 +298,13 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float cosI = Dot(wi, wh);
         le.a = d.D(wh); le.b = d.G(wo, wi);
         const float denom = (4 * cosThetaI * cosThetaO);
-        if (b.fresnel == MI_FRESNEL_DISNEY) {
+        if (b.fresnel == MI_FRESNEL_CONDUCTOR) {  // FresnelConductor::Evaluate(cosI) = FrConductor(|cosI|, 1, eta, k)
+            le.kind = LK_MICRO_CONDUCTOR;
+            const float c = clampf(absf(cosI), -1, 1);
+            le.c = c * c;
+            le.e = (float)(1. - (double)le.c);
+            le.f = (float)2 * c;
+        } else if (b.fresnel == MI_FRESNEL_DISNEY) {
             le.kind = LK_MICRO_DISNEY;
             le.c = b.p[2];                       // metallic
             le.e = FrDielectric(cosI, 1, b.p[3]);
@@ -332,6 +385,12 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
 
 DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     switch (b.type) {
+    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:470-475
+        if (!SameHemisphere(wo, wi)) return 0;
+        V3 wh = Normalize(wo + wi);
+        float pdf_wh = DistOf(b).Pdf(wo, wh);
+        return .5f * (AbsCosTheta(wi) * kInvPi + pdf_wh / (4 * Dot(wo, wh)));
+    }
     case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR: return 0;
     case MI_BXDF_LAMBERTIAN_TRANSMISSION: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
     case MI_BXDF_MICROFACET_REFLECTION: {
@@ -431,7 +490,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *pdf = 0;
     *sampledType = b.flags;
     LobeEval spec;
-    spec.kind = LK_NONE; spec.lobe = bi; spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
+    spec.kind = LK_NONE; spec.lobe = bi | (b.scaled ? 0x200 : 0); spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
     bool isSpecular = (b.flags & MI_BSDF_SPECULAR) != 0;
     switch (b.type) {
     case MI_BXDF_SPECULAR_REFLECTION: {  // (F*R)/|cos|
@@ -467,9 +526,23 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             if (!Refract(wo, Faceforward(V3(0, 0, 1), wo), etaI / etaT, &wi)) break;
             *sampledType = MI_BSDF_SPECULAR | MI_BSDF_TRANSMISSION;
             *pdf = 1 - F;
-            spec.kind = LK_MUL2_DIV; spec.lobe = bi | 0x100;  // bit 8: use S (= T) instead of R
+            spec.kind = LK_MUL2_DIV; spec.lobe |= 0x100;  // bit 8: use S (= T) instead of R
             spec.a = (1 - F); spec.b = (etaI * etaI) / (etaT * etaT); SetDivisor(spec, AbsCosTheta(wi));
         }
+        break;
+    }
+    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:450-468
+        if ((double)ur0 < .5) {
+            const float v0 = minf(2 * ur0, kOneMinusEpsilon);
+            wi = CosineSampleHemisphere(v0, ur1);
+            if (wo.z < 0) wi.z *= -1;
+        } else {
+            const float v0 = minf(2 * (ur0 - .5f), kOneMinusEpsilon);
+            V3 wh = DistOf(b).Sample_wh(wo, v0, ur1);
+            wi = Reflect(wo, wh);
+            if (!SameHemisphere(wo, wi)) break;
+        }
+        *pdf = LobePdf(b, wo, wi);
         break;
     }
     case MI_BXDF_LAMBERTIAN_TRANSMISSION: {

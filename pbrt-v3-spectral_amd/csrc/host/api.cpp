@@ -172,7 +172,25 @@ struct Api {
             Warn("Material \"" + name + "\" unknown. Using \"matte\".");
             type = "matte";
         }
-        if (!CompileMaterial(type, mp, &m, &scene->warnings, &errs)) {
+        bool compiled;
+        if (type == "mix") {  // api.cpp:573-593 + CreateMixMaterial (mixmat.cpp:66-72)
+            auto lookup = [&](const char *param) -> mi_material {
+                const std::string nm = mp.FindString(param, "");
+                auto it = gs.namedMaterials.find(nm);
+                if (it == gs.namedMaterials.end() || it->second->material < 0) {
+                    Err("Named material \"" + nm + "\" undefined.  Using \"matte\"");
+                    mi_material mm;
+                    std::vector<std::string> e2;
+                    CompileMaterial("matte", mp, &mm, &scene->warnings, &e2);
+                    return mm;
+                }
+                return scene->materials[it->second->material];
+            };
+            const mi_material m1 = lookup("namedmaterial1"), m2 = lookup("namedmaterial2");
+            compiled = CompileMixMaterial(m1, m2, mp.GetSpectrum("amount", Spectrum(0.5f)), &m, &errs);
+        } else
+            compiled = CompileMaterial(type, mp, &m, &scene->warnings, &errs);
+        if (!compiled) {
             for (auto &e : errs) Err(e);
             Err("Material \"" + name + "\" replaced by default matte on this path.");
             ParamSet e1, e2;

@@ -8,6 +8,8 @@
 namespace mipt {
 namespace {
 
+#include "metal_copper_31.inc"
+
 inline float RoughnessToAlpha(float roughness) {  // src/core/microfacet.h:140-145
     roughness = std::max(roughness, (float)1e-3);
     float x = std::log(roughness);
@@ -107,6 +109,62 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_SPECULAR, R);
             b.fresnel = MI_FRESNEL_NOOP;
             Add(m, b, errs);
+        }
+        return true;
+    }
+    if (type == "metal") {  // src/materials/metal.cpp:58-81,128-147: MicrofacetReflection(1, TR, FresnelConductor(1, eta, k))
+        m->kind = 6;
+        Spectrum copperN, copperK;
+        for (int i = 0; i < MI_NSPEC; ++i) { copperN.c[i] = kCopperN[i]; copperK.c[i] = kCopperK[i]; }
+        Spectrum eta = mp.GetSpectrum("eta", copperN);
+        Spectrum k = mp.GetSpectrum("k", copperK);
+        float rough = mp.GetFloat("roughness", .01f);
+        float ur, vr;
+        float uRough = mp.GetFloatOrNull("uroughness", &ur) ? ur : rough;
+        float vRough = mp.GetFloatOrNull("vroughness", &vr) ? vr : rough;
+        if (mp.FindBool("remaproughness", true)) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
+        mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, Spectrum(1.f));
+        b.fresnel = MI_FRESNEL_CONDUCTOR;
+        b.p[0] = uRough; b.p[1] = vRough;
+        SetS(b, eta);
+        for (int i = 0; i < MI_NSPEC; ++i) b.K[i] = k.c[i];
+        Add(m, b, errs);
+        return true;
+    }
+    if (type == "substrate") {  // src/materials/substrate.cpp:45-64,66-81: FresnelBlend(Kd, Ks, TR)
+        m->kind = 7;
+        Spectrum d = mp.GetSpectrum("Kd", Spectrum(.5f)).Clamp();
+        Spectrum s = mp.GetSpectrum("Ks", Spectrum(.5f)).Clamp();
+        float roughu = mp.GetFloat("uroughness", .1f);
+        float roughv = mp.GetFloat("vroughness", .1f);
+        if (!d.IsBlack() || !s.IsBlack()) {
+            if (mp.FindBool("remaproughness", true)) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
+            mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_BLEND, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, d);
+            SetS(b, s);
+            b.p[0] = roughu; b.p[1] = roughv;
+            Add(m, b, errs);
+        }
+        return true;
+    }
+    if (type == "translucent") {  // src/materials/translucent.cpp:45-83,85-102
+        m->kind = 8;
+        const float eta = 1.5f;
+        m->eta = eta;
+        Spectrum r = mp.GetSpectrum("reflect", Spectrum(0.5f)).Clamp();
+        Spectrum t = mp.GetSpectrum("transmit", Spectrum(0.5f)).Clamp();
+        if (r.IsBlack() && t.IsBlack()) return true;
+        Spectrum kd = mp.GetSpectrum("Kd", Spectrum(0.25f)).Clamp();
+        if (!kd.IsBlack()) {
+            if (!r.IsBlack()) Add(m, Lambertian(r * kd), errs);
+            if (!t.IsBlack())
+                Add(m, MakeBxDF(MI_BXDF_LAMBERTIAN_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_DIFFUSE, t * kd), errs);
+        }
+        Spectrum ks = mp.GetSpectrum("Ks", Spectrum(0.25f)).Clamp();
+        if (!ks.IsBlack() && (!r.IsBlack() || !t.IsBlack())) {
+            float rough = mp.GetFloat("roughness", .1f);
+            if (mp.FindBool("remaproughness", true)) rough = RoughnessToAlpha(rough);
+            if (!r.IsBlack()) Add(m, MicrofacetReflectionDielectric(r * ks, rough, rough, 1.f, eta), errs);
+            if (!t.IsBlack()) Add(m, MicrofacetTransmission(t * ks, rough, rough, 1.f, eta, false), errs);
         }
         return true;
     }
@@ -253,6 +311,29 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     }
     errs->push_back("material \"" + type + "\" is outside the PathIntegrator hot-path scope (SURVEY 2 row 18)");
     return false;
+}
+
+// MixMaterial::ComputeScatteringFunctions (src/materials/mixmat.cpp:46-64): the lobes of m1 wrapped in
+// ScaledBxDF(s1 = amount.Clamp()), then those of m2 in ScaledBxDF(s2 = (1 - s1).Clamp()); the BSDF (and
+// its eta) is m1's.
+bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spectrum &amount, mi_material *out,
+                        std::vector<std::string> *errs) {
+    *out = mi_material{};
+    out->kind = 9;
+    out->eta = m1.eta;
+    const Spectrum s1 = amount.Clamp();
+    const Spectrum s2 = (Spectrum(1.f) - s1).Clamp();
+    const mi_material *src[2] = {&m1, &m2};
+    const Spectrum *sc[2] = {&s1, &s2};
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < src[k]->n_bxdfs; ++i) {
+            mi_bxdf b = src[k]->bxdf[i];
+            if (b.scaled) { errs->push_back("a \"mix\" of \"mix\" materials (nested ScaledBxDF) is not built on this path"); return false; }
+            b.scaled = 1;
+            for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j];
+            if (!Add(out, b, errs)) return false;
+        }
+    return true;
 }
 
 }  // namespace mipt

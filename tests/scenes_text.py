@@ -92,6 +92,33 @@ AttributeBegin
   Shape "sphere" "float radius" [.5]
 AttributeEnd
 AttributeBegin
+  Material "metal" "float roughness" [.2]
+  Translate -1.4 0.35 -3.6
+  Shape "sphere" "float radius" [.35]
+AttributeEnd
+AttributeBegin
+  Material "metal" "spectrum eta" [400 1.5 550 0.9 700 0.3] "spectrum k" [400 2.0 550 2.6 700 4.1] "float uroughness" [.05] "float vroughness" [.3]
+  Translate -0.7 0.35 -3.6
+  Shape "sphere" "float radius" [.35]
+AttributeEnd
+AttributeBegin
+  Material "substrate" "rgb Kd" [.5 .2 .1] "rgb Ks" [.3 .3 .3] "float uroughness" [.1] "float vroughness" [.25]
+  Translate 0 0.35 -3.6
+  Shape "sphere" "float radius" [.35]
+AttributeEnd
+AttributeBegin
+  Material "translucent" "rgb Kd" [.5 .5 .3] "rgb Ks" [.3 .3 .3] "rgb reflect" [.6 .6 .6] "rgb transmit" [.4 .4 .4] "float roughness" [.15]
+  Translate 0.7 0.35 -3.6
+  Shape "sphere" "float radius" [.35]
+AttributeEnd
+MakeNamedMaterial "mixA" "string type" "plastic" "rgb Kd" [.7 .1 .1] "rgb Ks" [.3 .3 .3] "float roughness" [.1]
+MakeNamedMaterial "mixB" "string type" "mirror" "rgb Kr" [.9 .9 .9]
+AttributeBegin
+  Material "mix" "string namedmaterial1" "mixA" "string namedmaterial2" "mixB" "rgb amount" [.7 .5 .3]
+  Translate 1.4 0.35 -3.6
+  Shape "sphere" "float radius" [.35]
+AttributeEnd
+AttributeBegin
   Material "plastic" "rgb Kd" [.1 .2 .6] "rgb Ks" [.5 .5 .5] "float roughness" [.08]
   Translate -1.6 0 -2.2
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3 0 3 1 1 3 2]

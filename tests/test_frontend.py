@@ -115,7 +115,7 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     Sampler "sobol"
     Integrator "bdpt"
     WorldBegin
-    Material "metal"
+    Material "hair"
     Shape "cylinder"
     LightSource "infinite"
     ObjectBegin "o"
@@ -125,7 +125,7 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     """
     s = pt.Scene(text=txt)
     errs = "\n".join(s.errors)
-    for word in ("orthographic", "sobol", "bdpt", "metal", "cylinder", "infinite", "instancing"):
+    for word in ("orthographic", "sobol", "bdpt", "hair", "cylinder", "infinite", "instancing"):
         assert word in errs, word
     assert s.stats["n_triangles"] == 1
 
@@ -155,6 +155,20 @@ def test_material_lobe_lists_follow_reference_order(pt):
     assert sorted(m.n_bxdfs for m in disney) == [5, 6]
     thin = [m for m in disney if m.n_bxdfs == 6][0]  # diffuse, fakeSS, retro, microfacet, transmission, lambertian T
     assert [thin.bxdf[i].type for i in range(6)] == [8, 9, 10, 5, 6, 7]
+    # widened materials: metal = one conductor microfacet lobe with R = 1 (metal.cpp:58-81);
+    # default eta/k = copper resampled to the 31 bins (around 1.1-1.3 / 2.2-2.6 in the blue, 0.2 / 3.5+ in the red)
+    metal = [m for m in mats if m.kind == 6]
+    assert len(metal) == 2 and all(m.n_bxdfs == 1 and m.bxdf[0].type == 5 and m.bxdf[0].fresnel == 3 for m in metal)
+    cu = metal[0].bxdf[0]
+    assert all(cu.R[i] == 1.0 for i in range(31))
+    assert 1.0 < cu.S[2] < 1.3 and 0.15 < cu.S[30] < 0.3 and 2.0 < cu.K[2] < 2.7 and 3.8 < cu.K[30] < 4.5
+    sub = [m for m in mats if m.kind == 7][0]
+    assert sub.n_bxdfs == 1 and sub.bxdf[0].type == 13 and sub.bxdf[0].flags == (1 | 8)
+    tr = [m for m in mats if m.kind == 8][0]   # translucent.cpp:56-78: Lambert R, Lambert T, microfacet R, microfacet T
+    assert [tr.bxdf[i].type for i in range(tr.n_bxdfs)] == [0, 7, 5, 6] and tr.eta == 1.5
+    mix = [m for m in mats if m.kind == 9][0]  # mixmat.cpp:46-64: m1's lobes scaled by amount, then m2's by 1 - amount
+    assert [mix.bxdf[i].type for i in range(mix.n_bxdfs)] == [0, 5, 2] and all(mix.bxdf[i].scaled for i in range(3))
+    assert abs(mix.bxdf[0].scale[15] + mix.bxdf[2].scale[15] - 1) < 1e-6 and mix.bxdf[0].scale[15] == mix.bxdf[1].scale[15]
 
 
 def test_spectral_dat_roundtrip_and_header(pt, tmp_path):

@@ -192,23 +192,26 @@ def _bsdf(ob, s, mat, mode, wo, wi=(0, 0, 1), u=(0.5, 0.5), flags=31):
     return out
 
 
-@pytest.mark.parametrize("kind", ["matte", "plastic"])
+@pytest.mark.parametrize("kind", ["matte", "plastic", "metal", "substrate", "translucent", "mix"])
 def test_bsdf_sampling_matches_its_pdf(pt, ob, kind):
     """tests/bsdfs.cpp:484-556 in miniature: the histogram of Sample_f directions over a
     10x20 (cos theta, phi) grid matches the integral of Pdf (chi-square, alpha = 0.01) for
-    Lambertian and Trowbridge-Reitz (plastic, roughness 0.15) lobes."""
+    Lambertian and Trowbridge-Reitz (plastic, roughness 0.15) lobes, and for the widened
+    materials (conductor microfacet, FresnelBlend, translucent's reflection side, a mix)."""
     from scipy import stats
-    s = pt.Scene(KILLEROO, spp=1)
+    kind_id = {"matte": 0, "plastic": 1, "metal": 6, "substrate": 7, "translucent": 8, "mix": 9}[kind]
+    s = pt.Scene(KILLEROO, spp=1) if kind_id < 2 else pt.Scene(text=st.material_zoo(res=16, spp=1))
     d = s.desc
     mats = [d.materials[i] for i in range(d.n_materials)]
-    mat = [i for i, m in enumerate(mats) if (m.kind == (0 if kind == "matte" else 1)) and m.n_bxdfs > 0][-1]
+    mat = [i for i, m in enumerate(mats) if m.kind == kind_id and m.n_bxdfs > 0][0 if kind == "metal" else -1]
+    flags = 31 & ~16   # BSDF_ALL & ~BSDF_SPECULAR: the mix holds a mirror lobe, a delta has no pdf to bin
     rng = np.random.default_rng(3)
     wo = np.array([0.3, 0.2, 0.0], np.float32)
     wo[2] = math.sqrt(1 - wo[0] ** 2 - wo[1] ** 2)
     n_theta, n_phi, n = 10, 20, 60000
     hist = np.zeros((n_theta, n_phi))
     for _ in range(n):
-        o = _bsdf(ob, s, mat, 1, wo, u=rng.random(2))
+        o = _bsdf(ob, s, mat, 1, wo, u=rng.random(2), flags=flags)
         if o[31] <= 0:
             continue
         wi = o[32:35]
@@ -228,7 +231,7 @@ def test_bsdf_sampling_matches_its_pdf(pt, ob, kind):
                     ct = (i + (a + .5) / sub) / n_theta
                     ph = (j + (b + .5) / sub) / n_phi * 2 * math.pi
                     st_ = math.sqrt(max(0, 1 - ct * ct))
-                    acc += _bsdf(ob, s, mat, 0, wo, wi=(st_ * math.cos(ph), st_ * math.sin(ph), ct))[31]
+                    acc += _bsdf(ob, s, mat, 0, wo, wi=(st_ * math.cos(ph), st_ * math.sin(ph), ct), flags=flags)[31]
             expected[i, j] = acc / (sub * sub) * (1.0 / n_theta) * (2 * math.pi / n_phi) * n
     mask = expected > 5
     chi2 = ((hist[mask] - expected[mask]) ** 2 / expected[mask]).sum()
