@@ -332,6 +332,20 @@ struct Api {
             std::vector<int> idx(vi->begin(), vi->begin() + (vi->size() / 3) * 3);
             nTris = (int)idx.size() / 3;
             firstTri = AddTriangleMesh(idx, *P, N, uvs);
+        } else if (name == "plymesh") {  // CreatePLYMesh, plymesh.cpp:149-283
+            std::string fn = params.FindOneString("filename", "");
+            if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;  // FindOneFilename -> AbsolutePath(ResolveFilename())
+            PLYMeshData ply;
+            std::vector<std::string> w;
+            std::string e;
+            const bool okPly = ReadPLYMesh(fn, &ply, &w, &e);
+            for (const std::string &m : w) Warn(m);
+            if (!okPly) { Err(e); return; }
+            if (params.FindTexture("alpha") != "" || params.FindTexture("shadowalpha") != "" ||
+                params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
+                Err("alpha-mask textures are outside the hot-path scope (SURVEY 8f item 1); ignored");
+            nTris = (int)ply.indices.size() / 3;
+            firstTri = AddTriangleMesh(ply.indices, ply.P, ply.N.empty() ? nullptr : &ply.N, ply.UV.empty() ? nullptr : &ply.UV);
         } else if (name == "loopsubdiv") {  // CreateLoopSubdiv, loopsubdiv.cpp:402-424
             int nLevels = params.FindOneInt("levels", params.FindOneInt("nlevels", 3));
             const std::vector<int> *vi = ParamSet::Find(params.ints, "indices");

@@ -68,6 +68,14 @@ void BuildLightDistribution(HostScene *scene, const std::string &strategy);
 // Material compilation (constant textures -> fixed BxDF list),
 // src/materials/{matte,plastic,glass,uber,disney,mirror}.cpp.
 // Returns false (and appends to errs) for materials this path does not cover.
+// Shape "plymesh" (plymesh.cpp)
+struct PLYMeshData {
+    std::vector<int> indices;
+    std::vector<Vec3> P, N;
+    std::vector<Vec2> UV;
+};
+bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std::string> *warnings, std::string *err);
+
 bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spectrum &amount, mi_material *out,
                         std::vector<std::string> *errs);
 bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_material *out,

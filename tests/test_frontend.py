@@ -254,3 +254,68 @@ def test_spectralpath_integrator_is_parsed(pt):
         warned = any("spectral rendering" in m for m in s.warnings)
         assert warned == (want > 1)
         assert s.stats["n_errors"] == 0
+
+
+def _write_ply(path, fmt, verts, faces, normals=None, uvs=None, uv_names=("u", "v")):
+    import struct
+    head = ["ply", "format %s 1.0" % fmt, "comment test mesh", "element vertex %d" % len(verts),
+            "property float x", "property float y", "property float z"]
+    if normals is not None:
+        head += ["property float nx", "property float ny", "property float nz"]
+    if uvs is not None:
+        head += ["property double %s" % uv_names[0], "property double %s" % uv_names[1]]
+    head += ["property uchar red", "element face %d" % len(faces), "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(head) + "\n").encode())
+        e = "<" if fmt != "binary_big_endian" else ">"
+        for i, v in enumerate(verts):
+            row = list(v) + (list(normals[i]) if normals is not None else [])
+            if fmt == "ascii":
+                txt = " ".join(repr(float(np.float32(x))) for x in row)
+                if uvs is not None:
+                    txt += " %r %r" % (float(uvs[i][0]), float(uvs[i][1]))
+                fh.write((txt + " 255\n").encode())
+            else:
+                fh.write(struct.pack(e + "%df" % len(row), *row))
+                if uvs is not None:
+                    fh.write(struct.pack(e + "2d", *uvs[i]))
+                fh.write(struct.pack("B", 255))
+        for f in faces:
+            if fmt == "ascii":
+                fh.write(("%d %s\n" % (len(f), " ".join(map(str, f)))).encode())
+            else:
+                fh.write(struct.pack("B", len(f)) + struct.pack(e + "%di" % len(f), *f))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_plymesh_reads_like_the_equivalent_trianglemesh(pt, tmp_path, fmt):
+    """Shape "plymesh" (plymesh.cpp:149-283): positions, normals, (s,t) texture coordinates, triangles and
+    quads (a,b,c,d) -> (a,b,c),(d,a,c); faces with other vertex counts are skipped with a warning."""
+    rng = np.random.default_rng(2)
+    verts = rng.uniform(-1, 1, (12, 3)).astype(np.float32)
+    normals = rng.normal(size=(12, 3)).astype(np.float32)
+    uvs = rng.random((12, 2)).astype(np.float32)
+    faces = [(0, 1, 2), (3, 4, 5, 6), (7, 8, 9), (9, 10, 11, 0), (1, 2, 3, 4, 5)]
+    _write_ply(tmp_path / "m.ply", fmt, verts, faces, normals, uvs, uv_names=("s", "t"))
+    tri = [0, 1, 2, 3, 4, 5, 6, 3, 5, 7, 8, 9, 9, 10, 11, 0, 9, 11]
+    head = 'LookAt 0 0 -5 0 0 0 0 1 0\nCamera "perspective"\nFilm "image" "integer xresolution" [8] "integer yresolution" [8]\nWorldBegin\nRotate 30 0 1 0\nTranslate .5 0 0\n'
+    a = pt.Scene(text=head + 'Shape "plymesh" "string filename" "m.ply"\nWorldEnd\n', base_dir=str(tmp_path))
+    fl = lambda x: " ".join(repr(float(v)) for v in np.asarray(x).ravel())
+    b = pt.Scene(text=head + 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]\nWorldEnd\n'
+                 % (" ".join(map(str, tri)), fl(verts), fl(normals), fl(uvs)))
+    assert a.errors == [] and a.stats["n_triangles"] == b.stats["n_triangles"] == 6
+    assert any("Ignoring face with 5 vertices" in w for w in a.warnings)
+    da, db = a.desc, b.desc
+    for name, n in (("P", 36), ("N", 36), ("UV", 24)):
+        assert [getattr(da, name)[i] for i in range(n)] == [getattr(db, name)[i] for i in range(n)], name
+    assert [da.tri_indices[i] for i in range(18)] == [db.tri_indices[i] for i in range(18)]
+    assert da.n_nodes == db.n_nodes
+
+
+def test_plymesh_errors(pt, tmp_path):
+    head = 'Camera "perspective"\nWorldBegin\n'
+    s = pt.Scene(text=head + 'Shape "plymesh" "string filename" "missing.ply"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("Couldn't open PLY file" in e for e in s.errors) and s.stats["n_triangles"] == 0
+    _write_ply(tmp_path / "bad.ply", "ascii", np.zeros((3, 3), np.float32), [(0, 1, 7)])
+    s = pt.Scene(text=head + 'Shape "plymesh" "string filename" "bad.ply"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("out of bounds" in e for e in s.errors) and s.stats["n_triangles"] == 0
