@@ -337,6 +337,17 @@ def write_dat(filename, film, scale=1.0):
         raise RuntimeError(host_lib().mi_scene_last_error().decode())
 
 
+def write_rgb(filename, film, weight, scale=1.0):
+    """Film::WriteImage with spectralFlag = false: weighted RGB image as .pfm or .tga (mi_film_write_rgb)."""
+    film = np.ascontiguousarray(film, np.float32)
+    weight = np.ascontiguousarray(weight, np.float32)
+    h, w, _ = film.shape
+    lib = host_lib()
+    lib.mi_film_write_rgb.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
+    if lib.mi_film_write_rgb(os.fsencode(filename), w, h, _fptr(film), _fptr(weight), scale) != 0:
+        raise RuntimeError(lib.mi_scene_last_error().decode())
+
+
 def read_dat(filename):
     w, h = C.c_int(), C.c_int()
     lib = host_lib()

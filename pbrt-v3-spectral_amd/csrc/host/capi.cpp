@@ -75,6 +75,13 @@ int mi_film_write_dat(const char *filename, int w, int h, const float *film_sum,
     return MI_OK;
 }
 
+int mi_film_write_rgb(const char *filename, int w, int h, const float *film_sum, const float *weight_sum, float scale) {
+    if (!filename || !film_sum || !weight_sum || w <= 0 || h <= 0) { g_err = "bad argument"; return MI_ERR_INVALID; }
+    std::string err;
+    if (!WriteRGBImage(filename, w, h, film_sum, weight_sum, scale, nullptr, &err)) { g_err = err; return MI_ERR_INVALID; }
+    return MI_OK;
+}
+
 int mi_film_read_dat(const char *filename, int *w, int *h, float *data, uint64_t capacity) {
     if (!filename || !w || !h) { g_err = "bad argument"; return MI_ERR_INVALID; }
     FILE *f = fopen(filename, "rb");

@@ -64,9 +64,13 @@ int PathIntegrator::Render(const HostScene &scene, std::string *err) {
     if (api.timings) api.timings(pt, &seconds, 1);
     api.destroy(pt);
     std::string out = outfile.empty() ? scene.filmFilename : outfile;
-    if (!scene.spectralFlag)
-        *err = "spectralFlag=false (RGB image output) is a \"next\" row (SURVEY 8f item 3); writing the spectral .dat";
     std::string werr;
+    if (!scene.spectralFlag) {  // Film::WriteImage, RGB branch (film.cpp:182-225)
+        std::string written;
+        if (!WriteRGBImage(out, w, h, film.data(), weight.data(), f.scale, &written, &werr)) { *err = werr; return MI_ERR_INVALID; }
+        if (written != out) *err = "image written as \"" + written + "\" (this build writes PFM and TGA; EXR/PNG are not linked)";
+        return MI_OK;
+    }
     if (!WriteSpectralDat(out, w, h, film.data(), f.scale, &werr)) { *err = werr; return MI_ERR_INVALID; }
     return MI_OK;
 }

@@ -76,6 +76,8 @@ struct PLYMeshData {
 };
 bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std::string> *warnings, std::string *err);
 
+bool WriteRGBImage(const std::string &filename, int w, int h, const float *filmSum, const float *weightSum, float scale,
+                   std::string *written, std::string *err);
 bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spectrum &amount, mi_material *out,
                         std::vector<std::string> *errs);
 bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_material *out,

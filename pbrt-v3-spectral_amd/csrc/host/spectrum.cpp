@@ -18,6 +18,19 @@ inline void XYZToRGB(const float xyz[3], float rgb[3]) {  // spectrum.h:56-60
 
 const float *Spectrum::CIE_Y() { return kCIE_Y; }
 
+void Spectrum::ToXYZ(float xyz[3]) const {
+    xyz[0] = xyz[1] = xyz[2] = 0.f;
+    for (int i = 0; i < kNSpec; ++i) {
+        xyz[0] += kCIE_X[i] * c[i];
+        xyz[1] += kCIE_Y[i] * c[i];
+        xyz[2] += kCIE_Z[i] * c[i];
+    }
+    float scale = float(kLambdaEnd - kLambdaStart) / float(kCIE_Y_integral * kNSpec);
+    xyz[0] *= scale;
+    xyz[1] *= scale;
+    xyz[2] *= scale;
+}
+
 float Spectrum::y() const {
     float yy = 0.f;
     for (int i = 0; i < kNSpec; ++i) yy += kCIE_Y[i] * c[i];

@@ -33,6 +33,7 @@ struct Spectrum {
         for (int i = 0; i < kNSpec; ++i) r.c[i] = c[i] < low ? low : (c[i] > high ? high : c[i]);
         return r;
     }
+    void ToXYZ(float xyz[3]) const;  // spectrum.h:402-414
     float y() const;  // spectrum.h:415-421 (fork clamps negative sums to 0)
     static Spectrum FromRGB(const float rgb[3], SpectrumType type = SpectrumType::Illuminant);
     static Spectrum FromXYZ(const float xyz[3], SpectrumType type = SpectrumType::Reflectance);

@@ -319,3 +319,36 @@ def test_plymesh_errors(pt, tmp_path):
     _write_ply(tmp_path / "bad.ply", "ascii", np.zeros((3, 3), np.float32), [(0, 1, 7)])
     s = pt.Scene(text=head + 'Shape "plymesh" "string filename" "bad.ply"\nWorldEnd\n', base_dir=str(tmp_path))
     assert any("out of bounds" in e for e in s.errors) and s.stats["n_triangles"] == 0
+
+
+def test_rgb_film_output_pfm_and_tga(pt, tmp_path):
+    """Film::WriteImage with "bool spectralFlag" false (film.cpp:182-225): XYZ -> RGB of the summed
+    spectrum, division by the filter-weight sum, clamp at 0, scale; PFM rows run bottom to top."""
+    rng = np.random.default_rng(4)
+    h, w = 5, 7
+    film = (rng.random((h, w, 31)) * 3).astype(np.float32)
+    weight = rng.integers(1, 5, (h, w)).astype(np.float32)
+    weight[0, 0] = 0
+    pt.write_rgb(str(tmp_path / "a.pfm"), film, weight, scale=2.0)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    head, rest = raw.split(b"\n", 3)[:3], raw.split(b"\n", 3)[3]
+    assert head[0] == b"PF" and head[1] == b"7 5" and float(head[2]) == -1.0
+    img = np.frombuffer(rest, "<f4").reshape(h, w, 3)[::-1]
+    # expected: y() of a flat spectrum is its value, so a constant spectrum c has XYZ ~ c*(X,Y,Z of white)
+    const = np.full((1, 1, 31), 0.5, np.float32)
+    pt.write_rgb(str(tmp_path / "c.pfm"), const, np.ones((1, 1), np.float32))
+    c = np.frombuffer(open(tmp_path / "c.pfm", "rb").read().split(b"\n", 3)[3], "<f4")
+    assert np.allclose(c, 0.5 * np.array([1.205, 0.948, 0.909]), atol=0.03)   # equal-energy white in sRGB primaries
+    # linearity and the weight / scale / clamp rules
+    lum = 0.212671 * img[..., 0] + 0.715160 * img[..., 1] + 0.072169 * img[..., 2]
+    s = pt.Scene(text='Camera "perspective"\nWorldBegin\nWorldEnd\n')
+    ciey = np.array([s.desc.cie_y[i] for i in range(31)])
+    y = (film * ciey).sum(-1) * (705 - 395) / (106.856895 * 31)
+    want = np.where(weight != 0, y / np.maximum(weight, 1), y) * 2.0
+    assert np.allclose(lum, want, rtol=2e-3)
+    assert (img >= 0)[weight != 0].all()
+    pt.write_rgb(str(tmp_path / "a.tga"), film, weight)
+    tga = open(tmp_path / "a.tga", "rb").read()
+    assert tga[2] == 2 and tga[12] == 7 and tga[14] == 5 and tga[16] == 24 and len(tga) == 18 + 3 * 35
+    pt.write_rgb(str(tmp_path / "b.exr"), film, weight)       # EXR is not linked: a .pfm beside it
+    assert (tmp_path / "b.pfm").exists()
