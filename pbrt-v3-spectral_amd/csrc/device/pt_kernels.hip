@@ -1595,7 +1595,14 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
-    uint32_t poolN = rp->path_pool ? rp->path_pool : (1u << 25);  // ~22 GB of path state at 32M slots
+    // Default pool: a quarter of the samples to render, between 4M and 32M slots in total (22 GB of path
+    // state at 32M): bigger pools mean fewer, better-filled launches, but the last iterations of a render
+    // drain the pool at low occupancy, which a small job (one shard of a multi-GPU frame) feels.
+    uint32_t poolN = rp->path_pool;
+    if (poolN == 0) {
+        const unsigned long long quarter = wd.totalWork * (unsigned long long)subCount / 4;
+        poolN = (uint32_t)std::min<unsigned long long>(1ull << 25, std::max<unsigned long long>(1ull << 22, quarter));
+    }
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
