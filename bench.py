@@ -105,7 +105,7 @@ def main():
         step()
 
     keys = ("camera_rays", "regular_rays", "shadow_rays", "extend_rays", "extend_nodes", "extend_tri_tests",
-            "iterations", "bvh_nodes_visited", "tri_tests")
+            "iterations", "bvh_nodes_visited", "tri_tests", "total_paths")
     acc = dict.fromkeys(keys, 0)
     t_kernel = [0.0] * 7
     ptdist.barrier()
@@ -156,6 +156,24 @@ def main():
                 "kernel_time_s": {"generate": round(t_kernel[1], 4), "trav0": round(t_kernel[6], 4), "extend": round(t_kernel[2], 4),
                                   "shade": round(t_kernel[3], 4), "shadow": round(t_kernel[4], 4),
                                   "mis": round(t_kernel[5], 4), "render_loop": round(t_kernel[0], 4)}}
+
+    # per kernel class: algorithmic bytes / summed class time on this rank. The class times come
+    # from HIP events that bracket the traversal kernel together with its resolve kernel, and the classes of
+    # the concurrent streams overlap, so these are lower bounds of what each class reaches alone.
+    other_rays = max(1, acc["regular_rays"] + acc["shadow_rays"] - acc["extend_rays"])
+    other_bytes = 32.0 * (acc["bvh_nodes_visited"] - acc["extend_nodes"]) + 48.0 * (acc["tri_tests"] - acc["extend_tri_tests"]) \
+        + (64.0 + 248.0) * other_rays
+    vertices = max(1, acc["total_paths"])
+
+    def _cls(nbytes, secs):
+        g = nbytes / secs / 1e9 if secs > 0 else 0.0
+        return {"achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "unit": "GB/s", "seconds": round(secs, 4)}
+    roofline["classes"] = {
+        "extend (k_trav<0> + k_resolve_extend)": _cls(b_ray * ext_rays, t_kernel[2]),
+        "shadow + mis (k_trav<1,2> + resolves), B_ray + 248 B": _cls(other_bytes, t_kernel[4] + t_kernel[5]),
+        "shade (k_shade), 0.96 KB/vertex": _cls(960.0 * vertices, t_kernel[3]),
+        "generate (k_generate), 408 B/sample": _cls(408.0 * acc["camera_rays"], t_kernel[1]),
+    }
 
     # The same kernel with the GPU to itself: one untimed 64-spp pass through a one-stream
     # integrator (rank 0, N = 1), so the concurrent-launch figure above has its reference.
