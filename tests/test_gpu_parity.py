@@ -286,3 +286,40 @@ def test_spectralpath_with_one_band_is_the_path_integrator(pt):
     fa, wa = pt.CreatePathIntegrator(a).Render()
     fb, wb = pt.CreatePathIntegrator(b).Render()
     assert np.array_equal(wa, wb) and _rel_l2(fb, fa) < 1e-6
+
+
+_ZOO_VARIANTS = {
+    "thin_lens": [('Camera "perspective" "float fov" [40]', 'Camera "perspective" "float fov" [40] "float lensradius" [.15] "float focaldistance" [8]')],
+    "maxdepth0": [('"integer maxdepth" [6]', '"integer maxdepth" [0]')],
+    "maxdepth1": [('"integer maxdepth" [6]', '"integer maxdepth" [1]')],
+    "rr_off": [('Integrator "path"', 'Integrator "path" "float rrthreshold" [0]')],
+    "pixelbounds": [('Integrator "path"', 'Integrator "path" "integer pixelbounds" [10 40 5 30]')],
+    "clamp_scale": [('Film "image"', 'Film "image" "float maxsampleluminance" [1.5] "float scale" [2.5]')],
+    "mitchell": [('Sampler "halton"', 'PixelFilter "mitchell" "float xwidth" [1.5] "float ywidth" [2] "float B" [.4] "float C" [.3]\nSampler "halton"')],
+    "sinc": [('Sampler "halton"', 'PixelFilter "sinc" "float xwidth" [3] "float ywidth" [3] "float tau" [2]\nSampler "halton"')],
+    "triangle": [('Sampler "halton"', 'PixelFilter "triangle" "float xwidth" [1.2] "float ywidth" [.7]\nSampler "halton"')],
+    "pixel_center": [('Sampler "halton"', 'Sampler "halton" "bool samplepixelcenter" "true"\n# ')],
+}
+
+
+@pytest.mark.parametrize("variant", sorted(_ZOO_VARIANTS))
+def test_camera_film_filter_and_integrator_parameters(pt, ob, variant):
+    """The parameters of the path's own plugins (perspective.cpp:148-189, film.cpp:311-352, path.cpp:190-213,
+    filters/*.cpp, halton.cpp:133-140), one at a time on the material zoo."""
+    txt = st.material_zoo(res=48, spp=8, depth=6)
+    for a, b in _ZOO_VARIANTS[variant]:
+        assert a in txt, a
+        txt = txt.replace(a, b, 1)
+    s = pt.Scene(text=txt)
+    assert s.errors == []
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
+    assert np.allclose(weight, oweight, rtol=1e-5, atol=1e-6)
+    assert _rel_l2(film, ofilm) < 2e-3
+    assert np.median(_pixel_l2(film, ofilm, 8)) <= 1e-5 * max(float(ofilm.mean()) / 8, 1e-9)
+    if variant == "pixelbounds":
+        assert not weight[:5].any() and not weight[:, :10].any() and weight[5:30, 10:40].all()
+    if variant == "maxdepth0":
+        assert integ.counters.shadow_rays == 0
