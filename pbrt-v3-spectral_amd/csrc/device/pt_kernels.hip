@@ -64,13 +64,24 @@ enum : int {
     P_ETASCALE, P_FILMX, P_FILMY,
     P_SOX, P_SOY, P_SOZ, P_SDX, P_SDY, P_SDZ,       // shadow ray (tMax = 1 - ShadowEpsilon)
     P_MOX, P_MOY, P_MOZ, P_MDX, P_MDY, P_MDZ,       // MIS ray
-    P_L,                                            // 31 planes each from here on
-    P_BETA = P_L + MI_NSPEC,
-    P_LNEE = P_BETA + MI_NSPEC,
-    P_LMIS = P_LNEE + MI_NSPEC,
-    P_COUNT = P_LMIS + MI_NSPEC,
-    P_LCA = P_COUNT   // 31 more planes, allocated for Integrator "spectralpath" only: the sample's stitched bands
+    P_COUNT
 };
+// ---- spectral planes. A 31-bin spectrum of a slot is stored as NQ = 8 float4 "quad planes": bins
+// 4c..4c+3 of slot i at q[(set + c) * pool + i] (bin 31 is padding, kept 0 in everything that is summed or
+// tested). One 16-B access per lane moves four bins, so a spectral pass issues a quarter of the memory
+// instructions of one-float planes and -- the lanes of a shading wave hold scattered slots -- touches fewer
+// cache lines per bin.
+constexpr int NQ = 8;
+enum : int {
+    Q_L = 0,                // radiance gathered by the path
+    Q_BETA = NQ,            // throughput
+    Q_LNEE = 2 * NQ,        // pending light-sample contribution (added when the shadow ray is unoccluded)
+    Q_LMIS = 3 * NQ,        // pending BSDF-sample (MIS) contribution
+    Q_COUNT = 4 * NQ,
+    Q_LCA = Q_COUNT         // Integrator "spectralpath" only: the sample's stitched bands
+};
+DEV float Get4(const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+DEV void Set4(float4 &v, int k, float x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
 // ---- int planes
 enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT,
              I_NPEND, I_PEND0, I_PEND1, I_PEND2, I_PEND3,  // quadrics postponed by the traversal kernel
@@ -91,11 +102,13 @@ constexpr int MISS_CLASS = 7;
 
 struct Pool {
     float *f;
+    float4 *q;   // spectral quad planes
     int *i;
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
+    DEV float4 &Q(int plane, uint32_t slot) const { return q[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
 };
 
@@ -658,10 +671,12 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
         }
         bool added = false;
         if (!occluded) {
-            for (int b = 0; b < MI_NSPEC; ++b) {
-                float c = pool.F(P_LNEE + b, slot);
-                added |= (c != 0.f);
-                pool.F(P_L + b, slot) += c;
+            for (int c = 0; c < NQ; ++c) {
+                const float4 a = pool.Q(Q_LNEE + c, slot);
+                added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+                float4 l = pool.Q(Q_L + c, slot);
+                l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+                pool.Q(Q_L + c, slot) = l;
             }
         }
         flags &= ~F_SHADOW;
@@ -696,10 +711,12 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
                     emit = Dot(li.n, -rd) > 0;
                 }
                 if (emit) {
-                    for (int b = 0; b < MI_NSPEC; ++b) {
-                        float c = pool.F(P_LMIS + b, slot);
-                        added |= (c != 0.f);
-                        pool.F(P_L + b, slot) += c;
+                    for (int c = 0; c < NQ; ++c) {
+                        const float4 a = pool.Q(Q_LMIS + c, slot);
+                        added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+                        float4 l = pool.Q(Q_L + c, slot);
+                        l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+                        pool.Q(Q_L + c, slot) = l;
                     }
                 }
             }
@@ -762,11 +779,18 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         float yy = 0.f;
         bool hasNaN = false;
         float *row = &sL[threadIdx.x * 33];
-        for (int b = 0; b < MI_NSPEC; ++b) {
-            float v = pool.F(P_L + b, slot);
-            hasNaN |= isnanf_(v);
-            yy += s.cieY[b] * v;
-            row[b] = v;
+        for (int c = 0; c < NQ; ++c) {
+            const float4 v4 = pool.Q(Q_L + c, slot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = 4 * c + k;
+                if (b < MI_NSPEC) {
+                    const float v = Get4(v4, k);
+                    hasNaN |= isnanf_(v);
+                    yy += s.cieY[b] * v;
+                    row[b] = v;
+                }
+            }
         }
         float y = YScale(yy);
         bool zero = false;
@@ -776,15 +800,31 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         if (zero) ++bad;
         if (nBands > 1) {
             const int lo = s.bandDelta * band, hi = min(s.bandDelta * (band + 1), MI_NSPEC);
-            for (int b = lo; b < hi; ++b) pool.F(P_LCA + b, slot) = zero ? 0.f : row[b];
+            for (int c = 0; c < NQ; ++c) {   // bins [lo, hi) of the stitched spectrum <- this band's path
+                if (4 * c + 3 < lo || 4 * c >= hi) continue;
+                float4 v4 = pool.Q(Q_LCA + c, slot);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int b = 4 * c + k;
+                    if (b >= lo && b < hi) Set4(v4, k, zero ? 0.f : row[b]);
+                }
+                pool.Q(Q_LCA + c, slot) = v4;
+            }
             zero = false;
             if (band + 1 < nBands) restart = true;
             else {
                 yy = 0.f;
-                for (int b = 0; b < MI_NSPEC; ++b) {
-                    const float v = pool.F(P_LCA + b, slot);
-                    yy += s.cieY[b] * v;
-                    row[b] = v;
+                for (int c = 0; c < NQ; ++c) {
+                    const float4 v4 = pool.Q(Q_LCA + c, slot);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int b = 4 * c + k;
+                        if (b < MI_NSPEC) {
+                            const float v = Get4(v4, k);
+                            yy += s.cieY[b] * v;
+                            row[b] = v;
+                        }
+                    }
                 }
                 y = YScale(yy);
             }
@@ -898,7 +938,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         pool.F(P_TMAX, slot) = ray.tMax;
         pool.F(P_ETASCALE, slot) = 1.f;
         pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
-        for (int b = 0; b < MI_NSPEC; ++b) { pool.F(P_L + b, slot) = 0.f; pool.F(P_BETA + b, slot) = 1.f; }
+        for (int c = 0; c < NQ; ++c) {
+            pool.Q(Q_L + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+            pool.Q(Q_BETA + c, slot) = make_float4(1.f, 1.f, 1.f, (c == NQ - 1) ? 0.f : 1.f);
+        }
         pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
         pool.I(I_SAMPLE, slot) = (int)sampleNum;
         pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
@@ -906,7 +949,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         if (!restart) pool.I(I_DIM, slot) = 5;
         if (nBands > 1) {
             pool.I(I_BAND, slot) = restart ? band + 1 : 0;
-            if (!restart) for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_LCA + b, slot) = 0.f;
+            if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         pool.I(I_BOUNCES, slot) = 0;
         flags = F_ALIVE;
@@ -980,7 +1023,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 const mi_light &l = s.lights[li];
                 if (l.two_sided || Dot(isect.n, -rd) > 0)
 #pragma unroll 1
-                    for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_L + b, slot) += pool.F(P_BETA + b, slot) * l.L[b];
+                    for (int c = 0; c < NQ; ++c) {
+                        const float4 bt = pool.Q(Q_BETA + c, slot);
+                        float4 L4 = pool.Q(Q_L + c, slot);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int b = 4 * c + k;
+                            if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * l.L[b]);
+                        }
+                        pool.Q(Q_L + c, slot) = L4;
+                    }
             }
         }
         if (!found || bounces >= s.maxDepth) finished = true;
@@ -1027,14 +1079,23 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             const Divisor lpDiv = MakeDivisor(lightPdf);
                             bool fNonBlack = false, liNonBlack = false;
 #pragma unroll 1
-                            for (int b = 0; b < MI_NSPEC; ++b) {
-                                const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
-                                const float Li = LiBin(light, ls, b);
-                                fNonBlack |= (f != 0.f);
-                                liNonBlack |= (Li != 0.f);
-                                float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
-                                if (!selIsOne) Ld = DivBy(Ld, selDiv);
-                                pool.F(P_LNEE + b, slot) = pool.F(P_BETA + b, slot) * Ld;
+                            for (int c = 0; c < NQ; ++c) {
+                                const float4 bt = pool.Q(Q_BETA + c, slot);
+                                float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const int b = 4 * c + k;
+                                    if (b < MI_NSPEC) {
+                                        const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                        const float Li = LiBin(light, ls, b);
+                                        fNonBlack |= (f != 0.f);
+                                        liNonBlack |= (Li != 0.f);
+                                        float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
+                                        if (!selIsOne) Ld = DivBy(Ld, selDiv);
+                                        Set4(out, k, Get4(bt, k) * Ld);
+                                    }
+                                }
+                                pool.Q(Q_LNEE + c, slot) = out;
                             }
                             if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
@@ -1062,12 +1123,21 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 const Divisor spDiv = MakeDivisor(sPdf);
                                 bool fNonBlack = false;
 #pragma unroll 1
-                                for (int b = 0; b < MI_NSPEC; ++b) {
-                                    const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
-                                    fNonBlack |= (f != 0.f);
-                                    float Ld = DivBy((f * light.L[b]) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
-                                    if (!selIsOne) Ld = DivBy(Ld, selDiv);
-                                    pool.F(P_LMIS + b, slot) = pool.F(P_BETA + b, slot) * Ld;
+                                for (int c = 0; c < NQ; ++c) {
+                                    const float4 bt = pool.Q(Q_BETA + c, slot);
+                                    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        const int b = 4 * c + k;
+                                        if (b < MI_NSPEC) {
+                                            const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                            fNonBlack |= (f != 0.f);
+                                            float Ld = DivBy((f * light.L[b]) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
+                                            if (!selIsOne) Ld = DivBy(Ld, selDiv);
+                                            Set4(out, k, Get4(bt, k) * Ld);
+                                        }
+                                    }
+                                    pool.Q(Q_LMIS + c, slot) = out;
                                 }
                                 if (fNonBlack && go) {
                                     Ray mr = SpawnRay(isect, wi);
@@ -1100,13 +1170,21 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const Divisor pdfDiv = MakeDivisor(pdf);
                     float maxRR = 0;
 #pragma unroll 1
-                    for (int b = 0; b < MI_NSPEC; ++b) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
-                        const float f = EvalBin<NL>(ev, mat->bxdf, b);
-                        fNonBlack |= (f != 0.f);
-                        const float nb = pool.F(P_BETA + b, slot) * DivBy(f * absdot, pdfDiv);
-                        pool.F(P_BETA + b, slot) = nb;
-                        const float rr = nb * etaScale;
-                        maxRR = (b == 0) ? rr : maxf(maxRR, rr);
+                    for (int c = 0; c < NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
+                        float4 bt = pool.Q(Q_BETA + c, slot);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int b = 4 * c + k;
+                            if (b < MI_NSPEC) {
+                                const float f = EvalBin<NL>(ev, mat->bxdf, b);
+                                fNonBlack |= (f != 0.f);
+                                const float nb = Get4(bt, k) * DivBy(f * absdot, pdfDiv);
+                                Set4(bt, k, nb);
+                                const float rr = nb * etaScale;
+                                maxRR = (b == 0) ? rr : maxf(maxRR, rr);
+                            }
+                        }
+                        pool.Q(Q_BETA + c, slot) = bt;
                     }
                     if (fNonBlack) {
                         Ray nr = SpawnRay(isect, wi);
@@ -1118,7 +1196,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             else {
                                 const Divisor inv = MakeDivisor(1 - q);
 #pragma unroll 1
-                                for (int b = 0; b < MI_NSPEC; ++b) pool.F(P_BETA + b, slot) = DivBy(pool.F(P_BETA + b, slot), inv);
+                                for (int c = 0; c < NQ; ++c) {
+                                    float4 bt = pool.Q(Q_BETA + c, slot);
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k)
+                                        if (4 * c + k < MI_NSPEC) Set4(bt, k, DivBy(Get4(bt, k), inv));
+                                    pool.Q(Q_BETA + c, slot) = bt;
+                                }
                             }
                         }
                         if (killed) finished = true;
@@ -1288,14 +1372,15 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
     return MI_OK;
 }
 
-int EnsurePool(SubRenderer &sub, uint32_t n, int nFloatPlanes) {
+int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     Pool &p = sub.pool;
     if (p.n == n && p.f) return MI_OK;
     if (p.f) {
-        hipFree(p.f); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
-        p.f = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
+        hipFree(p.f); hipFree(p.q); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
+        p.f = nullptr; p.q = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
     }
-    HIPCHK(hipMalloc((void **)&p.f, (size_t)nFloatPlanes * n * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&p.q, (size_t)nQuadPlanes * n * sizeof(float4)));
     HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
@@ -1606,7 +1691,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
-    int rc = EnsurePool(sub, poolN, P_COUNT + (s.nBands > 1 ? MI_NSPEC : 0));
+    int rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
     if (rc != MI_OK) return rc;
     HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
     HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));
@@ -1764,6 +1849,7 @@ void mi_pt_destroy(mi_pt *pt) {
     for (SubRenderer &sub : pt->subs) {
         Pool &p = sub.pool;
         if (p.f) hipFree(p.f);
+        if (p.q) hipFree(p.q);
         if (p.i) hipFree(p.i);
         if (p.shadowQ) hipFree(p.shadowQ);
         if (p.misQ) hipFree(p.misQ);
