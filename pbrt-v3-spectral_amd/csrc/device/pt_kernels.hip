@@ -59,12 +59,17 @@ constexpr int STACK_SPILL = 64 - STACK_LDS;     // deeper entries (pbrt allows 6
 
 // ---- float planes
 enum : int {
-    P_OX = 0, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TMAX,
-    P_HIT_T, P_B0, P_B1, P_B2,
-    P_ETASCALE, P_FILMX, P_FILMY,
-    P_SOX, P_SOY, P_SOZ, P_SDX, P_SDY, P_SDZ,       // shadow ray (tMax = 1 - ShadowEpsilon)
-    P_MOX, P_MOY, P_MOZ, P_MDX, P_MDY, P_MDZ,       // MIS ray
+    P_FILMX = 0, P_FILMY,
     P_COUNT
+};
+// ---- float4 record planes: values that are read and written together travel in one 16-B access
+enum : int {
+    R_RAY0 = 0,   // path ray: o.xyz, tMax
+    R_RAY1,       //           d.xyz, etaScale
+    R_HIT,        // t, b0, b1, b2 of the last traversal (path ray, or MIS ray)
+    R_SH0, R_SH1, // shadow ray (tMax = 1 - ShadowEpsilon): o.xyz d.x | d.y d.z - -
+    R_MI0, R_MI1, // MIS ray: same packing
+    R_COUNT
 };
 // ---- spectral planes. A 31-bin spectrum of a slot is stored as NQ = 8 float4 "quad planes": bins
 // 4c..4c+3 of slot i at q[(set + c) * pool + i] (bin 31 is padding, kept 0 in everything that is summed or
@@ -103,12 +108,14 @@ constexpr int MISS_CLASS = 7;
 struct Pool {
     float *f;
     float4 *q;   // spectral quad planes
+    float4 *r;   // record planes
     int *i;
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
     DEV float4 &Q(int plane, uint32_t slot) const { return q[(size_t)plane * n + slot]; }
+    DEV float4 &R(int plane, uint32_t slot) const { return r[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
 };
 
@@ -422,7 +429,6 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
-    constexpr int PO = (MODE == 0) ? P_OX : ((MODE == 1) ? P_SOX : P_MOX);
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
     const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
@@ -466,9 +472,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         if (MODE == 0) { slot = my; take = (pool.I(I_FLAGS, slot) & F_ALIVE) != 0; }
                         else slot = queue[my];
                         if (take) {
-                            InitRayCtx(r, pool.F(PO + 0, slot), pool.F(PO + 1, slot), pool.F(PO + 2, slot), pool.F(PO + 3, slot),
-                                       pool.F(PO + 4, slot), pool.F(PO + 5, slot));
-                            tMax = (MODE == 0) ? pool.F(P_TMAX, slot) : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
+                            const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
+                            const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
+                            if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
+                            else InitRayCtx(r, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+                            tMax = (MODE == 0) ? r0.w : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
                             StartTraversal(s, r, tMax, st, nodeCount);
                             triRay = MakeTriRay(V3(r.dx, r.dy, r.dz));
                             nPend = 0; hitPrim = -1;
@@ -479,7 +487,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             else {  // the ray misses the world bound: nothing to traverse
                                 pool.I(I_HITPRIM, slot) = -1;
                                 pool.I(I_NPEND, slot) = 0;
-                                if (!ANY) { pool.F(P_HIT_T, slot) = 0; pool.F(P_B0, slot) = 0; pool.F(P_B1, slot) = 0; pool.F(P_B2, slot) = 0; }
+                                if (!ANY) pool.R(R_HIT, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
                             }
                         }
                     }
@@ -565,7 +573,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (finished) {
                 pool.I(I_HITPRIM, slot) = hitPrim;
                 pool.I(I_NPEND, slot) = nPend;
-                if (!ANY) { pool.F(P_HIT_T, slot) = hitT; pool.F(P_B0, slot) = hitB0; pool.F(P_B1, slot) = hitB1; pool.F(P_B2, slot) = hitB2; }
+                if (!ANY) pool.R(R_HIT, slot) = make_float4(hitT, hitB0, hitB1, hitB2);
                 has = false;
                 leafCnt = 0;
             }
@@ -621,14 +629,14 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
         traced = true;
         int prim = pool.I(I_HITPRIM, slot);
         if (pool.I(I_NPEND, slot) != 0) {
-            V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
-            V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+            const float4 r0 = pool.R(R_RAY0, slot), r1 = pool.R(R_RAY1, slot), hr = pool.R(R_HIT, slot);
+            V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
             Hit h;
-            h.prim = prim; h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
-            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, pool.F(P_TMAX, slot), &h, prim >= 0, nodes, tris);
+            h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
+            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
             prim = found ? h.prim : -1;
             pool.I(I_HITPRIM, slot) = prim;
-            pool.F(P_HIT_T, slot) = h.t; pool.F(P_B0, slot) = h.b0; pool.F(P_B1, slot) = h.b1; pool.F(P_B2, slot) = h.b2;
+            pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
         }
         cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
     }
@@ -664,8 +672,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
         int flags = pool.I(I_FLAGS, slot);
         bool occluded = pool.I(I_HITPRIM, slot) >= 0;
         if (!occluded && pool.I(I_NPEND, slot) != 0) {
-            V3 ro(pool.F(P_SOX, slot), pool.F(P_SOY, slot), pool.F(P_SOZ, slot));
-            V3 rd(pool.F(P_SDX, slot), pool.F(P_SDY, slot), pool.F(P_SDZ, slot));
+            const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
+            V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
             Hit h;
             occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
         }
@@ -693,10 +701,10 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
     if (qi < ctr->misCount.v) {
         const uint32_t slot = pool.misQ[qi];
         const int flags = pool.I(I_FLAGS, slot);
-        V3 ro(pool.F(P_MOX, slot), pool.F(P_MOY, slot), pool.F(P_MOZ, slot));
-        V3 rd(pool.F(P_MDX, slot), pool.F(P_MDY, slot), pool.F(P_MDZ, slot));
+        const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
+        V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
         Hit h;
-        h.prim = pool.I(I_HITPRIM, slot); h.t = pool.F(P_HIT_T, slot); h.b0 = pool.F(P_B0, slot); h.b1 = pool.F(P_B1, slot); h.b2 = pool.F(P_B2, slot);
+        h.prim = pool.I(I_HITPRIM, slot); h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
         bool found = h.prim >= 0;
         if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris);
         bool added = false;
@@ -933,10 +941,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         Ray ray;
         CameraRay(s, pfx, pfy, lu, lv, &ray);
         ++cam;
-        pool.F(P_OX, slot) = ray.o.x; pool.F(P_OY, slot) = ray.o.y; pool.F(P_OZ, slot) = ray.o.z;
-        pool.F(P_DX, slot) = ray.d.x; pool.F(P_DY, slot) = ray.d.y; pool.F(P_DZ, slot) = ray.d.z;
-        pool.F(P_TMAX, slot) = ray.tMax;
-        pool.F(P_ETASCALE, slot) = 1.f;
+        pool.R(R_RAY0, slot) = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
+        pool.R(R_RAY1, slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, 1.f);   // etaScale = 1
         pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
         for (int c = 0; c < NQ; ++c) {
             pool.Q(Q_L + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1011,11 +1017,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         const int bounces = pool.I(I_BOUNCES, slot);
         const int prim = pool.I(I_HITPRIM, slot);
         const bool found = prim >= 0;
-        V3 ro(pool.F(P_OX, slot), pool.F(P_OY, slot), pool.F(P_OZ, slot));
-        V3 rd(pool.F(P_DX, slot), pool.F(P_DY, slot), pool.F(P_DZ, slot));
+        const float4 ray0 = pool.R(R_RAY0, slot), ray1 = pool.R(R_RAY1, slot);
+        V3 ro(ray0.x, ray0.y, ray0.z), rd(ray1.x, ray1.y, ray1.z);
         SurfaceInteraction isect;
         bool finished = false, passThrough = false;
-        if (found) HitInteraction(s, prim, ro, rd, pool.F(P_B0, slot), pool.F(P_B1, slot), pool.F(P_B2, slot), &isect);
+        if (found) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, ro, rd, hr.y, hr.z, hr.w, &isect); }
         // emitted light at the vertex, path.cpp:91-101
         if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
             const int li = s.prims[prim].area_light;
@@ -1039,8 +1045,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         int newFlags = 0;
         if (!finished && s.prims[prim].material < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
             Ray r = SpawnRay(isect, rd);
-            pool.F(P_OX, slot) = r.o.x; pool.F(P_OY, slot) = r.o.y; pool.F(P_OZ, slot) = r.o.z;
-            pool.F(P_TMAX, slot) = r.tMax;
+            pool.R(R_RAY0, slot) = make_float4(r.o.x, r.o.y, r.o.z, r.tMax);
             passThrough = true;  // flags and bounce count stay as they are
         }
         if (!finished && !passThrough) {
@@ -1099,8 +1104,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             }
                             if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
-                                pool.F(P_SOX, slot) = sr.o.x; pool.F(P_SOY, slot) = sr.o.y; pool.F(P_SOZ, slot) = sr.o.z;
-                                pool.F(P_SDX, slot) = sr.d.x; pool.F(P_SDY, slot) = sr.d.y; pool.F(P_SDZ, slot) = sr.d.z;
+                                pool.R(R_SH0, slot) = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.d.x);
+                                pool.R(R_SH1, slot) = make_float4(sr.d.y, sr.d.z, 0.f, 0.f);
                                 newFlags |= F_SHADOW;
                             }
                         }
@@ -1141,8 +1146,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 }
                                 if (fNonBlack && go) {
                                     Ray mr = SpawnRay(isect, wi);
-                                    pool.F(P_MOX, slot) = mr.o.x; pool.F(P_MOY, slot) = mr.o.y; pool.F(P_MOZ, slot) = mr.o.z;
-                                    pool.F(P_MDX, slot) = mr.d.x; pool.F(P_MDY, slot) = mr.d.y; pool.F(P_MDZ, slot) = mr.d.z;
+                                    pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
+                                    pool.R(R_MI1, slot) = make_float4(mr.d.y, mr.d.z, 0.f, 0.f);
                                     pool.I(I_MISLIGHT, slot) = lightNum;
                                     newFlags |= F_MIS;
                                 }
@@ -1162,7 +1167,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 bool fNonBlack = false;
                 if (ok && pdf != 0.f) {
                     const float absdot = AbsDot(wi, isect.shN);
-                    float etaScale = pool.F(P_ETASCALE, slot);
+                    float etaScale = ray1.w;
                     if ((sflags & MI_BSDF_SPECULAR) && (sflags & MI_BSDF_TRANSMISSION)) {
                         float eta = mat->eta;
                         etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
@@ -1207,10 +1212,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         }
                         if (killed) finished = true;
                         else {
-                            pool.F(P_OX, slot) = nr.o.x; pool.F(P_OY, slot) = nr.o.y; pool.F(P_OZ, slot) = nr.o.z;
-                            pool.F(P_DX, slot) = nr.d.x; pool.F(P_DY, slot) = nr.d.y; pool.F(P_DZ, slot) = nr.d.z;
-                            pool.F(P_TMAX, slot) = nr.tMax;
-                            pool.F(P_ETASCALE, slot) = etaScale;
+                            pool.R(R_RAY0, slot) = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.tMax);
+                            pool.R(R_RAY1, slot) = make_float4(nr.d.x, nr.d.y, nr.d.z, etaScale);
                             if (sflags & MI_BSDF_SPECULAR) newFlags |= F_SPECULAR;
                         }
                     }
@@ -1376,11 +1379,12 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     Pool &p = sub.pool;
     if (p.n == n && p.f) return MI_OK;
     if (p.f) {
-        hipFree(p.f); hipFree(p.q); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
-        p.f = nullptr; p.q = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
+        hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
+        p.f = nullptr; p.q = nullptr; p.r = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
     }
     HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&p.q, (size_t)nQuadPlanes * n * sizeof(float4)));
+    HIPCHK(hipMalloc((void **)&p.r, (size_t)R_COUNT * n * sizeof(float4)));
     HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
@@ -1850,6 +1854,7 @@ void mi_pt_destroy(mi_pt *pt) {
         Pool &p = sub.pool;
         if (p.f) hipFree(p.f);
         if (p.q) hipFree(p.q);
+        if (p.r) hipFree(p.r);
         if (p.i) hipFree(p.i);
         if (p.shadowQ) hipFree(p.shadowQ);
         if (p.misQ) hipFree(p.misQ);
