@@ -96,7 +96,11 @@ constexpr int MAX_PEND = 4;
 constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
 // ---- slot flags
 enum : int {
-    F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128
+    F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128,
+    // A new path has L = 0 and beta = 1. Writing those 16 quads into freshly (sparsely) refilled slots cost as
+    // much as the rest of k_generate, so they stay implicit until something else is written there:
+    F_L_ZERO = 256,     // Q_L holds no value yet; it reads as 0 (0 + x == x)
+    F_BETA_ONE = 512    // Q_BETA holds no value yet; it reads as 1 (1 * x == x)
 };
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
@@ -679,13 +683,16 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
         }
         bool added = false;
         if (!occluded) {
+            const bool lZero = (flags & F_L_ZERO) != 0;
             for (int c = 0; c < NQ; ++c) {
                 const float4 a = pool.Q(Q_LNEE + c, slot);
                 added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                float4 l = pool.Q(Q_L + c, slot);
+                float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!lZero) l = pool.Q(Q_L + c, slot);
                 l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
                 pool.Q(Q_L + c, slot) = l;
             }
+            flags &= ~F_L_ZERO;
         }
         flags &= ~F_SHADOW;
         if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
@@ -700,7 +707,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
     unsigned zero = 0, nodes = 0, tris = 0;
     if (qi < ctr->misCount.v) {
         const uint32_t slot = pool.misQ[qi];
-        const int flags = pool.I(I_FLAGS, slot);
+        int flags = pool.I(I_FLAGS, slot);
         const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
         V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
         Hit h;
@@ -719,13 +726,16 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
                     emit = Dot(li.n, -rd) > 0;
                 }
                 if (emit) {
+                    const bool lZero = (flags & F_L_ZERO) != 0;
                     for (int c = 0; c < NQ; ++c) {
                         const float4 a = pool.Q(Q_LMIS + c, slot);
                         added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                        float4 l = pool.Q(Q_L + c, slot);
+                        float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!lZero) l = pool.Q(Q_L + c, slot);
                         l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
                         pool.Q(Q_L + c, slot) = l;
                     }
+                    flags &= ~F_L_ZERO;
                 }
             }
         }
@@ -787,8 +797,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         float yy = 0.f;
         bool hasNaN = false;
         float *row = &sL[threadIdx.x * 33];
+        const bool lZero = (flags & F_L_ZERO) != 0;
         for (int c = 0; c < NQ; ++c) {
-            const float4 v4 = pool.Q(Q_L + c, slot);
+            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!lZero) v4 = pool.Q(Q_L + c, slot);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int b = 4 * c + k;
@@ -878,8 +890,12 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                         float fw = sFilter[iy * filterTableSize + ix];
                         size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
                         float *dst = film + pix * 32 + bin;
+#ifndef MIPT_X_GEN_NOATOMIC
                         if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
                         else if (!zero) atomicAdd(dst, (val * 1.f) * fw);      // contribSum += L * sampleWeight * fw
+#else
+                        if (fw == 123.f) *dst = val;
+#endif
                     }
                 }
             }
@@ -944,10 +960,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         pool.R(R_RAY0, slot) = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
         pool.R(R_RAY1, slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, 1.f);   // etaScale = 1
         pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
-        for (int c = 0; c < NQ; ++c) {
-            pool.Q(Q_L + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
-            pool.Q(Q_BETA + c, slot) = make_float4(1.f, 1.f, 1.f, (c == NQ - 1) ? 0.f : 1.f);
-        }
+
         pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
         pool.I(I_SAMPLE, slot) = (int)sampleNum;
         pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
@@ -958,7 +971,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         pool.I(I_BOUNCES, slot) = 0;
-        flags = F_ALIVE;
+        flags = F_ALIVE | F_L_ZERO | F_BETA_ONE;   // L = 0, beta = 1, not stored
     }
     if (valid) pool.I(I_FLAGS, slot) = flags;
     __shared__ unsigned sAlive[5];
@@ -983,6 +996,13 @@ DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimens
 // registers). Spectra are streamed bin by bin; each of the three spectral passes
 // (light sample, MIS sample, continuation) computes its values and its black/non-black
 // decision in one sweep.
+// The path's throughput quad c (see F_BETA_ONE).
+DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
+    float4 bt = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (!betaOne) bt = pool.Q(Q_BETA + c, slot);
+    return bt;
+}
+
 // timing experiments only (results are wrong when set)
 #ifndef MIPT_X_SKIP_NEE
 #define MIPT_X_SKIP_NEE 0
@@ -1014,6 +1034,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     if (cls >= 0 && qi < count) {
         slot = pool.shadeQ[(size_t)cls * pool.n + qi];
         const int flags = pool.I(I_FLAGS, slot);
+        bool lZero = (flags & F_L_ZERO) != 0, betaWritten = false;
+        const bool betaOne = (flags & F_BETA_ONE) != 0;
         const int bounces = pool.I(I_BOUNCES, slot);
         const int prim = pool.I(I_HITPRIM, slot);
         const bool found = prim >= 0;
@@ -1028,10 +1050,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (li >= 0) {
                 const mi_light &l = s.lights[li];
                 if (l.two_sided || Dot(isect.n, -rd) > 0)
+{
 #pragma unroll 1
                     for (int c = 0; c < NQ; ++c) {
-                        const float4 bt = pool.Q(Q_BETA + c, slot);
-                        float4 L4 = pool.Q(Q_L + c, slot);
+                        const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                        float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!lZero) L4 = pool.Q(Q_L + c, slot);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
@@ -1039,6 +1063,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         }
                         pool.Q(Q_L + c, slot) = L4;
                     }
+                    lZero = false;
+                }
             }
         }
         if (!found || bounces >= s.maxDepth) finished = true;
@@ -1085,7 +1111,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             bool fNonBlack = false, liNonBlack = false;
 #pragma unroll 1
                             for (int c = 0; c < NQ; ++c) {
-                                const float4 bt = pool.Q(Q_BETA + c, slot);
+                                const float4 bt = LoadBeta(pool, c, slot, betaOne);
                                 float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
@@ -1129,7 +1155,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 bool fNonBlack = false;
 #pragma unroll 1
                                 for (int c = 0; c < NQ; ++c) {
-                                    const float4 bt = pool.Q(Q_BETA + c, slot);
+                                    const float4 bt = LoadBeta(pool, c, slot, betaOne);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
@@ -1176,7 +1202,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     float maxRR = 0;
 #pragma unroll 1
                     for (int c = 0; c < NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
-                        float4 bt = pool.Q(Q_BETA + c, slot);
+                        float4 bt = LoadBeta(pool, c, slot, betaOne);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
@@ -1191,6 +1217,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         }
                         pool.Q(Q_BETA + c, slot) = bt;
                     }
+                    betaWritten = true;
                     if (fNonBlack) {
                         Ray nr = SpawnRay(isect, wi);
                         // Russian roulette, path.cpp:176-184
@@ -1231,6 +1258,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 newFlags |= F_ALIVE;
                 pool.I(I_BOUNCES, slot) = bounces + 1;
             }
+            if (lZero) newFlags |= F_L_ZERO;
+            if (betaOne && !betaWritten) newFlags |= F_BETA_ONE;
             wantShadow = (newFlags & F_SHADOW) != 0;
             wantMis = (newFlags & F_MIS) != 0;
             // a direct-lighting estimate with neither ray pending is already known to be black
