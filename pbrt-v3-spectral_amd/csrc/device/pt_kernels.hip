@@ -1153,8 +1153,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 }
                                 const Divisor spDiv = MakeDivisor(sPdf);
                                 bool fNonBlack = false;
+                                // (when the light's pdf for wi is 0 the estimate ends here, integrator.cpp:186-187:
+                                // nothing reads the spectrum then, so it is not formed)
 #pragma unroll 1
-                                for (int c = 0; c < NQ; ++c) {
+                                for (int c = 0; go && c < NQ; ++c) {
                                     const float4 bt = LoadBeta(pool, c, slot, betaOne);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
