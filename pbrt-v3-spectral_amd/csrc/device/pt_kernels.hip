@@ -890,12 +890,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                         float fw = sFilter[iy * filterTableSize + ix];
                         size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
                         float *dst = film + pix * 32 + bin;
-#ifndef MIPT_X_GEN_NOATOMIC
                         if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
                         else if (!zero) atomicAdd(dst, (val * 1.f) * fw);      // contribSum += L * sampleWeight * fw
-#else
-                        if (fw == 123.f) *dst = val;
-#endif
                     }
                 }
             }
@@ -1003,16 +999,6 @@ DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
     return bt;
 }
 
-// timing experiments only (results are wrong when set)
-#ifndef MIPT_X_SKIP_NEE
-#define MIPT_X_SKIP_NEE 0
-#endif
-#ifndef MIPT_X_SKIP_MIS
-#define MIPT_X_SKIP_MIS 0
-#endif
-#ifndef MIPT_X_SKIP_DIRECT
-#define MIPT_X_SKIP_DIRECT 0
-#endif
 #ifndef MIPT_SHADE_WAVES_PER_EU
 #define MIPT_SHADE_WAVES_PER_EU 4
 #endif
@@ -1083,7 +1069,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             int dim = pool.I(I_DIM, slot);
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
             // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
-            if (NumComponents(mat, nonSpec) > 0 && !MIPT_X_SKIP_DIRECT) {
+            if (NumComponents(mat, nonSpec) > 0) {
                 ++totalPaths;
                 newFlags |= F_NEE;
                 if (s.nLights > 0) {
@@ -1099,7 +1085,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         const Divisor selDiv = MakeDivisor(selPdf);
                         const LightSample ls = SampleLi(s, light, isect, uL0, uL1);
                         const float lightPdf = ls.pdf;
-                        if (lightPdf > 0 && !ls.black && !MIPT_X_SKIP_NEE) {
+                        if (lightPdf > 0 && !ls.black) {
                             BSDFEvalT<NL> ev;
                             BSDF_f<NL>(fr, isect.wo, ls.wi, nonSpec, &ev);
                             const float absdot = AbsDot(ls.wi, isect.shN);
@@ -1135,7 +1121,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 newFlags |= F_SHADOW;
                             }
                         }
-                        if (!IsDeltaLight(light) && !MIPT_X_SKIP_MIS) {  // BSDF sampling with MIS, integrator.cpp:167-213
+                        if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
                             V3 wi;
                             float sPdf = 0;
                             int sampledType = 0;
