@@ -115,6 +115,8 @@ struct Pool {
     float4 *r;   // record planes
     int *i;
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
+    uint32_t *extQ;            // this iteration's path rays: new camera rays from the front (coherent: consecutive
+                               // samples of a pixel), continuing paths from the back
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
@@ -142,10 +144,11 @@ struct DevCounters {
     // cleared together every iteration:
     DevCursor alive;                    // slots alive after generate
     DevCursor shadowCount, misCount;    // entries in Pool::shadowQ / misQ
+    DevCursor primCount, contCount;     // entries at the front / back of Pool::extQ
     DevCursor shadeCount[MAX_CLASSES];  // entries in shading queue c
     DevCursor travNext[3];              // work cursors of the persistent traversal kernels (extend/shadow/mis)
 };
-constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (3 + MAX_CLASSES + 3);
+constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (5 + MAX_CLASSES + 3);
 DEV DevStats &Stats(DevCounters *ctr) { return ctr->stats[blockIdx.x & (STAT_STRIPES - 1)]; }
 
 struct WorkDesc {
@@ -414,7 +417,7 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 #define MIPT_TRAV_BLOCKS_PER_CU 4
 #endif
 #ifndef MIPT_REFILL_BELOW
-#define MIPT_REFILL_BELOW 24
+#define MIPT_REFILL_BELOW 32
 #endif
 constexpr int TRAV_BLOCKS_PER_CU = MIPT_TRAV_BLOCKS_PER_CU;
 constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
@@ -435,8 +438,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     constexpr bool ANY = (MODE == 1);
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
-    const unsigned total = (MODE == 0) ? pool.n : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
-    const uint32_t *__restrict__ queue = (MODE == 1) ? pool.shadowQ : pool.misQ;
+    const unsigned nPrim = (MODE == 0) ? ctr->primCount.v : 0, nCont = (MODE == 0) ? ctr->contCount.v : 0;
+    const unsigned total = (MODE == 0) ? nPrim + nCont : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
+    const uint32_t *__restrict__ queue = (MODE == 0) ? pool.extQ : ((MODE == 1) ? pool.shadowQ : pool.misQ);
     const float4 *__restrict__ primTri = s.primTri;
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
     bool has = false;
@@ -472,10 +476,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (!has) {
                     const unsigned my = first + __popcll(idle & ((1ull << wlane) - 1));
                     if (my < chunkEnd) {
-                        bool take = true;
-                        if (MODE == 0) { slot = my; take = (pool.I(I_FLAGS, slot) & F_ALIVE) != 0; }
+                        if (MODE == 0) slot = queue[(my < nPrim) ? my : pool.n - nCont + (my - nPrim)];
                         else slot = queue[my];
-                        if (take) {
+                        {
                             const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
                             const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
                             if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
@@ -970,8 +973,14 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         flags = F_ALIVE | F_L_ZERO | F_BETA_ONE;   // L = 0, beta = 1, not stored
     }
     if (valid) pool.I(I_FLAGS, slot) = flags;
-    __shared__ unsigned sAlive[5];
+    __shared__ unsigned sAlive[5], sPrim[5], sCont[5];
     BlockReserve(&ctr->alive.v, valid && (flags & F_ALIVE), sAlive);
+    // the extend work list: new camera rays first (lanes of a traversal wave then hold neighbouring samples)
+    const bool isPrim = valid && got, isCont = valid && (flags & F_ALIVE) && !got;
+    const unsigned posP = BlockReserve(&ctr->primCount.v, isPrim, sPrim);
+    const unsigned posC = BlockReserve(&ctr->contCount.v, isCont, sCont);
+    if (isPrim) pool.extQ[posP] = slot;
+    if (isCont) pool.extQ[pool.n - 1 - posC] = slot;
     CountAdd(&Stats(ctr).cameraRays, cam);
     CountAdd(&Stats(ctr).badSamples, bad);
 }
@@ -1396,14 +1405,15 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     Pool &p = sub.pool;
     if (p.n == n && p.f) return MI_OK;
     if (p.f) {
-        hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.misQ); hipFree(p.shadeQ);
-        p.f = nullptr; p.q = nullptr; p.r = nullptr; p.i = nullptr; p.shadowQ = p.misQ = nullptr; p.shadeQ = nullptr;
+        hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ);
+        p.f = nullptr; p.q = nullptr; p.r = nullptr; p.i = nullptr; p.shadowQ = p.misQ = p.extQ = nullptr; p.shadeQ = nullptr;
     }
     HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
     HIPCHK(hipMalloc((void **)&p.q, (size_t)nQuadPlanes * n * sizeof(float4)));
     HIPCHK(hipMalloc((void **)&p.r, (size_t)R_COUNT * n * sizeof(float4)));
     HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
     HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&p.extQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&p.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)));
     p.n = n;
@@ -1874,6 +1884,7 @@ void mi_pt_destroy(mi_pt *pt) {
         if (p.r) hipFree(p.r);
         if (p.i) hipFree(p.i);
         if (p.shadowQ) hipFree(p.shadowQ);
+        if (p.extQ) hipFree(p.extQ);
         if (p.misQ) hipFree(p.misQ);
         if (p.shadeQ) hipFree(p.shadeQ);
         if (sub.ctr) hipFree(sub.ctr);

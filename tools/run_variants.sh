@@ -3,7 +3,7 @@
 for f in build_variants/lib_*.so; do
   n=$(basename $f .so)
   MIPT_HIP_LIB=$PWD/$f MIPT_STREAMS=1 timeout -k 10 200 python bench.py --steps 1 --warmup 1 --spp 256 --pool 8388608 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v1.json 2> gpurun_out/v1.err
-  if [ -z "$ONLY_K1" ]; then MIPT_HIP_LIB=$PWD/$f timeout -k 10 200 python bench.py --steps 1 --warmup 1 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v4.json 2> gpurun_out/v4.err; else rm -f gpurun_out/v4.json; fi
+  if [ -z "$ONLY_K1" ]; then MIPT_HIP_LIB=$PWD/$f timeout -k 10 200 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v4.json 2> gpurun_out/v4.err; else rm -f gpurun_out/v4.json; fi
   python - <<PY
 import json
 out=["$n"]
