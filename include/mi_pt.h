@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -136,7 +136,8 @@ typedef struct mi_material {
 typedef enum mi_light_type {
     MI_LIGHT_DIFFUSE_AREA = 0, /* src/lights/diffuse.cpp */
     MI_LIGHT_POINT,            /* src/lights/point.cpp */
-    MI_LIGHT_DISTANT           /* src/lights/distant.cpp */
+    MI_LIGHT_DISTANT,          /* src/lights/distant.cpp */
+    MI_LIGHT_INFINITE          /* src/lights/infinite.cpp (environment light; mi_envmap) */
 } mi_light_type;
 
 typedef struct mi_light {
@@ -144,12 +145,30 @@ typedef struct mi_light {
     int32_t shape;     /* area: >=0 triangle index, <0 ~sphere index */
     int32_t two_sided;
     float area;        /* Shape::Area() */
-    float L[MI_NSPEC]; /* Lemit / I / L */
+    float L[MI_NSPEC]; /* Lemit / I / L; infinite: Spectrum(Lmap->Lookup((.5,.5), .5), Illuminant), i.e. Power() / (pi r^2) */
     float pos[3];      /* point: pLight */
     float dir[3];      /* distant: wLight (normalised, world) */
     float world_radius;
     float world_center[3];
+    int32_t envmap;    /* infinite: index into mi_scene_desc.envmaps */
+    float l2w[9], w2l[9]; /* infinite: rotation part of LightToWorld / WorldToLight, row major */
 } mi_light;
+
+/* InfiniteAreaLight::Lmap (level 0 of the MIPMap<RGBSpectrum>, after the reference's power-of-two resampling)
+ * and its sampling distribution (src/lights/infinite.cpp:43-83, src/core/sampling.h:123-147). The light looks
+ * the map up with width 0 (bilinear on level 0, mipmap.h:271-281) and converts the RGB value to a spectrum per
+ * lookup (Spectrum(rgb, SpectrumType::Illuminant), spectrum.cpp:98-180 with rgb_illum below). */
+typedef struct mi_envmap {
+    int32_t width, height;     /* Lmap->Width(), Height() */
+    const float *rgb;          /* [height * width * 3] */
+    int32_t nu, nv;            /* Distribution2D: nu = 2 * width, nv = 2 * height */
+    const float *cond_func;    /* [nv * nu]       pConditionalV[v]->func */
+    const float *cond_cdf;     /* [nv * (nu + 1)] pConditionalV[v]->cdf */
+    const float *cond_func_int;/* [nv]            pConditionalV[v]->funcInt */
+    const float *marg_func;    /* [nv]            pMarginal->func (= cond_func_int) */
+    const float *marg_cdf;     /* [nv + 1] */
+    float marg_func_int;
+} mi_envmap;
 
 /* Light-selection pmf (src/core/lightdistrib.cpp). For UNIFORM / POWER the host
  * supplies one Distribution1D (func[n_lights], cdf[n_lights+1], func_int[1]). For
@@ -229,6 +248,8 @@ typedef struct mi_scene_desc {
     mi_sampler sampler;
     mi_integrator integrator;
     float cie_y[MI_NSPEC]; /* SampledSpectrum::Y, for y() guards */
+    uint32_t n_envmaps; const mi_envmap *envmaps;
+    float rgb_illum[7][MI_NSPEC]; /* rgbIllum2Spect{White,Cyan,Magenta,Yellow,Red,Green,Blue} (spectrum.h:322-398) */
 } mi_scene_desc;
 
 /* Counters with the reference's STAT names (src/core/integrator.cpp:48,

@@ -20,6 +20,7 @@ static constexpr Float MachineEpsilon = std::numeric_limits<Float>::epsilon() * 
 static constexpr Float ShadowEpsilon = 0.0001f;
 static constexpr Float Pi = 3.14159265358979323846;
 static constexpr Float InvPi = 0.31830988618379067154;
+static constexpr Float Inv2Pi = 0.15915494309189533577;  // pbrt.h:210
 static constexpr Float Inv4Pi = 0.07957747154594766788;
 static constexpr Float PiOver2 = 1.57079632679489661923;
 static constexpr Float PiOver4 = 0.78539816339744830961;

@@ -313,6 +313,79 @@ static Float ShapePdf(const mi_scene_desc &d, int shape, Float area, const Inter
 
 static bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT; }
 
+// ---- InfiniteAreaLight, src/lights/infinite.cpp:85-144
+// Lmap->Lookup(st) with width 0: level < 0 -> triangle(0, st), bilinear with ImageWrap::Repeat (mipmap.h:252-281)
+static void EnvLookup(const mi_envmap &e, const Float st[2], Float rgb[3]) {
+    Float s = st[0] * e.width - 0.5f;
+    Float t = st[1] * e.height - 0.5f;
+    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    Float ds = s - s0, dt = t - t0;
+    auto texel = [&](int ss, int tt, int k) { return e.rgb[3 * ((size_t)Mod(tt, e.height) * e.width + Mod(ss, e.width)) + k]; };
+    for (int k = 0; k < 3; ++k)
+        rgb[k] = (1 - ds) * (1 - dt) * texel(s0, t0, k) + (1 - ds) * dt * texel(s0, t0 + 1, k) + ds * (1 - dt) * texel(s0 + 1, t0, k) +
+                 ds * dt * texel(s0 + 1, t0 + 1, k);
+}
+// Spectrum(rgb, SpectrumType::Illuminant): SampledSpectrum::FromRGB, spectrum.cpp:98-180
+static Spec SpecFromRGBIllum(const mi_scene_desc &d, const Float rgb[3]) {
+    const Spec white = Spec::From(d.rgb_illum[0]), cyan = Spec::From(d.rgb_illum[1]), magenta = Spec::From(d.rgb_illum[2]),
+               yellow = Spec::From(d.rgb_illum[3]), red = Spec::From(d.rgb_illum[4]), green = Spec::From(d.rgb_illum[5]),
+               blue = Spec::From(d.rgb_illum[6]);
+    Spec r;
+    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
+        r += rgb[0] * white;
+        if (rgb[1] <= rgb[2]) { r += (rgb[1] - rgb[0]) * cyan; r += (rgb[2] - rgb[1]) * blue; }
+        else { r += (rgb[2] - rgb[0]) * cyan; r += (rgb[1] - rgb[2]) * green; }
+    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
+        r += rgb[1] * white;
+        if (rgb[0] <= rgb[2]) { r += (rgb[0] - rgb[1]) * magenta; r += (rgb[2] - rgb[0]) * blue; }
+        else { r += (rgb[2] - rgb[1]) * magenta; r += (rgb[0] - rgb[2]) * red; }
+    } else {
+        r += rgb[2] * white;
+        if (rgb[0] <= rgb[1]) { r += (rgb[0] - rgb[2]) * yellow; r += (rgb[1] - rgb[0]) * green; }
+        else { r += (rgb[1] - rgb[2]) * yellow; r += (rgb[0] - rgb[1]) * red; }
+    }
+    r *= .86445f;
+    for (int i = 0; i < NS; ++i) r.c[i] = Clamp(r.c[i], 0, Infinity);
+    return r;
+}
+static V3 Mul3(const float m[9], const V3 &v) {  // Transform::operator()(Vector3f), transform.h:235-240
+    return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+static Float SphericalTheta(const V3 &v) { return std::acos(Clamp(v.z, -1, 1)); }
+static Float SphericalPhi(const V3 &v) { Float p = std::atan2(v.y, v.x); return (p < 0) ? (p + 2 * Pi) : p; }
+static Spec InfiniteLe(const mi_scene_desc &d, const mi_light &l, const V3 &dir) {  // infinite.cpp:91-95
+    V3 w = Normalize(Mul3(l.w2l, dir));
+    Float st[2] = {SphericalPhi(w) * Inv2Pi, SphericalTheta(w) * InvPi}, rgb[3];
+    EnvLookup(d.envmaps[l.envmap], st, rgb);
+    return SpecFromRGBIllum(d, rgb);
+}
+// Distribution1D::SampleContinuous over tabulated func/cdf, sampling.h:71-89
+static Float SampleContinuous1D(const float *func, const float *cdf, Float funcInt, int n, Float u, Float *pdf, int *off) {
+    int size = n + 1, first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = Clamp(first - 1, 0, size - 2);
+    if (off) *off = offset;
+    Float du = u - cdf[offset];
+    if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    if (pdf) *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / n;
+}
+static Float InfinitePdfLi(const mi_scene_desc &d, const mi_light &l, const V3 &w) {  // infinite.cpp:133-141
+    const mi_envmap &e = d.envmaps[l.envmap];
+    V3 wi = Mul3(l.w2l, w);
+    Float theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+    Float sinTheta = std::sin(theta);
+    if (sinTheta == 0) return 0;
+    Float p[2] = {phi * Inv2Pi, theta * InvPi};
+    int iu = Clamp(int(p[0] * e.nu), 0, e.nu - 1);   // Distribution2D::Pdf, sampling.h:137-143
+    int iv = Clamp(int(p[1] * e.nv), 0, e.nv - 1);
+    return e.cond_func[(size_t)iv * e.nu + iu] / e.marg_func_int / (2 * Pi * Pi * sinTheta);
+}
+
 static LightSample SampleLi(const mi_scene_desc &d, const mi_light &l, const Interaction &ref, const Float u[2]) {
     LightSample ls;
     if (l.type == MI_LIGHT_DIFFUSE_AREA) {  // diffuse.cpp:68-81
@@ -332,6 +405,28 @@ static LightSample SampleLi(const mi_scene_desc &d, const mi_light &l, const Int
         ls.pLight = Interaction();
         ls.pLight.p = pLight;
         ls.Li = Spec::From(l.L) / DistanceSquared(pLight, ref.p);
+    } else if (l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
+        const mi_envmap &e = d.envmaps[l.envmap];
+        ls.pdf = 0;
+        ls.Li = Spec(0.f);
+        ls.pLight = Interaction();
+        Float pdfs[2];
+        int v;
+        Float d1 = SampleContinuous1D(e.marg_func, e.marg_cdf, e.marg_func_int, e.nv, u[1], &pdfs[1], &v);
+        Float d0 = SampleContinuous1D(e.cond_func + (size_t)v * e.nu, e.cond_cdf + (size_t)v * (e.nu + 1), e.cond_func_int[v], e.nu, u[0],
+                                      &pdfs[0], nullptr);
+        Float mapPdf = pdfs[0] * pdfs[1];
+        if (mapPdf == 0) return ls;
+        Float theta = d1 * Pi, phi = d0 * 2 * Pi;
+        Float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
+        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+        ls.wi = Mul3(l.l2w, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+        ls.pdf = mapPdf / (2 * Pi * Pi * sinTheta);
+        if (sinTheta == 0) ls.pdf = 0;
+        ls.pLight.p = ref.p + ls.wi * (2 * l.world_radius);
+        Float uv[2] = {d0, d1}, rgb[3];
+        EnvLookup(e, uv, rgb);
+        ls.Li = SpecFromRGBIllum(d, rgb);
     } else {  // distant.cpp:49-59
         V3 wLight(l.dir[0], l.dir[1], l.dir[2]);
         ls.wi = wLight;
@@ -491,7 +586,8 @@ static Spec EstimateDirect(const Scene &scene, const SurfaceInteraction &it, con
         if (!f.IsBlack() && scatteringPdf > 0) {
             Float weight = 1;
             if (!sampledSpecular) {
-                lightPdf = ShapePdf(d, light.shape, light.area, it, wi);  // DiffuseAreaLight::Pdf_Li
+                lightPdf = (light.type == MI_LIGHT_INFINITE) ? InfinitePdfLi(d, light, wi)
+                                                             : ShapePdf(d, light.shape, light.area, it, wi);  // DiffuseAreaLight::Pdf_Li
                 if (lightPdf == 0) return Ld;
                 weight = PowerHeuristic(1, scatteringPdf, 1, lightPdf);
             }
@@ -501,7 +597,7 @@ static Spec EstimateDirect(const Scene &scene, const SurfaceInteraction &it, con
             Spec Li2(0.f);
             if (found) {
                 if (d.prims[lightIsect.prim].area_light == lightNum) Li2 = PrimLe(d, lightIsect, -wi);
-            }  // else light.Le(ray) == 0 for every light type on this path (light.cpp:86)
+            } else if (light.type == MI_LIGHT_INFINITE) Li2 = InfiniteLe(d, light, ray.d);   // light.Le(ray); 0 for the other types (light.cpp:86)
             if (!Li2.IsBlack()) Ld += f * Li2 * weight / scatteringPdf;
         }
     }
@@ -523,7 +619,9 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
         bool foundIntersection = scene.Intersect(ray, &isect, c);
         if (bounces == 0 || specularBounce) {
             if (foundIntersection) L += beta * PrimLe(d, isect, -ray.d);
-            // no infinite lights on this path
+            else
+                for (uint32_t i = 0; i < d.n_lights; ++i)   // scene.infiniteLights, path.cpp:96-99
+                    if (d.lights[i].type == MI_LIGHT_INFINITE) L += beta * InfiniteLe(d, d.lights[i], ray.d);
         }
         if (!foundIntersection || bounces >= maxDepth) break;
         int matIdx = d.prims[isect.prim].material;

@@ -57,7 +57,14 @@ class Material(C.Structure):
 class Light(C.Structure):
     _fields_ = [("type", C.c_int32), ("shape", C.c_int32), ("two_sided", C.c_int32), ("area", C.c_float),
                 ("L", C.c_float * NSPEC), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
-                ("world_radius", C.c_float), ("world_center", C.c_float * 3)]
+                ("world_radius", C.c_float), ("world_center", C.c_float * 3), ("envmap", C.c_int32),
+                ("l2w", C.c_float * 9), ("w2l", C.c_float * 9)]
+
+
+class EnvMap(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.POINTER(C.c_float)), ("nu", C.c_int32), ("nv", C.c_int32),
+                ("cond_func", C.POINTER(C.c_float)), ("cond_cdf", C.POINTER(C.c_float)), ("cond_func_int", C.POINTER(C.c_float)),
+                ("marg_func", C.POINTER(C.c_float)), ("marg_cdf", C.POINTER(C.c_float)), ("marg_func_int", C.c_float)]
 
 
 class LightDistrib(C.Structure):
@@ -101,7 +108,8 @@ class SceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
                 ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
                 ("light_distrib", LightDistrib), ("camera", Camera), ("film", Film), ("sampler", Sampler),
-                ("integrator", Integrator), ("cie_y", C.c_float * NSPEC)]
+                ("integrator", Integrator), ("cie_y", C.c_float * NSPEC),
+                ("n_envmaps", C.c_uint32), ("envmaps", C.POINTER(EnvMap)), ("rgb_illum", (C.c_float * NSPEC) * 7)]
 
 
 class Counters(C.Structure):

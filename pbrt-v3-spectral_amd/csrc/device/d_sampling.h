@@ -156,23 +156,130 @@ DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &re
 
 DEV bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT; }
 
+// ---- InfiniteAreaLight (src/lights/infinite.cpp:85-141)
+// Spectrum(rgb, SpectrumType::Illuminant) (SampledSpectrum::FromRGB, spectrum.cpp:98-180) reduced to scalars:
+// bin value = Clamp(((0 + white*w0) + basis[i1]*w1) + basis[i2]*w2) * .86445f, 0, inf).
+struct IllumRGB {
+    int i1, i2;
+    float w0, w1, w2;
+};
+DEV IllumRGB MakeIllumRGB(const float rgb[3]) {
+    IllumRGB q;
+    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
+        q.w0 = rgb[0];
+        if (rgb[1] <= rgb[2]) { q.i1 = 1; q.w1 = rgb[1] - rgb[0]; q.i2 = 6; q.w2 = rgb[2] - rgb[1]; }
+        else { q.i1 = 1; q.w1 = rgb[2] - rgb[0]; q.i2 = 5; q.w2 = rgb[1] - rgb[2]; }
+    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
+        q.w0 = rgb[1];
+        if (rgb[0] <= rgb[2]) { q.i1 = 2; q.w1 = rgb[0] - rgb[1]; q.i2 = 6; q.w2 = rgb[2] - rgb[0]; }
+        else { q.i1 = 2; q.w1 = rgb[2] - rgb[1]; q.i2 = 4; q.w2 = rgb[0] - rgb[2]; }
+    } else {
+        q.w0 = rgb[2];
+        if (rgb[0] <= rgb[1]) { q.i1 = 3; q.w1 = rgb[0] - rgb[2]; q.i2 = 5; q.w2 = rgb[1] - rgb[0]; }
+        else { q.i1 = 3; q.w1 = rgb[1] - rgb[2]; q.i2 = 4; q.w2 = rgb[0] - rgb[1]; }
+    }
+    return q;
+}
+DEV float IllumBin(const DScene &s, const IllumRGB &q, int bin) {
+    float r = 0.f;
+    r += s.rgbIllum[bin] * q.w0;
+    r += s.rgbIllum[q.i1 * MI_NSPEC + bin] * q.w1;
+    r += s.rgbIllum[q.i2 * MI_NSPEC + bin] * q.w2;
+    r *= .86445f;
+    return clampf(r, 0.f, kInfinity);
+}
+// Lmap->Lookup(st), width 0: bilinear on level 0 with ImageWrap::Repeat (mipmap.h:252-281)
+DEV void EnvLookup(const mi_envmap &e, float s0f, float t0f, float rgb[3]) {
+    float sx = s0f * e.width - 0.5f;
+    float ty = t0f * e.height - 0.5f;
+    int s0 = (int)floorf(sx), t0 = (int)floorf(ty);
+    float ds = sx - s0, dt = ty - t0;
+    const int sA = ModI(s0, e.width), sB = ModI(s0 + 1, e.width), tA = ModI(t0, e.height), tB = ModI(t0 + 1, e.height);
+    const float *p00 = &e.rgb[3 * ((size_t)tA * e.width + sA)], *p01 = &e.rgb[3 * ((size_t)tB * e.width + sA)];
+    const float *p10 = &e.rgb[3 * ((size_t)tA * e.width + sB)], *p11 = &e.rgb[3 * ((size_t)tB * e.width + sB)];
+    for (int k = 0; k < 3; ++k)
+        rgb[k] = (1 - ds) * (1 - dt) * p00[k] + (1 - ds) * dt * p01[k] + ds * (1 - dt) * p10[k] + ds * dt * p11[k];
+}
+DEV V3 Mul3(const float m[9], const V3 &v) {
+    return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+DEV float SphericalTheta(const V3 &v) { return acosF(clampf(v.z, -1, 1)); }
+DEV float SphericalPhi(const V3 &v) { float p = atan2F(v.y, v.x); return (p < 0) ? (p + 2 * kPi) : p; }
+constexpr float kInv2Pi = 0.15915494309189533577f;
+DEV IllumRGB InfiniteLe(const DScene &s, const mi_light &l, const V3 &dir) {  // infinite.cpp:91-95
+    V3 w = Normalize(Mul3(l.w2l, dir));
+    float rgb[3];
+    EnvLookup(s.envmaps[l.envmap], SphericalPhi(w) * kInv2Pi, SphericalTheta(w) * kInvPi, rgb);
+    return MakeIllumRGB(rgb);
+}
+DEV float SampleContinuous1D(const float *func, const float *cdf, float funcInt, int n, float u, float *pdf, int *off) {
+    int size = n + 1, first = 0, len = size;   // sampling.h:71-89
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    if (off) *off = offset;
+    float du = u - cdf[offset];
+    if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    if (pdf) *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / n;
+}
+DEV float InfinitePdfLi(const DScene &s, const mi_light &l, const V3 &w) {  // infinite.cpp:133-141, sampling.h:137-143
+    const mi_envmap &e = s.envmaps[l.envmap];
+    V3 wi = Mul3(l.w2l, w);
+    float theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+    float sinTheta = sinF(theta);
+    if (sinTheta == 0) return 0;
+    int iu = (int)(phi * kInv2Pi * e.nu), iv = (int)(theta * kInvPi * e.nv);
+    iu = iu < 0 ? 0 : (iu > e.nu - 1 ? e.nu - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > e.nv - 1 ? e.nv - 1 : iv);
+    return e.cond_func[(size_t)iv * e.nu + iu] / e.marg_func_int / (2 * kPi * kPi * sinTheta);
+}
+
 struct LightSample {
     V3 wi;
     float pdf;
     bool black;      // Li == 0 (back-facing area light)
     float liScale;   // Li[bin] = L[bin] * liScale (point light: I / d^2 is a true division, flag below)
     bool divide;     // Li[bin] = L[bin] / liScale
+    bool isEnv;      // infinite light: Li[bin] = IllumBin(env, bin)
+    IllumRGB env;
     Interaction pLight;
 };
 DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &ref, float u0, float u1) {
     LightSample ls;
-    ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.divide = false;
+    ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.divide = false; ls.isEnv = false;
+    ls.env.i1 = ls.env.i2 = 0; ls.env.w0 = ls.env.w1 = ls.env.w2 = 0;
     if (l.type == MI_LIGHT_DIFFUSE_AREA) {
         Interaction pShape = ShapeSample(s, l.shape, ref, u0, u1, &ls.pdf);
         if (ls.pdf == 0 || (pShape.p - ref.p).LengthSquared() == 0) { ls.pdf = 0; return ls; }
         ls.wi = Normalize(pShape.p - ref.p);
         ls.pLight = pShape;
         ls.black = !(l.two_sided || Dot(pShape.n, -ls.wi) > 0);
+    } else if (l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
+        const mi_envmap &e = s.envmaps[l.envmap];
+        float pdfs[2];
+        int v;
+        const float d1 = SampleContinuous1D(e.marg_func, e.marg_cdf, e.marg_func_int, e.nv, u1, &pdfs[1], &v);
+        const float d0 = SampleContinuous1D(e.cond_func + (size_t)v * e.nu, e.cond_cdf + (size_t)v * (e.nu + 1), e.cond_func_int[v],
+                                            e.nu, u0, &pdfs[0], nullptr);
+        const float mapPdf = pdfs[0] * pdfs[1];
+        if (mapPdf == 0) return ls;
+        const float theta = d1 * kPi, phi = d0 * 2 * kPi;
+        const float cosTheta = cosF(theta), sinTheta = sinF(theta);
+        const float sinPhi = sinF(phi), cosPhi = cosF(phi);
+        ls.wi = Mul3(l.l2w, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+        ls.pdf = mapPdf / (2 * kPi * kPi * sinTheta);
+        if (sinTheta == 0) ls.pdf = 0;
+        ls.pLight.p = ref.p + ls.wi * (2 * l.world_radius);
+        float rgb[3];
+        EnvLookup(e, d0, d1, rgb);
+        ls.env = MakeIllumRGB(rgb);
+        ls.isEnv = true;
+        ls.black = false;   // (a black map value shows up bin by bin: the caller tests Li != 0)
     } else if (l.type == MI_LIGHT_POINT) {
         V3 pLight(l.pos[0], l.pos[1], l.pos[2]);
         ls.wi = Normalize(pLight - ref.p);
@@ -190,7 +297,10 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
     }
     return ls;
 }
-DEV float LiBin(const mi_light &l, const LightSample &ls, int bin) { return ls.divide ? l.L[bin] / ls.liScale : l.L[bin]; }
+DEV float LiBin(const DScene &s, const mi_light &l, const LightSample &ls, int bin) {
+    if (ls.isEnv) return IllumBin(s, ls.env, bin);
+    return ls.divide ? l.L[bin] / ls.liScale : l.L[bin];
+}
 
 // ------------------------------------------------------------------ Distribution1D
 DEV int SampleDiscrete(const float *func, const float *cdf, float funcInt, int n, float u, float *pdf) {

@@ -50,6 +50,10 @@ struct DScene {
     const uint32_t *pixelOffsetTable;  // 128x128 Halton per-pixel index offsets (halton.cpp:98-118)
     const float *filterTable;  // 256 floats
     float cieY[MI_NSPEC];
+    const mi_envmap *envmaps;      // device copies: the pointers inside point to device memory
+    const float *rgbIllum;         // [7][31] rgbIllum2Spect White, Cyan, Magenta, Yellow, Red, Green, Blue
+    int infiniteLights[4];         // indices of the MI_LIGHT_INFINITE lights (scene.infiniteLights), -1 = none
+    int nInfiniteLights;
     mi_camera camera;
     // film
     int croppedBounds[4], sampleBounds[4], pixelBounds[4];

@@ -718,6 +718,18 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
         bool found = h.prim >= 0;
         if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris);
         bool added = false;
+        if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
+            const bool lZero = (flags & F_L_ZERO) != 0;
+            for (int c = 0; c < NQ; ++c) {
+                const float4 a = pool.Q(Q_LMIS + c, slot);
+                added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+                float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!lZero) l = pool.Q(Q_L + c, slot);
+                l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+                pool.Q(Q_L + c, slot) = l;
+            }
+            flags &= ~F_L_ZERO;
+        }
         if (found) {
             const int lightNum = pool.I(I_MISLIGHT, slot);
             if (s.prims[h.prim].area_light == lightNum) {
@@ -1062,6 +1074,24 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 }
             }
         }
+        if ((bounces == 0 || (flags & F_SPECULAR)) && !found) {  // escaped: scene.infiniteLights, path.cpp:96-99
+            for (int il = 0; il < s.nInfiniteLights; ++il) {
+                const IllumRGB le = InfiniteLe(s, s.lights[s.infiniteLights[il]], rd);
+#pragma unroll 1
+                for (int c = 0; c < NQ; ++c) {
+                    const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                    float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!lZero) L4 = pool.Q(Q_L + c, slot);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int b = 4 * c + k;
+                        if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * IllumBin(s, le, b));
+                    }
+                    pool.Q(Q_L + c, slot) = L4;
+                }
+                lZero = false;
+            }
+        }
         if (!found || bounces >= s.maxDepth) finished = true;
         int newFlags = 0;
         if (!finished && s.prims[prim].material < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
@@ -1113,7 +1143,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     const int b = 4 * c + k;
                                     if (b < MI_NSPEC) {
                                         const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
-                                        const float Li = LiBin(light, ls, b);
+                                        const float Li = LiBin(s, light, ls, b);
                                         fNonBlack |= (f != 0.f);
                                         liNonBlack |= (Li != 0.f);
                                         float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
@@ -1142,10 +1172,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 float weight = 1;
                                 bool go = true;
                                 if (!(sampledType & MI_BSDF_SPECULAR)) {
-                                    const float lp = ShapePdf(s, light.shape, light.area, isect, wi);
+                                    const float lp = (light.type == MI_LIGHT_INFINITE) ? InfinitePdfLi(s, light, wi)
+                                                                                       : ShapePdf(s, light.shape, light.area, isect, wi);
                                     if (lp == 0) go = false;
                                     else { float pf = 1 * sPdf, pg = 1 * lp; weight = (pf * pf) / (pf * pf + pg * pg); }
                                 }
+                                const bool isEnvLight = light.type == MI_LIGHT_INFINITE;
+                                IllumRGB envLe;
+                                envLe.i1 = envLe.i2 = 0; envLe.w0 = envLe.w1 = envLe.w2 = 0;
+                                if (isEnvLight && go) envLe = InfiniteLe(s, light, wi);   // light.Le(ray) when the ray escapes
                                 const Divisor spDiv = MakeDivisor(sPdf);
                                 bool fNonBlack = false;
                                 // (when the light's pdf for wi is 0 the estimate ends here, integrator.cpp:186-187:
@@ -1160,7 +1195,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         if (b < MI_NSPEC) {
                                             const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
                                             fNonBlack |= (f != 0.f);
-                                            float Ld = DivBy((f * light.L[b]) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
+                                            const float LiB = isEnvLight ? IllumBin(s, envLe, b) : light.L[b];   // Le of the light if the ray reaches it
+                                            float Ld = DivBy((f * LiB) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
                                             if (!selIsOne) Ld = DivBy(Ld, selDiv);
                                             Set4(out, k, Get4(bt, k) * Ld);
                                         }
@@ -1303,7 +1339,7 @@ __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcIn
             LightSample ls = SampleLi(s, l, intr, u0, u1);
             if (ls.pdf > 0) {
                 float yy = 0.f;
-                if (!ls.black) for (int b = 0; b < MI_NSPEC; ++b) yy += s.cieY[b] * LiBin(l, ls, b);
+                if (!ls.black) for (int b = 0; b < MI_NSPEC; ++b) yy += s.cieY[b] * LiBin(s, l, ls, b);
                 f[j] += YScale(yy) / ls.pdf;
             }
         }
@@ -1633,6 +1669,33 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     }
     s.nNodes = d->n_nodes; s.nPrims = d->n_prims; s.nLights = d->n_lights; s.nMaterials = d->n_materials;
     for (int i = 0; i < MI_NSPEC; ++i) s.cieY[i] = d->cie_y[i];
+    {   // environment maps of the infinite lights: tables to the device, then the records that point at them
+        std::vector<mi_envmap> envs(d->n_envmaps);
+        for (uint32_t i = 0; i < d->n_envmaps; ++i) {
+            const mi_envmap &e = d->envmaps[i];
+            if (e.width < 1 || e.height < 1 || e.nu < 1 || e.nv < 1 || !e.rgb || !e.cond_func || !e.cond_cdf || !e.cond_func_int ||
+                !e.marg_func || !e.marg_cdf) { g_err = "malformed mi_envmap"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+            mi_envmap m = e;
+            UP(e.rgb, (size_t)e.width * e.height * 3, m.rgb);
+            UP(e.cond_func, (size_t)e.nu * e.nv, m.cond_func);
+            UP(e.cond_cdf, (size_t)(e.nu + 1) * e.nv, m.cond_cdf);
+            UP(e.cond_func_int, (size_t)e.nv, m.cond_func_int);
+            UP(e.marg_func, (size_t)e.nv, m.marg_func);
+            UP(e.marg_cdf, (size_t)e.nv + 1, m.marg_cdf);
+            envs[i] = m;
+        }
+        s.envmaps = nullptr;
+        if (!envs.empty()) UP(envs.data(), envs.size(), s.envmaps);
+        UP(&d->rgb_illum[0][0], (size_t)7 * MI_NSPEC, s.rgbIllum);
+        s.nInfiniteLights = 0;
+        for (int k = 0; k < 4; ++k) s.infiniteLights[k] = -1;
+        for (uint32_t i = 0; i < d->n_lights; ++i)
+            if (d->lights[i].type == MI_LIGHT_INFINITE) {
+                if ((uint32_t)d->lights[i].envmap >= d->n_envmaps) { g_err = "infinite light without environment map"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+                if (s.nInfiniteLights == 4) { g_err = "more than 4 infinite lights"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+                s.infiniteLights[s.nInfiniteLights++] = (int)i;
+            }
+    }
     s.camera = d->camera;
     for (int i = 0; i < 4; ++i) { s.croppedBounds[i] = d->film.cropped_bounds[i]; s.sampleBounds[i] = d->film.sample_bounds[i]; s.pixelBounds[i] = d->integrator.pixel_bounds[i]; }
     s.filterRadius[0] = d->film.filter_radius[0]; s.filterRadius[1] = d->film.filter_radius[1];

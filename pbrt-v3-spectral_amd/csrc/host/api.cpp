@@ -435,6 +435,23 @@ struct Api {
             Spectrum Ls = L * sc;
             for (int i = 0; i < MI_NSPEC; ++i) l.L[i] = Ls.c[i];
             l.dir[0] = w.x; l.dir[1] = w.y; l.dir[2] = w.z;
+        } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, infinite.cpp:176-186
+            Spectrum L = ps.FindOneSpectrum("L", Spectrum(1.0));
+            Spectrum sc = ps.FindOneSpectrum("scale", Spectrum(1.0));
+            std::string texmap = ps.FindOneString("mapname", "");
+            if (!texmap.empty() && texmap[0] != '/') texmap = baseDir + "/" + texmap;   // FindOneFilename
+            (void)ps.FindOneInt("samples", ps.FindOneInt("nsamples", 1));
+            HostEnvMap env;
+            Spectrum centre;
+            std::vector<std::string> errs;
+            BuildEnvMap(L * sc, texmap, &env, &centre, &errs);
+            for (const std::string &e : errs) Err(e);
+            l.type = MI_LIGHT_INFINITE;
+            l.envmap = (int)scene->envStore.size();
+            scene->envStore.push_back(std::move(env));
+            for (int i = 0; i < MI_NSPEC; ++i) l.L[i] = centre.c[i];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) { l.l2w[3 * r + c] = ctm.m.m[r][c]; l.w2l[3 * r + c] = ctm.mInv.m[r][c]; }
         } else {
             Err("LightSource \"" + name + "\" is outside the hot-path scope (SURVEY 2 row 20); skipped.");
             return;
@@ -717,6 +734,21 @@ void Api::WorldEnd() {
     scene->stats.nMaterials = (int)scene->materials.size();
     const float *Y = Spectrum::CIE_Y();
     for (int i = 0; i < MI_NSPEC; ++i) d.cie_y[i] = Y[i];
+    for (int k = 0; k < 7; ++k) {
+        const float *basis = Spectrum::RGBIllumBasis(k);
+        for (int i = 0; i < MI_NSPEC; ++i) d.rgb_illum[k][i] = basis[i];
+    }
+    scene->envmaps.clear();
+    for (const HostEnvMap &e : scene->envStore) {
+        mi_envmap m{};
+        m.width = e.width; m.height = e.height; m.rgb = e.rgb.data();
+        m.nu = e.nu; m.nv = e.nv;
+        m.cond_func = e.condFunc.data(); m.cond_cdf = e.condCdf.data(); m.cond_func_int = e.condFuncInt.data();
+        m.marg_func = e.margFunc.data(); m.marg_cdf = e.margCdf.data(); m.marg_func_int = e.margFuncInt;
+        scene->envmaps.push_back(m);
+    }
+    d.n_envmaps = (uint32_t)scene->envmaps.size();
+    d.envmaps = scene->envmaps.empty() ? nullptr : scene->envmaps.data();
     scene->Finalize();
 }
 

@@ -17,6 +17,13 @@ struct SceneStats {
     int nLights = 0, nMaterials = 0;
 };
 
+// LightSource "infinite" (envmap.cpp)
+struct HostEnvMap {
+    int width = 0, height = 0, nu = 0, nv = 0;
+    std::vector<float> rgb, condFunc, condCdf, condFuncInt, margFunc, margCdf;
+    float margFuncInt = 0;
+};
+
 struct HostScene {
     // geometry
     std::vector<mi_bvh_node> nodes;
@@ -28,6 +35,8 @@ struct HostScene {
     std::vector<mi_sphere> spheres;
     std::vector<mi_material> materials;
     std::vector<mi_light> lights;
+    std::vector<HostEnvMap> envStore;   // storage behind desc.envmaps
+    std::vector<mi_envmap> envmaps;
     // light distribution
     std::vector<float> ldFunc, ldCdf, ldFuncInt;
     // sampler tables
@@ -76,6 +85,7 @@ struct PLYMeshData {
 };
 bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std::string> *warnings, std::string *err);
 
+bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store, Spectrum *centre, std::vector<std::string> *errors);
 bool WriteRGBImage(const std::string &filename, int w, int h, const float *filmSum, const float *weightSum, float scale,
                    std::string *written, std::string *err);
 bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spectrum &amount, mi_material *out,

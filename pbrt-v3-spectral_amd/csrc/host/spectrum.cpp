@@ -17,6 +17,11 @@ inline void XYZToRGB(const float xyz[3], float rgb[3]) {  // spectrum.h:56-60
 }  // namespace
 
 const float *Spectrum::CIE_Y() { return kCIE_Y; }
+const float *Spectrum::RGBIllumBasis(int k) {
+    static const float *const b[7] = {kRGBIllum2SpectWhite, kRGBIllum2SpectCyan, kRGBIllum2SpectMagenta, kRGBIllum2SpectYellow,
+                                      kRGBIllum2SpectRed, kRGBIllum2SpectGreen, kRGBIllum2SpectBlue};
+    return b[k];
+}
 
 void Spectrum::ToXYZ(float xyz[3]) const {
     xyz[0] = xyz[1] = xyz[2] = 0.f;

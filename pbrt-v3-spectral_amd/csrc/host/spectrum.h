@@ -40,6 +40,7 @@ struct Spectrum {
     // "spectrum" parameters given as (lambda, value) pairs, spectrum.h:302-321
     static Spectrum FromSampled(const float *lambda, const float *v, int n);
     static const float *CIE_Y();  // the 31-bin Y matching function
+    static const float *RGBIllumBasis(int k);  // rgbIllum2Spect White, Cyan, Magenta, Yellow, Red, Green, Blue
 };
 inline Spectrum operator*(float a, const Spectrum &s) { return s * a; }
 inline Spectrum Sqrt(const Spectrum &s) { Spectrum r; for (int i = 0; i < kNSpec; ++i) r.c[i] = std::sqrt(s.c[i]); return r; }

@@ -130,3 +130,30 @@ WorldEnd
 
 def material_zoo(res=96, spp=16, depth=6, strategy="spatial"):
     return MATERIAL_ZOO % dict(res=res, spp=spp, depth=depth, strategy=strategy)
+
+
+def write_env_pfm(path, w=40, h=24, seed=5):
+    """A small procedural environment map (non-power-of-two on purpose: the MIPMap resamples it) with a 'sun'."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    img = (rng.random((h, w, 3)) ** 3 * 4).astype(np.float32)
+    img[3:6, 10:14] = [30, 25, 18]
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(img[::-1].tobytes())
+    return img
+
+
+def zoo_with_infinite_light(kind, res=64, spp=16, depth=6, strategy="power"):
+    """The material zoo lit by (also) a LightSource "infinite": kind = "const" (constant L beside the other lights),
+    "map" (rotated PFM map beside the other lights) or "only_env" (the map alone). The map file is env.pfm in base_dir."""
+    zoo = material_zoo(res=res, spp=spp, depth=depth, strategy=strategy)
+    if kind == "const":
+        return zoo.replace('LightSource "point"', 'LightSource "infinite" "rgb L" [.4 .5 .7]\nLightSource "point"')
+    if kind == "map":
+        return zoo.replace('LightSource "point"', 'AttributeBegin\nRotate -90 1 0 0\nRotate 30 0 0 1\nLightSource "infinite" "rgb L" [.6 .6 .6] '
+                           '"string mapname" "env.pfm"\nAttributeEnd\nLightSource "point"')
+    t = zoo.replace('LightSource "point" "rgb I" [6 6 8] "point from" [-4 3 -3]', '')
+    t = t.replace('LightSource "distant" "rgb L" [.4 .4 .5] "point from" [0 10 -4] "point to" [0 0 0]', '')
+    t = t.replace('AreaLightSource "diffuse" "rgb L" [18 17 15]', '')
+    return t.replace('WorldBegin', 'WorldBegin\nAttributeBegin\nRotate -90 1 0 0\nLightSource "infinite" "string mapname" "env.pfm"\nAttributeEnd')

@@ -117,7 +117,7 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     WorldBegin
     Material "hair"
     Shape "cylinder"
-    LightSource "infinite"
+    LightSource "goniometric"
     ObjectBegin "o"
     ObjectEnd
     Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
@@ -125,7 +125,7 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     """
     s = pt.Scene(text=txt)
     errs = "\n".join(s.errors)
-    for word in ("orthographic", "sobol", "bdpt", "hair", "cylinder", "infinite", "instancing"):
+    for word in ("orthographic", "sobol", "bdpt", "hair", "cylinder", "goniometric", "instancing"):
         assert word in errs, word
     assert s.stats["n_triangles"] == 1
 
@@ -352,3 +352,31 @@ def test_rgb_film_output_pfm_and_tga(pt, tmp_path):
     assert tga[2] == 2 and tga[12] == 7 and tga[14] == 5 and tga[16] == 24 and len(tga) == 18 + 3 * 35
     pt.write_rgb(str(tmp_path / "b.exr"), film, weight)       # EXR is not linked: a .pfm beside it
     assert (tmp_path / "b.pfm").exists()
+
+
+def test_infinite_light_environment_map(pt, tmp_path):
+    """LightSource "infinite" (infinite.cpp:43-83,176-186): constant map = one texel; a 40x24 PFM is resampled to 64x32
+    (mipmap.h:118-196); the sampling distribution is 2W x 2H with normalised cdfs; formats other than PFM are reported."""
+    img = st.write_env_pfm(str(tmp_path / "env.pfm"))
+    head = 'Camera "perspective"\nWorldBegin\n'
+    s = pt.Scene(text=head + 'LightSource "infinite" "rgb L" [1 2 3]\nShape "sphere"\nWorldEnd\n')
+    d = s.desc
+    assert s.errors == [] and d.n_lights == 1 and d.lights[0].type == 3 and d.n_envmaps == 1
+    e = d.envmaps[0]
+    assert (e.width, e.height, e.nu, e.nv) == (1, 1, 2, 2) and e.marg_cdf[2] == 1.0 and e.cond_cdf[2] == 1.0
+    s = pt.Scene(text=head + 'Rotate 90 0 0 1\nLightSource "infinite" "string mapname" "env.pfm" "rgb scale" [2 2 2]\nShape "sphere"\nWorldEnd\n',
+                 base_dir=str(tmp_path))
+    d = s.desc
+    assert s.errors == []
+    e = d.envmaps[0]
+    assert (e.width, e.height, e.nu, e.nv) == (64, 32, 128, 64)
+    rgb = np.array([e.rgb[i] for i in range(64 * 32 * 3)]).reshape(32, 64, 3)
+    assert (rgb >= 0).all() and abs(rgb.mean() / (2 * 0.92 * img.mean()) - 1) < 0.25   # resampled, scaled by L's RGB
+    cdf = np.array([e.marg_cdf[i] for i in range(65)])
+    assert cdf[0] == 0 and cdf[-1] == 1 and (np.diff(cdf) >= 0).all()
+    row = np.array([e.cond_cdf[10 * 129 + i] for i in range(129)])
+    assert row[0] == 0 and row[-1] == 1 and (np.diff(row) >= 0).all()
+    l = d.lights[0]
+    assert abs(l.l2w[0]) < 1e-6 and abs(abs(l.l2w[1]) - 1) < 1e-6           # the Rotate reached the light's frame
+    s = pt.Scene(text=head + 'LightSource "infinite" "string mapname" "sky.exr"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("PFM" in m for m in s.errors) and s.desc.envmaps[0].width == 1

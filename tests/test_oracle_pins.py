@@ -247,3 +247,20 @@ def test_spatial_light_distribution_is_a_pmf_favouring_near_lights(pt, ob):
     ob.lib().oracle_light_pmf(s.desc_ptr, p.ctypes.data_as(C.POINTER(C.c_float)), pmf.ctypes.data_as(C.POINTER(C.c_float)))
     assert pmf.sum() == pytest.approx(1, abs=1e-5) and (pmf > 0).all()
     assert pmf[0] + pmf[1] > 0.8
+
+
+def test_infinite_light_white_furnace(pt, ob):
+    """An albedo-1 matte sphere inside a constant LightSource "infinite" is invisible: it reflects exactly the radiance
+    that arrives (furnace argument of tests/analytic_scenes.cpp applied to the environment light). Exercises Le for
+    escaped rays, Sample_Li / Pdf_Li and the MIS of EstimateDirect against each other."""
+    txt = ('LookAt 0 0 -5 0 0 0 0 1 0\nCamera "perspective" "float fov" [30]\n'
+           'Film "image" "integer xresolution" [24] "integer yresolution" [24]\nSampler "halton" "integer pixelsamples" [128]\n'
+           'Integrator "path" "integer maxdepth" [60] "float rrthreshold" [0]\nWorldBegin\n'
+           'LightSource "infinite" "spectrum L" [300 1 800 1]\nMaterial "matte" "spectrum Kd" [300 1 800 1]\nShape "sphere"\nWorldEnd\n')
+    s = pt.Scene(text=txt)
+    assert s.errors == []
+    film, weight, c, _ = ob.render(s)
+    img = film.mean(-1) / weight
+    background, sphere = img[0, 0], img[10:14, 10:14].mean()
+    assert abs(sphere / background - 1) < 0.02
+    assert np.allclose(img, background, rtol=0.15)        # no pixel stands out (64 spp noise at the silhouette)
