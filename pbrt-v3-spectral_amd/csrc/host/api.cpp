@@ -463,15 +463,27 @@ struct Api {
     }
 
     void Texture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &ps) {
-        if (texname != "constant") {
-            Err("Texture class \"" + texname + "\" is outside the hot-path scope (only \"constant\", SURVEY 2 row 29)");
+        // Every texture on this path evaluates to a constant, so "scale" and "mix" of such textures fold into
+        // constants with the reference's arithmetic (src/textures/scale.h:56-58, mix.h:57-61, scale.cpp, mix.cpp).
+        if (texname != "constant" && texname != "scale" && texname != "mix") {
+            Err("Texture class \"" + texname + "\" is outside the hot-path scope (only \"constant\", \"scale\", \"mix\" of constants, SURVEY 2 row 29)");
             return;
         }
         ParamSet empty;
         TextureParams tp(ps, empty, gs.textures, &scene->errors);
-        if (type == "float") gs.textures.floatTex[name] = tp.GetFloat("value", 1.f);
-        else if (type == "color" || type == "spectrum") gs.textures.spectrumTex[name] = tp.GetSpectrum("value", Spectrum(1.f));
-        else Err("Texture type \"" + type + "\" unknown.");
+        const bool isFloat = type == "float", isSpec = type == "color" || type == "spectrum";
+        if (!isFloat && !isSpec) { Err("Texture type \"" + type + "\" unknown."); return; }
+        if (texname == "constant") {
+            if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("value", 1.f);
+            else gs.textures.spectrumTex[name] = tp.GetSpectrum("value", Spectrum(1.f));
+        } else if (texname == "scale") {
+            if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("tex1", 1.f) * tp.GetFloat("tex2", 1.f);
+            else gs.textures.spectrumTex[name] = tp.GetSpectrum("tex1", Spectrum(1.f)) * tp.GetSpectrum("tex2", Spectrum(1.f));
+        } else {
+            const float amt = tp.GetFloat("amount", 0.5f);
+            if (isFloat) gs.textures.floatTex[name] = (1 - amt) * tp.GetFloat("tex1", 0.f) + amt * tp.GetFloat("tex2", 1.f);
+            else gs.textures.spectrumTex[name] = (1 - amt) * tp.GetSpectrum("tex1", Spectrum(0.f)) + amt * tp.GetSpectrum("tex2", Spectrum(1.f));
+        }
     }
 
     void WorldEnd();

@@ -380,3 +380,30 @@ def test_infinite_light_environment_map(pt, tmp_path):
     assert abs(l.l2w[0]) < 1e-6 and abs(abs(l.l2w[1]) - 1) < 1e-6           # the Rotate reached the light's frame
     s = pt.Scene(text=head + 'LightSource "infinite" "string mapname" "sky.exr"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
     assert any("PFM" in m for m in s.errors) and s.desc.envmaps[0].width == 1
+
+
+def test_scale_and_mix_textures_of_constants_fold(pt):
+    """Texture "scale" (tex1 * tex2) and "mix" ((1 - amount) * tex1 + amount * tex2) over constant textures."""
+    txt = ('Camera "perspective"\nWorldBegin\n'
+           'Texture "a" "spectrum" "constant" "rgb value" [.2 .4 .6]\nTexture "b" "float" "constant" "float value" [.5]\n'
+           'Texture "c" "spectrum" "scale" "texture tex1" "a" "rgb tex2" [.5 .5 .5]\n'
+           'Texture "d" "spectrum" "mix" "texture tex1" "a" "texture tex2" "c" "float amount" [.25]\n'
+           'Texture "r" "float" "mix" "texture tex1" "b" "float tex2" [.1] "texture amount" "b"\n'
+           'Material "plastic" "texture Kd" "d" "rgb Ks" [.3 .3 .3] "texture roughness" "r"\nShape "sphere"\n'
+           'Material "matte" "texture Kd" "a"\nShape "sphere"\nWorldEnd\n')
+    s = pt.Scene(text=txt)
+    assert s.errors == []
+    d = s.desc
+    plastic = [d.materials[i] for i in range(d.n_materials) if d.materials[i].kind == 1][0]
+    matte = [d.materials[i] for i in range(d.n_materials) if d.materials[i].kind == 0 and d.materials[i].n_bxdfs == 1][-1]
+    a = np.array([matte.bxdf[0].R[i] for i in range(31)], np.float32)
+    half = pt.Scene(text='Camera "perspective"\nWorldBegin\nMaterial "matte" "rgb Kd" [.5 .5 .5]\nShape "sphere"\nWorldEnd\n')
+    hm = [half.desc.materials[i] for i in range(half.desc.n_materials) if half.desc.materials[i].n_bxdfs == 1][-1]
+    t2 = np.array([hm.bxdf[0].R[i] for i in range(31)], np.float32)
+    want = np.float32(0.75) * a + np.float32(0.25) * (a * t2)
+    got = np.array([plastic.bxdf[0].R[i] for i in range(31)], np.float32)
+    assert np.array_equal(got, want)
+    # roughness texture r = (1 - .5) * .5 + .5 * .1 = .3, remapped by RoughnessToAlpha
+    assert abs(plastic.bxdf[1].p[0] - plastic.bxdf[1].p[1]) == 0 and 0.05 < plastic.bxdf[1].p[0] < 0.6
+    s2 = pt.Scene(text=txt.replace('"scale"', '"checkerboard"'))
+    assert any("checkerboard" in e for e in s2.errors)
