@@ -991,4 +991,24 @@ void oracle_light_pmf(const mi_scene_desc *desc, const float *p3, float *pmf) {
         pmf[i] = (dist->funcInt > 0) ? dist->func[i] / (dist->funcInt * dist->Count()) : 0;
 }
 
+// Distribution1D over func[n] (sampling.h:55-109): mode 0 = SampleDiscrete(u) -> out{offset, pdf};
+// mode 1 = SampleContinuous(u) -> out{x, pdf, offset}; mode 2 = DiscretePDF(index = (int)u) -> out{pdf}.
+void oracle_distribution1d(const float *func, int n, float u, int mode, float *out) {
+    Distribution1D dist(func, n);
+    if (mode == 0) {
+        Float pdf;
+        out[0] = (float)dist.SampleDiscrete(u, &pdf);
+        out[1] = pdf;
+    } else if (mode == 1) {
+        Float pdf;
+        int off;
+        out[0] = SampleContinuous1D(dist.func.data(), dist.cdf.data(), dist.funcInt, n, u, &pdf, &off);
+        out[1] = pdf;
+        out[2] = (float)off;
+    } else {
+        const int index = (int)u;
+        out[0] = dist.func[index] / (dist.funcInt * dist.Count());
+    }
+}
+
 }  // extern "C"

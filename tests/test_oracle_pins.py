@@ -264,3 +264,41 @@ def test_infinite_light_white_furnace(pt, ob):
     background, sphere = img[0, 0], img[10:14, 10:14].mean()
     assert abs(sphere / background - 1) < 0.02
     assert np.allclose(img, background, rtol=0.15)        # no pixel stands out (64 spp noise at the silhouette)
+
+
+def _dist1d(ob, func, u, mode):
+    f = np.asarray(func, np.float32)
+    out = np.zeros(3, np.float32)
+    ob.lib().oracle_distribution1d.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
+    ob.lib().oracle_distribution1d(f.ctypes.data_as(C.POINTER(C.c_float)), len(f), u, mode, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def test_distribution1d_known_answers(ob):
+    """tests/sampling.cpp:231-304 (Distribution1D.Discrete / Continuous), the literal expectations: the light-selection
+    pmfs and the environment light's Distribution2D are built from this class."""
+    func = [0, 1., 0., 3.]
+    for i, want in enumerate([0, .25, 0, .75]):
+        assert _dist1d(ob, func, i, 2)[0] == want
+    one_minus_eps = float(np.nextafter(np.float32(1), np.float32(0)))
+    for u, off, pdf in [(0., 1, .25), (0.125, 1, .25), (.24999, 1, .25), (.250001, 3, .75), (0.625, 3, .75), (one_minus_eps, 3, .75), (1., 3, .75)]:
+        o = _dist1d(ob, func, u, 0)
+        assert (o[0], o[1]) == (off, pdf), u
+    # the stream of hits around the cross-over point at 0.25 (plus / minus fp slop)
+    u = uMax = np.float32(.25)
+    for _ in range(20):
+        u, uMax = np.nextafter(u, np.float32(0)), np.nextafter(uMax, np.float32(1))
+    seen3 = False
+    while u <= uMax:
+        interval = int(_dist1d(ob, func, float(u), 0)[0])
+        assert interval == (3 if seen3 else interval) and interval in (1, 3)
+        seen3 |= interval == 3
+        u = np.nextafter(u, np.float32(1))
+    assert seen3
+    func = [1, 1, 2, 4, 8]
+    o = _dist1d(ob, func, 0., 1)
+    assert o[0] == 0 and o[1] == pytest.approx(5 * 1. / 16., rel=1e-6) and o[2] == 0
+    assert _dist1d(ob, func, 0.5, 1)[0] == pytest.approx(.8, rel=1e-6)
+    o = _dist1d(ob, func, 0.75, 1)
+    assert o[0] == pytest.approx(.9, rel=1e-6) and o[1] == pytest.approx(5 * 8. / 16., rel=1e-6) and o[2] == 4
+    assert _dist1d(ob, func, 1., 1)[0] == pytest.approx(1., rel=1e-6)
