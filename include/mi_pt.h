@@ -137,7 +137,8 @@ typedef enum mi_light_type {
     MI_LIGHT_DIFFUSE_AREA = 0, /* src/lights/diffuse.cpp */
     MI_LIGHT_POINT,            /* src/lights/point.cpp */
     MI_LIGHT_DISTANT,          /* src/lights/distant.cpp */
-    MI_LIGHT_INFINITE          /* src/lights/infinite.cpp (environment light; mi_envmap) */
+    MI_LIGHT_INFINITE,         /* src/lights/infinite.cpp (environment light; mi_envmap) */
+    MI_LIGHT_SPOT              /* src/lights/spot.cpp: pos, L = I, w2l, cos_total_width, cos_falloff_start */
 } mi_light_type;
 
 typedef struct mi_light {
@@ -151,7 +152,8 @@ typedef struct mi_light {
     float world_radius;
     float world_center[3];
     int32_t envmap;    /* infinite: index into mi_scene_desc.envmaps */
-    float l2w[9], w2l[9]; /* infinite: rotation part of LightToWorld / WorldToLight, row major */
+    float l2w[9], w2l[9]; /* infinite, spot: rotation part of LightToWorld / WorldToLight, row major */
+    float cos_total_width, cos_falloff_start; /* spot */
 } mi_light;
 
 /* InfiniteAreaLight::Lmap (level 0 of the MIPMap<RGBSpectrum>, after the reference's power-of-two resampling)

@@ -311,7 +311,7 @@ static Float ShapePdf(const mi_scene_desc &d, int shape, Float area, const Inter
     return pdf;
 }
 
-static bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT; }
+static bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT || l.type == MI_LIGHT_SPOT; }
 
 // ---- InfiniteAreaLight, src/lights/infinite.cpp:85-144
 // Lmap->Lookup(st) with width 0: level < 0 -> triangle(0, st), bilinear with ImageWrap::Repeat (mipmap.h:252-281)
@@ -405,6 +405,21 @@ static LightSample SampleLi(const mi_scene_desc &d, const mi_light &l, const Int
         ls.pLight = Interaction();
         ls.pLight.p = pLight;
         ls.Li = Spec::From(l.L) / DistanceSquared(pLight, ref.p);
+    } else if (l.type == MI_LIGHT_SPOT) {  // spot.cpp:51-70
+        V3 pLight(l.pos[0], l.pos[1], l.pos[2]);
+        ls.wi = Normalize(pLight - ref.p);
+        ls.pdf = 1.f;
+        ls.pLight = Interaction();
+        ls.pLight.p = pLight;
+        V3 wl = Normalize(Mul3(l.w2l, -ls.wi));
+        Float cosTheta = wl.z, falloff;
+        if (cosTheta < l.cos_total_width) falloff = 0;
+        else if (cosTheta >= l.cos_falloff_start) falloff = 1;
+        else {
+            Float delta = (cosTheta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
+            falloff = (delta * delta) * (delta * delta);
+        }
+        ls.Li = Spec::From(l.L) * falloff / DistanceSquared(pLight, ref.p);
     } else if (l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
         const mi_envmap &e = d.envmaps[l.envmap];
         ls.pdf = 0;

@@ -58,7 +58,7 @@ class Light(C.Structure):
     _fields_ = [("type", C.c_int32), ("shape", C.c_int32), ("two_sided", C.c_int32), ("area", C.c_float),
                 ("L", C.c_float * NSPEC), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
                 ("world_radius", C.c_float), ("world_center", C.c_float * 3), ("envmap", C.c_int32),
-                ("l2w", C.c_float * 9), ("w2l", C.c_float * 9)]
+                ("l2w", C.c_float * 9), ("w2l", C.c_float * 9), ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float)]
 
 
 class EnvMap(C.Structure):

@@ -154,7 +154,7 @@ DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &re
     return pdf;
 }
 
-DEV bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT; }
+DEV bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT || l.type == MI_LIGHT_SPOT; }
 
 // ---- InfiniteAreaLight (src/lights/infinite.cpp:85-141)
 // Spectrum(rgb, SpectrumType::Illuminant) (SampledSpectrum::FromRGB, spectrum.cpp:98-180) reduced to scalars:
@@ -244,14 +244,15 @@ struct LightSample {
     float pdf;
     bool black;      // Li == 0 (back-facing area light)
     float liScale;   // Li[bin] = L[bin] * liScale (point light: I / d^2 is a true division, flag below)
-    bool divide;     // Li[bin] = L[bin] / liScale
+    bool divide;     // Li[bin] = (L[bin] * liMul) / liScale  (point: liMul = 1; spot: the falloff)
+    float liMul;
     bool isEnv;      // infinite light: Li[bin] = IllumBin(env, bin)
     IllumRGB env;
     Interaction pLight;
 };
 DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &ref, float u0, float u1) {
     LightSample ls;
-    ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.divide = false; ls.isEnv = false;
+    ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.liMul = 1; ls.divide = false; ls.isEnv = false;
     ls.env.i1 = ls.env.i2 = 0; ls.env.w0 = ls.env.w1 = ls.env.w2 = 0;
     if (l.type == MI_LIGHT_DIFFUSE_AREA) {
         Interaction pShape = ShapeSample(s, l.shape, ref, u0, u1, &ls.pdf);
@@ -259,6 +260,24 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
         ls.wi = Normalize(pShape.p - ref.p);
         ls.pLight = pShape;
         ls.black = !(l.two_sided || Dot(pShape.n, -ls.wi) > 0);
+    } else if (l.type == MI_LIGHT_SPOT) {  // spot.cpp:51-70
+        V3 pLight(l.pos[0], l.pos[1], l.pos[2]);
+        ls.wi = Normalize(pLight - ref.p);
+        ls.pdf = 1.f;
+        ls.pLight.p = pLight;
+        V3 wl = Normalize(Mul3(l.w2l, -ls.wi));
+        const float cosTheta = wl.z;
+        float falloff;
+        if (cosTheta < l.cos_total_width) falloff = 0;
+        else if (cosTheta >= l.cos_falloff_start) falloff = 1;
+        else {
+            const float delta = (cosTheta - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
+            falloff = (delta * delta) * (delta * delta);
+        }
+        ls.divide = true;
+        ls.liMul = falloff;
+        ls.liScale = DistanceSquared(pLight, ref.p);
+        ls.black = false;   // (a zero falloff shows up bin by bin: the caller tests Li != 0)
     } else if (l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
         const mi_envmap &e = s.envmaps[l.envmap];
         float pdfs[2];
@@ -299,7 +318,7 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
 }
 DEV float LiBin(const DScene &s, const mi_light &l, const LightSample &ls, int bin) {
     if (ls.isEnv) return IllumBin(s, ls.env, bin);
-    return ls.divide ? l.L[bin] / ls.liScale : l.L[bin];
+    return ls.divide ? (l.L[bin] * ls.liMul) / ls.liScale : l.L[bin];
 }
 
 // ------------------------------------------------------------------ Distribution1D

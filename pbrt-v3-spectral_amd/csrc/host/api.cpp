@@ -435,6 +435,27 @@ struct Api {
             Spectrum Ls = L * sc;
             for (int i = 0; i < MI_NSPEC; ++i) l.L[i] = Ls.c[i];
             l.dir[0] = w.x; l.dir[1] = w.y; l.dir[2] = w.z;
+        } else if (name == "spot") {  // CreateSpotLight, spot.cpp:102-122
+            Spectrum I = ps.FindOneSpectrum("I", Spectrum(1.0));
+            Spectrum sc = ps.FindOneSpectrum("scale", Spectrum(1.0));
+            float coneangle = ps.FindOneFloat("coneangle", 30.);
+            float conedelta = ps.FindOneFloat("conedeltaangle", 5.);
+            Vec3 from = ps.FindOnePoint3("from", Vec3(0, 0, 0));
+            Vec3 to = ps.FindOnePoint3("to", Vec3(0, 0, 1));
+            Vec3 dir = Normalize(to - from);
+            Vec3 du, dv;
+            CoordinateSystem(dir, &du, &dv);
+            Transform dirToZ(Matrix4x4(du.x, du.y, du.z, 0., dv.x, dv.y, dv.z, 0., dir.x, dir.y, dir.z, 0., 0, 0, 0, 1.));
+            Transform light2world = ctm * Translate(Vec3(from.x, from.y, from.z)) * Inverse(dirToZ);
+            Vec3 p = light2world.Point(Vec3(0, 0, 0));
+            l.type = MI_LIGHT_SPOT;
+            Spectrum Is = I * sc;
+            for (int i = 0; i < MI_NSPEC; ++i) l.L[i] = Is.c[i];
+            l.pos[0] = p.x; l.pos[1] = p.y; l.pos[2] = p.z;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) { l.l2w[3 * r + c] = light2world.m.m[r][c]; l.w2l[3 * r + c] = light2world.mInv.m[r][c]; }
+            l.cos_total_width = std::cos(Radians(coneangle));
+            l.cos_falloff_start = std::cos(Radians(coneangle - conedelta));
         } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, infinite.cpp:176-186
             Spectrum L = ps.FindOneSpectrum("L", Spectrum(1.0));
             Spectrum sc = ps.FindOneSpectrum("scale", Spectrum(1.0));

@@ -51,6 +51,7 @@ void BuildLightDistribution(HostScene *scene, const std::string &strategyIn) {
             Spectrum L = Spectrum::FromArray(l.L), P;
             if (l.type == MI_LIGHT_DIFFUSE_AREA) P = (l.two_sided ? 2 : 1) * L * l.area * kPi;
             else if (l.type == MI_LIGHT_POINT) P = 4 * kPi * L;
+            else if (l.type == MI_LIGHT_SPOT) P = L * 2 * kPi * (1 - .5f * (l.cos_falloff_start + l.cos_total_width));  // spot.cpp:71-73
             else if (l.type == MI_LIGHT_INFINITE) P = (kPi * l.world_radius * l.world_radius) * L;  // infinite.cpp:85-89
             else P = L * kPi * l.world_radius * l.world_radius;
             power.push_back(P.y());

@@ -188,6 +188,11 @@ struct Transform {
 #undef MIPT_NOT_ONE
     }
 };
+inline void CoordinateSystem(const Vec3 &v1, Vec3 *v2, Vec3 *v3) {  // geometry.h:1029-1036
+    if (std::abs(v1.x) > std::abs(v1.y)) *v2 = Vec3(-v1.z, 0, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else *v2 = Vec3(0, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    *v3 = Cross(v1, *v2);
+}
 inline Transform Inverse(const Transform &t) { return Transform(t.mInv, t.m); }
 Transform Translate(const Vec3 &delta);
 Transform Scale(float x, float y, float z);

@@ -56,6 +56,7 @@ AttributeBegin
 AttributeEnd
 LightSource "point" "rgb I" [6 6 8] "point from" [-4 3 -3]
 LightSource "distant" "rgb L" [.4 .4 .5] "point from" [0 10 -4] "point to" [0 0 0]
+LightSource "spot" "rgb I" [40 36 30] "point from" [3 4 -4] "point to" [0.5 0 -2] "float coneangle" [25] "float conedeltaangle" [8]
 AttributeBegin
   Material "matte" "rgb Kd" [.6 .6 .6] "float sigma" [20]
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 -8  -8 0 8  8 0 8  8 0 -8]

@@ -1,5 +1,6 @@
 """Host front end (.pbrt -> mi_scene_desc) and C-ABI surface. No GPU needed."""
 import ctypes as C
+import math
 import os
 import re
 import subprocess
@@ -407,3 +408,18 @@ def test_scale_and_mix_textures_of_constants_fold(pt):
     assert abs(plastic.bxdf[1].p[0] - plastic.bxdf[1].p[1]) == 0 and abs(plastic.bxdf[1].p[0] - 0.857) < 0.002
     s2 = pt.Scene(text=txt.replace('"scale"', '"checkerboard"'))
     assert any("checkerboard" in e for e in s2.errors)
+
+
+def test_spot_light_is_parsed(pt):
+    """LightSource "spot" (spot.cpp:42-49,102-122): position, cone cosines, and the light frame whose +z is from -> to."""
+    s = pt.Scene(text='Camera "perspective"\nWorldBegin\nTranslate 1 0 0\n'
+                      'LightSource "spot" "rgb I" [2 2 2] "point from" [0 5 0] "point to" [0 0 0] "float coneangle" [40] "float conedeltaangle" [10]\n'
+                      'Shape "sphere"\nWorldEnd\n')
+    assert s.errors == []
+    l = s.desc.lights[0]
+    assert l.type == 4 and [round(v, 5) for v in l.pos] == [1.0, 5.0, 0.0]
+    assert l.cos_total_width == pytest.approx(math.cos(math.radians(40)), rel=1e-6)
+    assert l.cos_falloff_start == pytest.approx(math.cos(math.radians(30)), rel=1e-6)
+    w2l = np.array(list(l.w2l)).reshape(3, 3)
+    assert np.allclose(w2l @ np.array([0, -1, 0]), [0, 0, 1], atol=1e-6)      # the spot's axis (0,-1,0) is +z in its frame
+    assert np.allclose(w2l @ w2l.T, np.eye(3), atol=1e-6)

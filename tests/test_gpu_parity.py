@@ -125,8 +125,8 @@ def test_tile_shards_partition_the_render(pt, ob):
 @pytest.mark.parametrize("strategy", ["spatial", "power", "uniform"])
 def test_material_zoo_glass_uber_disney_all_light_types(pt, ob, strategy):
     """Every material of the hot path (matte/Oren-Nayar, plastic, glass smooth+rough, uber
-    with opacity, disney thick+thin, mirror), area + point + distant lights, smooth normals,
-    and the three light-selection strategies."""
+    with opacity, disney thick+thin, mirror, metal, substrate, translucent, mix), area + point +
+    distant + spot lights, smooth normals, and the three light-selection strategies."""
     s = pt.Scene(text=st.material_zoo(res=96, spp=32, depth=6, strategy=strategy))
     assert s.errors == []
     integ = pt.CreatePathIntegrator(s)

@@ -241,8 +241,8 @@ def test_bsdf_sampling_matches_its_pdf(pt, ob, kind):
 
 def test_spatial_light_distribution_is_a_pmf_favouring_near_lights(pt, ob):
     s = pt.Scene(text=st.material_zoo())
-    assert s.desc.light_distrib.type == 2 and s.desc.n_lights == 4
-    pmf = np.zeros(4, np.float32)
+    assert s.desc.light_distrib.type == 2 and s.desc.n_lights == 5   # 2 area-light triangles, point, distant, spot
+    pmf = np.zeros(5, np.float32)
     p = np.array([0, 4.5, 0], np.float32)  # just under the area light quad (lights 0,1)
     ob.lib().oracle_light_pmf(s.desc_ptr, p.ctypes.data_as(C.POINTER(C.c_float)), pmf.ctypes.data_as(C.POINTER(C.c_float)))
     assert pmf.sum() == pytest.approx(1, abs=1e-5) and (pmf > 0).all()
