@@ -197,41 +197,57 @@ DEV float FrConductorBin(float cos2, float sin2, float twoCos, float etaT, float
     return (Rp + Rs) * 0.5f;
 }
 
+// Lobe-type masks: the shading kernel is instantiated for sets of BxDF types (bit = mi_bxdf_type, bits 16.. =
+// mi_fresnel_type), so that a wave shading matte surfaces carries no microfacet or Disney code and registers.
+// The guards compile the other cases out; a lobe outside the mask cannot occur (the host picks the kernel from
+// the lobes the class holds).
+#define TM_HAS(tm, type) ((((tm) >> (type)) & 1u) != 0u)
+#define TM_FRESNEL(tm, f) ((((tm) >> (16 + (f))) & 1u) != 0u)
+#define TM_SPECULAR(tm) (TM_HAS(tm, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(tm, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(tm, MI_BXDF_FRESNEL_SPECULAR))
+constexpr unsigned TM_ALL = 0xffffffffu;
+constexpr unsigned TM_SCALED = 1u << 31;  // some lobe is a ScaledBxDF (mix material)
+constexpr unsigned TM_DIFFUSE = (1u << MI_BXDF_LAMBERTIAN_REFLECTION) | (1u << MI_BXDF_OREN_NAYAR) | (1u << (16 + MI_FRESNEL_NOOP));
+constexpr unsigned TM_PLASTIC = TM_DIFFUSE | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << (16 + MI_FRESNEL_DIELECTRIC));
+
+template <unsigned TM>
 DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
     const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
     float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
     switch (le.kind & 0xff) {
-    case LK_MICRO_CONDUCTOR: {
+    case LK_MICRO_CONDUCTOR: if constexpr (TM_FRESNEL(TM, MI_FRESNEL_CONDUCTOR)) {
         const float F = FrConductorBin(le.c, le.e, le.f, bx[li].S[bin], bx[li].K[bin]);
         return LobeDiv(((R * le.a) * le.b) * F, le);
-    }
-    case LK_FBLEND: {
+    } break;
+    case LK_FBLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {
         const float Rs = bx[li].S[bin];
         const float diffuse = (((R * le.f) * (1.f - Rs)) * le.a) * le.b;
         const float specular = (Rs + (1.f - Rs) * le.c) * le.e;
         return diffuse + specular;
-    }
+    } break;
     case LK_MUL1: return R * le.a;
     case LK_MUL2: return (R * le.a) * le.b;
-    case LK_MUL3: return ((R * le.a) * le.b) * le.c;
-    case LK_MUL3_DIV: return LobeDiv(((R * le.a) * le.b) * le.c, le);
-    case LK_MUL1_DIV: return LobeDiv(R * le.a, le);
-    case LK_MUL2_DIV: return LobeDiv((R * le.a) * le.b, le);
-    case LK_MICRO_DISNEY: {
+    case LK_MUL3: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_DIFFUSE) || TM_HAS(TM, MI_BXDF_DISNEY_RETRO)) return ((R * le.a) * le.b) * le.c; break;
+    case LK_MUL3_DIV: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) return LobeDiv(((R * le.a) * le.b) * le.c, le); break;
+    case LK_MUL1_DIV: if constexpr (TM_SPECULAR(TM)) return LobeDiv(R * le.a, le); break;
+    case LK_MUL2_DIV: if constexpr (TM_SPECULAR(TM)) return LobeDiv((R * le.a) * le.b, le); break;
+    case LK_MICRO_DISNEY: if constexpr (TM_FRESNEL(TM, MI_FRESNEL_DISNEY)) {
         float S = bx[li].S[bin];
         // Lerp(metallic, Spectrum(FrDielectric), FrSchlick(R0, cosI)); FrSchlick = Lerp(w, R0, 1)
         float schlick = (1 - le.f) * S + le.f * 1.f;
         float F = (1 - le.c) * le.e + le.c * schlick;
         return LobeDiv(((R * le.a) * le.b) * F, le);
+    } break;
+    case LK_MTRANS: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) return ((1.f - le.a) * R) * le.b;
+    case LK_CONST: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) return le.a;
+    default: break;
     }
-    case LK_MTRANS: return ((1.f - le.a) * R) * le.b;
-    case LK_CONST: return le.a;
-    default: return 0.f;
-    }
+    return 0.f;
 }
 // bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
+template <unsigned TM>
 DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
-    const float v = LobeValueInner(le, bx, bin);
+    const float v = LobeValueInner<TM>(le, bx, bin);
+    if constexpr ((TM & TM_SCALED) == 0) return v;
     return (le.lobe & 0x200) ? bx[le.lobe & 0xff].scale[bin] * v : v;
 }
 
@@ -253,11 +269,12 @@ DEV int NumComponents(const mi_material *m, int flags) {
 DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.f}; }
 
 // BxDF::f for lobe i (local wo, wi) -> LobeEval. Mirrors o_bsdf / reflection.cpp per lobe.
+template <unsigned TM>
 DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
     LobeEval le;
     le.kind = LK_NONE; le.lobe = i | (b.scaled ? 0x200 : 0); le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
     switch (b.type) {
-    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:285-298
+    case MI_BXDF_FRESNEL_BLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {  // reflection.cpp:285-298
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
@@ -269,11 +286,11 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         le.c = (hc * hc) * (hc * hc) * hc;
         le.e = DistOf(b).D(wh) / (4 * AbsDot(wi, wh) * maxf(AbsCosTheta(wi), AbsCosTheta(wo)));
         break;
-    }
+    } break;
     case MI_BXDF_LAMBERTIAN_REFLECTION:
     case MI_BXDF_LAMBERTIAN_TRANSMISSION:
         le.kind = LK_MUL1; le.a = kInvPi; break;
-    case MI_BXDF_OREN_NAYAR: {
+    case MI_BXDF_OREN_NAYAR: if constexpr (TM_HAS(TM, MI_BXDF_OREN_NAYAR)) {
         float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
         float maxCos = 0;
         if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
@@ -287,8 +304,8 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
         le.kind = LK_MUL2; le.a = kInvPi; le.b = (b.p[0] + b.p[1] * maxCos * sinAlpha * tanBeta);
         break;
-    }
-    case MI_BXDF_MICROFACET_REFLECTION: {
+    } break;
+    case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {
         float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
         V3 wh = wi + wo;
         if (cosThetaI == 0 || cosThetaO == 0) break;
@@ -298,13 +315,13 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float cosI = Dot(wi, wh);
         le.a = d.D(wh); le.b = d.G(wo, wi);
         const float denom = (4 * cosThetaI * cosThetaO);
-        if (b.fresnel == MI_FRESNEL_CONDUCTOR) {  // FresnelConductor::Evaluate(cosI) = FrConductor(|cosI|, 1, eta, k)
+        if (TM_FRESNEL(TM, MI_FRESNEL_CONDUCTOR) && b.fresnel == MI_FRESNEL_CONDUCTOR) {  // FresnelConductor::Evaluate(cosI) = FrConductor(|cosI|, 1, eta, k)
             le.kind = LK_MICRO_CONDUCTOR;
             const float c = clampf(absf(cosI), -1, 1);
             le.c = c * c;
             le.e = (float)(1. - (double)le.c);
             le.f = (float)2 * c;
-        } else if (b.fresnel == MI_FRESNEL_DISNEY) {
+        } else if (TM_FRESNEL(TM, MI_FRESNEL_DISNEY) && b.fresnel == MI_FRESNEL_DISNEY) {
             le.kind = LK_MICRO_DISNEY;
             le.c = b.p[2];                       // metallic
             le.e = FrDielectric(cosI, 1, b.p[3]);
@@ -315,8 +332,8 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         }
         SetDivisor(le, denom);
         break;
-    }
-    case MI_BXDF_MICROFACET_TRANSMISSION: {
+    } break;
+    case MI_BXDF_MICROFACET_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) {
         if (SameHemisphere(wo, wi)) break;
         float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
         if (cosThetaI == 0 || cosThetaO == 0) break;
@@ -333,13 +350,13 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         le.b = absf(d.D(wh) * d.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
                     (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
         break;
-    }
-    case MI_BXDF_DISNEY_DIFFUSE: {
+    } break;
+    case MI_BXDF_DISNEY_DIFFUSE: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_DIFFUSE)) {
         float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
         le.kind = LK_MUL3; le.a = kInvPi; le.b = (1 - Fo / 2); le.c = (1 - Fi / 2);
         break;
-    }
-    case MI_BXDF_DISNEY_FAKE_SS: {
+    } break;
+    case MI_BXDF_DISNEY_FAKE_SS: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_FAKE_SS)) {
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
@@ -350,8 +367,8 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float ss = 1.25f * (Fss * (1 / (AbsCosTheta(wo) + AbsCosTheta(wi)) - .5f) + .5f);
         le.kind = LK_MUL2; le.a = kInvPi; le.b = ss;
         break;
-    }
-    case MI_BXDF_DISNEY_RETRO: {
+    } break;
+    case MI_BXDF_DISNEY_RETRO: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_RETRO)) {
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
@@ -360,15 +377,15 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float Rr = 2 * b.p[0] * cosThetaD * cosThetaD;
         le.kind = LK_MUL3; le.a = kInvPi; le.b = Rr; le.c = (Fo + Fi + Fo * Fi * (Rr - 1));
         break;
-    }
-    case MI_BXDF_DISNEY_SHEEN: {
+    } break;
+    case MI_BXDF_DISNEY_SHEEN: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_SHEEN)) {
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
         le.kind = LK_MUL1; le.a = SchlickWeight(Dot(wi, wh));
         break;
-    }
-    case MI_BXDF_DISNEY_CLEARCOAT: {
+    } break;
+    case MI_BXDF_DISNEY_CLEARCOAT: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) {
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
@@ -377,28 +394,29 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float Gr = smithG_GGX(AbsCosTheta(wo), .25f) * smithG_GGX(AbsCosTheta(wi), .25f);
         le.kind = LK_CONST; le.a = b.p[0] * Gr * Fr * Dr / 4;
         break;
-    }
+    } break;
     default: break;  // specular lobes: f == 0
     }
     return le;
 }
 
+template <unsigned TM>
 DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     switch (b.type) {
-    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:470-475
+    case MI_BXDF_FRESNEL_BLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {  // reflection.cpp:470-475
         if (!SameHemisphere(wo, wi)) return 0;
         V3 wh = Normalize(wo + wi);
         float pdf_wh = DistOf(b).Pdf(wo, wh);
         return .5f * (AbsCosTheta(wi) * kInvPi + pdf_wh / (4 * Dot(wo, wh)));
-    }
-    case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR: return 0;
-    case MI_BXDF_LAMBERTIAN_TRANSMISSION: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
-    case MI_BXDF_MICROFACET_REFLECTION: {
+    } break;
+    case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR: if constexpr (TM_HAS(TM, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(TM, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(TM, MI_BXDF_FRESNEL_SPECULAR)) { return 0; } break;
+    case MI_BXDF_LAMBERTIAN_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_LAMBERTIAN_TRANSMISSION)) { return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0; } break;
+    case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {
         if (!SameHemisphere(wo, wi)) return 0;
         V3 wh = Normalize(wo + wi);
         return DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
-    }
-    case MI_BXDF_MICROFACET_TRANSMISSION: {
+    } break;
+    case MI_BXDF_MICROFACET_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) {
         if (SameHemisphere(wo, wi)) return 0;
         const float etaA = b.p[2], etaB = b.p[3];
         float eta = CosTheta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
@@ -406,17 +424,18 @@ DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
         float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
         float dwh_dwi = absf((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
         return DistOf(b).Pdf(wo, wh) * dwh_dwi;
-    }
-    case MI_BXDF_DISNEY_CLEARCOAT: {
+    } break;
+    case MI_BXDF_DISNEY_CLEARCOAT: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) {
         if (!SameHemisphere(wo, wi)) return 0;
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return 0;
         wh = Normalize(wh);
         float Dr = GTR1(AbsCosTheta(wh), b.p[1]);
         return Dr * AbsCosTheta(wh) / (4 * Dot(wo, wh));
+    } break;
+    default: break;
     }
-    default: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
-    }
+    return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * kInvPi : 0;
 }
 
 // NL = compile-time bound on the material's lobe count: the shading kernels are
@@ -429,7 +448,7 @@ struct BSDFEvalT {
 };
 
 // BSDF::f(woW, wiW, flags): fills the lobe list (reflection.cpp:670-683).
-template <int NL>
+template <int NL, unsigned TM>
 DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BSDFEvalT<NL> *ev) {
     ev->n = 0;
     V3 wi = fr.WorldToLocal(wiW), wo = fr.WorldToLocal(woW);
@@ -442,12 +461,13 @@ DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BS
             const mi_bxdf &b = m->bxdf[i];
             if (MatchesFlags(b, flags) &&
                 ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION)))) {
-                LobeEval le = LobeF(b, i, wo, wi);
+                LobeEval le = LobeF<TM>(b, i, wo, wi);
                 if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
             }
         }
     }
 }
+template <unsigned TM>
 DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags) {  // reflection.cpp:770-785
     const mi_material *m = fr.m;
     if (m->n_bxdfs == 0) return 0.f;
@@ -456,23 +476,23 @@ DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags)
     float pdf = 0.f;
     int matchingComps = 0;
     for (int i = 0; i < m->n_bxdfs; ++i)
-        if (MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf(m->bxdf[i], wo, wi); }
+        if (MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf<TM>(m->bxdf[i], wo, wi); }
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 
-template <int NL>
+template <int NL, unsigned TM>
 DEV float EvalBin(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int bin) {
     float f = 0.f;
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-        if (i < ev.n) f += LobeValue(ev.lobes[i], bx, bin);
+        if (i < ev.n) f += LobeValue<TM>(ev.lobes[i], bx, bin);
     return f;
 }
 
 // BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a
 // black f (including the early-outs that leave *pdf untouched). On success the value is
 // described by *ev (one specular LobeEval, or the lobe list for the sampled direction).
-template <int NL>
+template <int NL, unsigned TM>
 DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, float u0, float u1, float *pdf, int type,
                        int *sampledType, BSDFEvalT<NL> *ev) {
     const mi_material *m = fr.m;
@@ -493,14 +513,14 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     spec.kind = LK_NONE; spec.lobe = bi | (b.scaled ? 0x200 : 0); spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
     bool isSpecular = (b.flags & MI_BSDF_SPECULAR) != 0;
     switch (b.type) {
-    case MI_BXDF_SPECULAR_REFLECTION: {  // (F*R)/|cos|
+    case MI_BXDF_SPECULAR_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_SPECULAR_REFLECTION)) {  // (F*R)/|cos|
         wi = V3(-wo.x, -wo.y, wo.z);
         *pdf = 1;
         float F = (b.fresnel == MI_FRESNEL_DIELECTRIC) ? FrDielectric(CosTheta(wi), b.p[2], b.p[3]) : 1.f;
         spec.kind = LK_MUL1_DIV; spec.a = F; SetDivisor(spec, AbsCosTheta(wi));
         break;
-    }
-    case MI_BXDF_SPECULAR_TRANSMISSION: {  // ((T*(1-F))*ratio)/|cos|
+    } break;
+    case MI_BXDF_SPECULAR_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_SPECULAR_TRANSMISSION)) {  // ((T*(1-F))*ratio)/|cos|
         const float etaA = b.p[0], etaB = b.p[1];
         bool entering = CosTheta(wo) > 0;
         float etaI = entering ? etaA : etaB, etaT = entering ? etaB : etaA;
@@ -511,8 +531,8 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
         spec.b = (etaI * etaI) / (etaT * etaT);
         SetDivisor(spec, AbsCosTheta(wi));
         break;
-    }
-    case MI_BXDF_FRESNEL_SPECULAR: {
+    } break;
+    case MI_BXDF_FRESNEL_SPECULAR: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_SPECULAR)) {
         const float etaA = b.p[0], etaB = b.p[1];
         float F = FrDielectric(CosTheta(wo), etaA, etaB);
         if (ur0 < F) {
@@ -530,8 +550,8 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             spec.a = (1 - F); spec.b = (etaI * etaI) / (etaT * etaT); SetDivisor(spec, AbsCosTheta(wi));
         }
         break;
-    }
-    case MI_BXDF_FRESNEL_BLEND: {  // reflection.cpp:450-468
+    } break;
+    case MI_BXDF_FRESNEL_BLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {  // reflection.cpp:450-468
         if ((double)ur0 < .5) {
             const float v0 = minf(2 * ur0, kOneMinusEpsilon);
             wi = CosineSampleHemisphere(v0, ur1);
@@ -542,30 +562,30 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, wi)) break;
         }
-        *pdf = LobePdf(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi);
         break;
-    }
-    case MI_BXDF_LAMBERTIAN_TRANSMISSION: {
+    } break;
+    case MI_BXDF_LAMBERTIAN_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_LAMBERTIAN_TRANSMISSION)) {
         wi = CosineSampleHemisphere(ur0, ur1);
         if (wo.z > 0) wi.z *= -1;
-        *pdf = LobePdf(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi);
         break;
-    }
-    case MI_BXDF_MICROFACET_REFLECTION: {
+    } break;
+    case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {
         V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
         wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, wi)) break;
         *pdf = DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
         break;
-    }
-    case MI_BXDF_MICROFACET_TRANSMISSION: {
+    } break;
+    case MI_BXDF_MICROFACET_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) {
         V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
         float eta = CosTheta(wo) > 0 ? (b.p[2] / b.p[3]) : (b.p[3] / b.p[2]);
         if (!Refract(wo, wh, eta, &wi)) break;
-        *pdf = LobePdf(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi);
         break;
-    }
-    case MI_BXDF_DISNEY_CLEARCOAT: {
+    } break;
+    case MI_BXDF_DISNEY_CLEARCOAT: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) {
         float alpha2 = b.p[1] * b.p[1];
         float cosTheta = __builtin_sqrtf(maxf(0.f, (1 - powF(alpha2, 1 - ur0)) / (1 - alpha2)));
         float sinTheta = __builtin_sqrtf(maxf(0.f, 1 - cosTheta * cosTheta));
@@ -574,13 +594,13 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
         if (!SameHemisphere(wo, wh)) wh = -wh;
         wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, wi)) break;
-        *pdf = LobePdf(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi);
         break;
-    }
+    } break;
     default: {
         wi = CosineSampleHemisphere(ur0, ur1);
         if (wo.z < 0) wi.z *= -1;
-        *pdf = LobePdf(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi);
         break;
     }
     }
@@ -588,7 +608,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *wiWorld = fr.LocalToWorld(wi);
     if (!isSpecular && matchingComps > 1)
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (i != bi && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf(m->bxdf[i], wo, wi);
+            if (i != bi && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi);
     if (matchingComps > 1) *pdf /= matchingComps;
     if (isSpecular) {
         ev->n = 1;
@@ -601,7 +621,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
                 const mi_bxdf &bb = m->bxdf[i];
                 if (MatchesFlags(bb, type) &&
                     ((reflect && (bb.flags & MI_BSDF_REFLECTION)) || (!reflect && (bb.flags & MI_BSDF_TRANSMISSION)))) {
-                    LobeEval le = LobeF(bb, i, wo, wi);
+                    LobeEval le = LobeF<TM>(bb, i, wo, wi);
                     if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
                 }
             }

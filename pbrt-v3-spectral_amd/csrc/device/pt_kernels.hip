@@ -1023,7 +1023,7 @@ DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
 #ifndef MIPT_SHADE_WAVES_PER_EU
 #define MIPT_SHADE_WAVES_PER_EU 4
 #endif
-template <int NL>
+template <int NL, unsigned TM>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_SHADE_WAVES_PER_EU, 8))) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
     // the grid covers the queues of `classes` back to back, each padded to whole blocks
     unsigned blk = blockIdx.x, count = 0;
@@ -1126,9 +1126,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         const float lightPdf = ls.pdf;
                         if (lightPdf > 0 && !ls.black) {
                             BSDFEvalT<NL> ev;
-                            BSDF_f<NL>(fr, isect.wo, ls.wi, nonSpec, &ev);
+                            BSDF_f<NL, TM>(fr, isect.wo, ls.wi, nonSpec, &ev);
                             const float absdot = AbsDot(ls.wi, isect.shN);
-                            const float scatteringPdf = BSDF_Pdf(fr, isect.wo, ls.wi, nonSpec);
+                            const float scatteringPdf = BSDF_Pdf<TM>(fr, isect.wo, ls.wi, nonSpec);
                             const bool delta = IsDeltaLight(light);
                             float weight = 1.f;
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 for (int k = 0; k < 4; ++k) {
                                     const int b = 4 * c + k;
                                     if (b < MI_NSPEC) {
-                                        const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                        const float f = EvalBin<NL, TM>(ev, mat->bxdf, b) * absdot;
                                         const float Li = LiBin(s, light, ls, b);
                                         fNonBlack |= (f != 0.f);
                                         liNonBlack |= (Li != 0.f);
@@ -1165,7 +1165,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             float sPdf = 0;
                             int sampledType = 0;
                             BSDFEvalT<NL> ev;
-                            const bool ok = BSDF_Sample_f<NL>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
+                            const bool ok = BSDF_Sample_f<NL, TM>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
                             if (ok && sPdf > 0) {
                                 const float absdot = AbsDot(wi, isect.shN);
                                 // Pdf_Li has no side effect: evaluate it before knowing whether f is black
@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     for (int k = 0; k < 4; ++k) {
                                         const int b = 4 * c + k;
                                         if (b < MI_NSPEC) {
-                                            const float f = EvalBin<NL>(ev, mat->bxdf, b) * absdot;
+                                            const float f = EvalBin<NL, TM>(ev, mat->bxdf, b) * absdot;
                                             fNonBlack |= (f != 0.f);
                                             const float LiB = isEnvLight ? IllumBin(s, envLe, b) : light.L[b];   // Le of the light if the ray reaches it
                                             float Ld = DivBy((f * LiB) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
@@ -1222,7 +1222,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 int sflags = 0;
                 const float u0 = Get1D(s, index, dim), u1 = Get1D(s, index, dim);
                 BSDFEvalT<NL> ev;
-                const bool ok = BSDF_Sample_f<NL>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
+                const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
                 bool fNonBlack = false;
                 if (ok && pdf != 0.f) {
                     const float absdot = AbsDot(wi, isect.shN);
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
                             if (b < MI_NSPEC) {
-                                const float f = EvalBin<NL>(ev, mat->bxdf, b);
+                                const float f = EvalBin<NL, TM>(ev, mat->bxdf, b);
                                 fNonBlack |= (f != 0.f);
                                 const float nb = Get4(bt, k) * DivBy(f * absdot, pdfDiv);
                                 Set4(bt, k, nb);
@@ -1414,6 +1414,7 @@ struct mi_pt {
     std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
+    unsigned diffuseClasses = 0, plasticClasses = 0;              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
 };
 
@@ -1548,6 +1549,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     std::vector<int> matClass(d->n_materials, 0);
     {
         std::vector<std::vector<int>> signatures;
+        unsigned classTypes[MAX_CLASSES] = {0};  // per class: lobe types (bits 0..15) and fresnel kinds (bits 16..) present
         for (uint32_t i = 0; i < d->n_materials; ++i) {
             const mi_material &m = d->materials[i];
             std::vector<int> sig;
@@ -1557,10 +1559,23 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             if (c == signatures.size()) signatures.push_back(sig);
             matClass[i] = (int)std::min<size_t>(c, MISS_CLASS - 1);
             ((m.n_bxdfs > 2 || c >= (size_t)MISS_CLASS - 1) ? pt->largeClasses : pt->smallClasses) |= 1u << matClass[i];
+            for (int j = 0; j < m.n_bxdfs; ++j) {
+                classTypes[matClass[i]] |= (1u << m.bxdf[j].type) | (1u << (16 + m.bxdf[j].fresnel));
+                if (m.bxdf[j].scaled) classTypes[matClass[i]] |= TM_SCALED;
+            }
         }
         pt->smallClasses &= ~pt->largeClasses;   // a shared overflow class runs the 8-lobe kernel
         pt->smallClasses |= 1u << MISS_CLASS;
         s.classMask = pt->smallClasses | pt->largeClasses;
+        // kernels compiled for a subset of the lobe types take the classes that fit
+        pt->diffuseClasses = 1u << MISS_CLASS;
+        for (int c = 0; c < MISS_CLASS; ++c) {
+            if (!((pt->smallClasses >> c) & 1u)) continue;
+            if ((classTypes[c] & ~TM_DIFFUSE) == 0) pt->diffuseClasses |= 1u << c;
+            else if ((classTypes[c] & ~TM_PLASTIC) == 0) pt->plasticClasses |= 1u << c;
+        }
+        if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = 0;
+        pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses);
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
     {
@@ -1821,8 +1836,10 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         const dim3 shadeGrid(grid.x + MAX_CLASSES);
-        hipLaunchKernelGGL(k_shade<2>, shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
-        if (pt->largeClasses) hipLaunchKernelGGL(k_shade<MI_MAX_BXDFS>, shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+        if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+        if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
         HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
