@@ -205,7 +205,10 @@ DEV float FrConductorBin(float cos2, float sin2, float twoCos, float etaT, float
 #define TM_FRESNEL(tm, f) ((((tm) >> (16 + (f))) & 1u) != 0u)
 #define TM_SPECULAR(tm) (TM_HAS(tm, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(tm, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(tm, MI_BXDF_FRESNEL_SPECULAR))
 constexpr unsigned TM_ALL = 0xffffffffu;
-constexpr unsigned TM_SCALED = 1u << 31;  // some lobe is a ScaledBxDF (mix material)
+constexpr unsigned TM_SCALED = 1u << 31;   // some lobe is a ScaledBxDF (mix material)
+#define TM_LIGHT(tm, t) ((((tm) >> (24 + (t))) & 1u) != 0u)   // bits 24..: mi_light_type present in the scene
+constexpr unsigned TM_LIGHTS_ALL = 0x1fu << 24;
+constexpr unsigned TM_LIGHTS_NO_ENV = TM_LIGHTS_ALL & ~(1u << (24 + MI_LIGHT_INFINITE));
 constexpr unsigned TM_DIFFUSE = (1u << MI_BXDF_LAMBERTIAN_REFLECTION) | (1u << MI_BXDF_OREN_NAYAR) | (1u << (16 + MI_FRESNEL_NOOP));
 constexpr unsigned TM_PLASTIC = TM_DIFFUSE | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << (16 + MI_FRESNEL_DIELECTRIC));
 

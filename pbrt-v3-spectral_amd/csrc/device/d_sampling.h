@@ -250,6 +250,7 @@ struct LightSample {
     IllumRGB env;
     Interaction pLight;
 };
+template <unsigned TM>
 DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &ref, float u0, float u1) {
     LightSample ls;
     ls.pdf = 0; ls.black = true; ls.liScale = 1; ls.liMul = 1; ls.divide = false; ls.isEnv = false;
@@ -260,7 +261,7 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
         ls.wi = Normalize(pShape.p - ref.p);
         ls.pLight = pShape;
         ls.black = !(l.two_sided || Dot(pShape.n, -ls.wi) > 0);
-    } else if (l.type == MI_LIGHT_SPOT) {  // spot.cpp:51-70
+    } else if (TM_LIGHT(TM, MI_LIGHT_SPOT) && l.type == MI_LIGHT_SPOT) {  // spot.cpp:51-70
         V3 pLight(l.pos[0], l.pos[1], l.pos[2]);
         ls.wi = Normalize(pLight - ref.p);
         ls.pdf = 1.f;
@@ -278,7 +279,7 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
         ls.liMul = falloff;
         ls.liScale = DistanceSquared(pLight, ref.p);
         ls.black = false;   // (a zero falloff shows up bin by bin: the caller tests Li != 0)
-    } else if (l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
+    } else if (TM_LIGHT(TM, MI_LIGHT_INFINITE) && l.type == MI_LIGHT_INFINITE) {  // infinite.cpp:97-125
         const mi_envmap &e = s.envmaps[l.envmap];
         float pdfs[2];
         int v;
@@ -316,8 +317,9 @@ DEV LightSample SampleLi(const DScene &s, const mi_light &l, const Interaction &
     }
     return ls;
 }
+template <unsigned TM>
 DEV float LiBin(const DScene &s, const mi_light &l, const LightSample &ls, int bin) {
-    if (ls.isEnv) return IllumBin(s, ls.env, bin);
+    if (TM_LIGHT(TM, MI_LIGHT_INFINITE) && ls.isEnv) return IllumBin(s, ls.env, bin);
     return ls.divide ? (l.L[bin] * ls.liMul) / ls.liScale : l.L[bin];
 }
 

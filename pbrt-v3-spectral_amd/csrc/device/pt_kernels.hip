@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             }
         }
         if ((bounces == 0 || (flags & F_SPECULAR)) && !found) {  // escaped: scene.infiniteLights, path.cpp:96-99
-            for (int il = 0; il < s.nInfiniteLights; ++il) {
+            for (int il = 0; TM_LIGHT(TM, MI_LIGHT_INFINITE) && il < s.nInfiniteLights; ++il) {
                 const IllumRGB le = InfiniteLe(s, s.lights[s.infiniteLights[il]], rd);
 #pragma unroll 1
                 for (int c = 0; c < NQ; ++c) {
@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         const mi_light &light = s.lights[lightNum];
                         const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
                         const Divisor selDiv = MakeDivisor(selPdf);
-                        const LightSample ls = SampleLi(s, light, isect, uL0, uL1);
+                        const LightSample ls = SampleLi<TM>(s, light, isect, uL0, uL1);
                         const float lightPdf = ls.pdf;
                         if (lightPdf > 0 && !ls.black) {
                             BSDFEvalT<NL> ev;
@@ -1143,7 +1143,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     const int b = 4 * c + k;
                                     if (b < MI_NSPEC) {
                                         const float f = EvalBin<NL, TM>(ev, mat->bxdf, b) * absdot;
-                                        const float Li = LiBin(s, light, ls, b);
+                                        const float Li = LiBin<TM>(s, light, ls, b);
                                         fNonBlack |= (f != 0.f);
                                         liNonBlack |= (Li != 0.f);
                                         float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
@@ -1172,12 +1172,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 float weight = 1;
                                 bool go = true;
                                 if (!(sampledType & MI_BSDF_SPECULAR)) {
-                                    const float lp = (light.type == MI_LIGHT_INFINITE) ? InfinitePdfLi(s, light, wi)
+                                    const float lp = (TM_LIGHT(TM, MI_LIGHT_INFINITE) && light.type == MI_LIGHT_INFINITE) ? InfinitePdfLi(s, light, wi)
                                                                                        : ShapePdf(s, light.shape, light.area, isect, wi);
                                     if (lp == 0) go = false;
                                     else { float pf = 1 * sPdf, pg = 1 * lp; weight = (pf * pf) / (pf * pf + pg * pg); }
                                 }
-                                const bool isEnvLight = light.type == MI_LIGHT_INFINITE;
+                                const bool isEnvLight = TM_LIGHT(TM, MI_LIGHT_INFINITE) && light.type == MI_LIGHT_INFINITE;
                                 IllumRGB envLe;
                                 envLe.i1 = envLe.i2 = 0; envLe.w0 = envLe.w1 = envLe.w2 = 0;
                                 if (isEnvLight && go) envLe = InfiniteLe(s, light, wi);   // light.Le(ray) when the ray escapes
@@ -1336,10 +1336,10 @@ __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcIn
         float u0 = RadicalInverse(s, 3, i), u1 = RadicalInverse(s, 4, i);
         for (int j = 0; j < nL; ++j) {
             const mi_light &l = s.lights[j];
-            LightSample ls = SampleLi(s, l, intr, u0, u1);
+            LightSample ls = SampleLi<TM_ALL>(s, l, intr, u0, u1);
             if (ls.pdf > 0) {
                 float yy = 0.f;
-                if (!ls.black) for (int b = 0; b < MI_NSPEC; ++b) yy += s.cieY[b] * LiBin(s, l, ls, b);
+                if (!ls.black) for (int b = 0; b < MI_NSPEC; ++b) yy += s.cieY[b] * LiBin<TM_ALL>(s, l, ls, b);
                 f[j] += YScale(yy) / ls.pdf;
             }
         }
@@ -1414,6 +1414,7 @@ struct mi_pt {
     std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
+    bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
 };
@@ -1575,6 +1576,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             else if ((classTypes[c] & ~TM_PLASTIC) == 0) pt->plasticClasses |= 1u << c;
         }
         if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = 0;
+        if (getenv("MIPT_ALL_LIGHTS")) pt->hasInfiniteLight = true;
         pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses);
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
@@ -1709,6 +1711,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 if ((uint32_t)d->lights[i].envmap >= d->n_envmaps) { g_err = "infinite light without environment map"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
                 if (s.nInfiniteLights == 4) { g_err = "more than 4 infinite lights"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
                 s.infiniteLights[s.nInfiniteLights++] = (int)i;
+                pt->hasInfiniteLight = true;
             }
     }
     s.camera = d->camera;
@@ -1836,10 +1839,17 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         const dim3 shadeGrid(grid.x + MAX_CLASSES);
-        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
-        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-        if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
-        if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        if (pt->hasInfiniteLight) {
+            if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+            if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+            if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+            if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        } else {
+            if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+            if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+            if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL & ~TM_LIGHTS_ALL | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+            if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL & ~TM_LIGHTS_ALL | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        }
         HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
