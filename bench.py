@@ -22,8 +22,9 @@ The JSON line also carries
                  B_ray = 32*N_node + 48*N_tri + 64 with N_node/N_tri counted by the kernel,
                  divided by the kernel's average launch duration (HIP events on the stream
                  each launch goes to, inside mi_pt_render), against the 8 TB/s HBM peak.
-                 The render runs MIPT_STREAMS sub-renderers concurrently, so a launch
-                 shares the CUs with the other streams' kernels while it is timed.
+                 By default one sub-renderer (one stream) renders the frame, so each launch has
+                 the GPU to itself while it is timed; --streams K runs K sub-renderers
+                 concurrently (a few % more throughput, but then a timed launch shares the CUs).
   cpu_baseline:  the CPU oracle (a port of the reference algorithm, oracle/) timed on the
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -53,15 +54,19 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="resident path slots (0 = library default)")
     ap.add_argument("--cpu-samples", type=int, default=80_000_000,
                     help="camera samples the CPU oracle renders for cpu_baseline (0 = skip)")
-    ap.add_argument("--exclusive-spp", type=int, default=64,
-                    help="spp of the extra one-stream pass that times the traversal kernel alone (0 = skip)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="concurrent sub-renderers (0 = MIPT_STREAMS from the environment, else 1)")
+    ap.add_argument("--exclusive-spp", type=int, default=0,
+                    help="with --streams > 1: spp of an extra one-stream pass that times the traversal kernel alone (0 = skip)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per k_extend launch from a separate rocprofv3 --pmc pass")
     a = ap.parse_args()
 
-    # four sub-renderer streams need their own hardware queues (HIP maps streams onto 4 by default)
+    # concurrent sub-renderer streams need their own hardware queues (HIP maps streams onto 4 by default)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    os.environ.setdefault("MIPT_STREAMS", "4")
+    if a.streams > 0:
+        os.environ["MIPT_STREAMS"] = str(a.streams)
+    os.environ.setdefault("MIPT_STREAMS", "1")
     import torch
     import pbrt_v3_spectral_amd as pt
     import importlib.util
@@ -148,7 +153,7 @@ def main():
                 traffic = tr["k_trav0_hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_trav<0>", "concurrent_streams": int(os.environ.get("MIPT_STREAMS", "2")), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_trav<0>", "concurrent_streams": int(os.environ.get("MIPT_STREAMS", "1")), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tri_tests_per_ray": round(n_tri, 2),
                 "rays_per_launch": round(ext_rays / n_launch), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
@@ -177,19 +182,19 @@ def main():
 
     # The same kernel with the GPU to itself: one untimed 64-spp pass through a one-stream
     # integrator (rank 0, N = 1), so the concurrent-launch figure above has its reference.
-    if rank == 0 and world == 1 and a.exclusive_spp > 0:
+    if rank == 0 and world == 1 and a.exclusive_spp > 0 and roofline["concurrent_streams"] > 1:
         os.environ["MIPT_STREAMS"] = "1"
         solo = pt.CreatePathIntegrator(scene, local_rank)
         os.environ["MIPT_STREAMS"] = str(roofline["concurrent_streams"])
         for _ in range(2):   # first pass allocates the pool
-            solo.Render(spp=a.exclusive_spp, path_pool=1 << 21, download=False)
+            solo.Render(spp=a.exclusive_spp, path_pool=1 << 23, download=False)
         sc_, st_ = solo.counters.as_dict(), solo.timings()
         s_rays = max(1, sc_["extend_rays"])
         s_bray = 32.0 * sc_["extend_nodes"] / s_rays + 48.0 * sc_["extend_tri_tests"] / s_rays + 64.0
         s_gbs = s_bray * s_rays / st_[6] / 1e9
         roofline["exclusive"] = {"streams": 1, "achieved": round(s_gbs, 1), "frac": round(s_gbs / HBM_PEAK_GBS, 4),
                                  "avg_launch_ms": round(st_[6] / max(1, sc_["iterations"]) * 1e3, 4),
-                                 "launches": sc_["iterations"], "sample": "%d spp pass, 2M-slot pool" % a.exclusive_spp,
+                                 "launches": sc_["iterations"], "sample": "%d spp pass, 8M-slot pool" % a.exclusive_spp,
                                  "mray_per_s": round((sc_["regular_rays"] + sc_["shadow_rays"]) / st_[0] / 1e6, 1)}
         del solo
 

@@ -213,16 +213,14 @@ constexpr unsigned TM_DIFFUSE = (1u << MI_BXDF_LAMBERTIAN_REFLECTION) | (1u << M
 constexpr unsigned TM_PLASTIC = TM_DIFFUSE | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << (16 + MI_FRESNEL_DIELECTRIC));
 
 template <unsigned TM>
-DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
-    const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
-    float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
+DEV float LobeValueCore(const LobeEval &le, float R, float Sv, float Kv) {  // R: the lobe's spectrum at the bin (S when bit 8 of le.lobe is set)
     switch (le.kind & 0xff) {
     case LK_MICRO_CONDUCTOR: if constexpr (TM_FRESNEL(TM, MI_FRESNEL_CONDUCTOR)) {
-        const float F = FrConductorBin(le.c, le.e, le.f, bx[li].S[bin], bx[li].K[bin]);
+        const float F = FrConductorBin(le.c, le.e, le.f, Sv, Kv);
         return LobeDiv(((R * le.a) * le.b) * F, le);
     } break;
     case LK_FBLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {
-        const float Rs = bx[li].S[bin];
+        const float Rs = Sv;
         const float diffuse = (((R * le.f) * (1.f - Rs)) * le.a) * le.b;
         const float specular = (Rs + (1.f - Rs) * le.c) * le.e;
         return diffuse + specular;
@@ -234,7 +232,7 @@ DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
     case LK_MUL1_DIV: if constexpr (TM_SPECULAR(TM)) return LobeDiv(R * le.a, le); break;
     case LK_MUL2_DIV: if constexpr (TM_SPECULAR(TM)) return LobeDiv((R * le.a) * le.b, le); break;
     case LK_MICRO_DISNEY: if constexpr (TM_FRESNEL(TM, MI_FRESNEL_DISNEY)) {
-        float S = bx[li].S[bin];
+        float S = Sv;
         // Lerp(metallic, Spectrum(FrDielectric), FrSchlick(R0, cosI)); FrSchlick = Lerp(w, R0, 1)
         float schlick = (1 - le.f) * S + le.f * 1.f;
         float F = (1 - le.c) * le.e + le.c * schlick;
@@ -245,6 +243,18 @@ DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
     default: break;
     }
     return 0.f;
+}
+// Which of a lobe's other spectra its value reads (compile-time, from the kernel's lobe mask).
+#define TM_NEEDS_S(tm) (TM_FRESNEL(tm, MI_FRESNEL_CONDUCTOR) || TM_FRESNEL(tm, MI_FRESNEL_DISNEY) || TM_HAS(tm, MI_BXDF_FRESNEL_BLEND))
+#define TM_NEEDS_K(tm) (TM_FRESNEL(tm, MI_FRESNEL_CONDUCTOR))
+template <unsigned TM>
+DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
+    const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
+    const float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
+    float Sv = 0.f, Kv = 0.f;
+    if constexpr (TM_NEEDS_S(TM)) Sv = bx[li].S[bin];
+    if constexpr (TM_NEEDS_K(TM)) Kv = bx[li].K[bin];
+    return LobeValueCore<TM>(le, R, Sv, Kv);
 }
 // bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
 template <unsigned TM>
@@ -490,6 +500,50 @@ DEV float EvalBin(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int bin) {
     for (int i = 0; i < NL; ++i)
         if (i < ev.n) f += LobeValue<TM>(ev.lobes[i], bx, bin);
     return f;
+}
+
+// Four bins (quad c) of the lobe list at once. The lobes' spectra are fetched first, as unaligned 16-B loads that
+// do not depend on the lobe kind, so that one quad costs one memory round trip; fetched bin by bin inside the kind
+// switch, every bin of every lobe waits for its own load. Bin 31 (the pad lane of quad 7) reads the 4 bytes after
+// the array -- still inside the material table, whose allocation carries 16 B of slack -- and is never used.
+typedef float __attribute__((ext_vector_type(4), aligned(4))) float4u;
+DEV float4 LoadSpec4(const float *spec, int c) {
+    const float4u v = *reinterpret_cast<const float4u *>(spec + 4 * c);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV float Quad(const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+template <int NL, unsigned TM>
+DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c) {
+    if constexpr (NL > 2) {   // long lobe lists: the quads of all lobes would not fit the register file
+        const int b = 4 * c;
+        return make_float4(EvalBin<NL, TM>(ev, bx, b), EvalBin<NL, TM>(ev, bx, b + 1), EvalBin<NL, TM>(ev, bx, b + 2),
+                           (b + 3 < MI_NSPEC) ? EvalBin<NL, TM>(ev, bx, b + 3) : 0.f);
+    }
+    float4 R[NL], Sv[NL], Kv[NL], Sc[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        R[i] = Sv[i] = Kv[i] = Sc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < ev.n) {
+            const int lobe = ev.lobes[i].lobe, li = lobe & 0xff;
+            R[i] = LoadSpec4((lobe & 0x100) ? bx[li].S : bx[li].R, c);
+            if constexpr (TM_NEEDS_S(TM)) Sv[i] = LoadSpec4(bx[li].S, c);
+            if constexpr (TM_NEEDS_K(TM)) Kv[i] = LoadSpec4(bx[li].K, c);
+            if constexpr ((TM & TM_SCALED) != 0) { if (lobe & 0x200) Sc[i] = LoadSpec4(bx[li].scale, c); }
+        }
+    }
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < ev.n) {
+                float v = LobeValueCore<TM>(ev.lobes[i], Quad(R[i], k), Quad(Sv[i], k), Quad(Kv[i], k));
+                if constexpr ((TM & TM_SCALED) != 0) { if (ev.lobes[i].lobe & 0x200) v = Quad(Sc[i], k) * v; }
+                f[k] += v;
+            }
+    }
+    return make_float4(f[0], f[1], f[2], f[3]);
 }
 
 // BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a

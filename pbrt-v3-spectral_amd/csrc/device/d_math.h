@@ -36,12 +36,15 @@ DEV bool isnanf_(float a) { return a != a; }
 // rounded in (nearly) all cases; ocml's float versions are only ~1-2 ulp. Evaluating
 // in double and rounding once gives the correctly rounded float result (up to
 // double-rounding ties), so a path takes the same discrete decisions as on the CPU.
-DEV float sinF(float x) { return (float)sin((double)x); }
-DEV float cosF(float x) { return (float)cos((double)x); }
-DEV float acosF(float x) { return (float)acos((double)x); }
-DEV float atan2F(float y, float x) { return (float)atan2((double)y, (double)x); }
-DEV float logF(float x) { return (float)log((double)x); }
-DEV float powF(float x, float y) { return (float)pow((double)x, (double)y); }
+// They are deliberately not inlined: each expands to several hundred instructions, and the shading kernels
+// are bound by instruction fetch (their code does not fit the instruction cache), not by call overhead.
+#define DEV_CALL __device__ __noinline__
+static DEV_CALL float sinF(float x) { return (float)sin((double)x); }
+static DEV_CALL float cosF(float x) { return (float)cos((double)x); }
+static DEV_CALL float acosF(float x) { return (float)acos((double)x); }
+static DEV_CALL float atan2F(float y, float x) { return (float)atan2((double)y, (double)x); }
+static DEV_CALL float logF(float x) { return (float)log((double)x); }
+static DEV_CALL float powF(float x, float y) { return (float)pow((double)x, (double)y); }
 
 // x / d for many x and one d: one IEEE reciprocal, then per quotient a multiply and two
 // fused corrections (q = x*r; rem = fma(-q, d, x); q += rem*r). With r the correctly

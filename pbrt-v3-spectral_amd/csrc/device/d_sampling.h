@@ -91,6 +91,15 @@ DEV float SampleDimension(const DScene &s, uint64_t index, int dim) {  // halton
     else if (dim == 1) return RadicalInverse(s, 1, index / (uint64_t)s.baseScales[1]);
     else return ScrambledRadicalInverseBase(s.primes[dim], s.primeMagic[dim], &s.perms[s.primeSums[dim]], index);
 }
+// The same for dim >= 2 (every dimension after the film position) as one shared, out-of-line copy: the
+// integrator draws 8 dimensions per path vertex, and the shading kernels are bound by instruction fetch.
+static DEV_CALL float ScrambledDimension(const int32_t *primes, const int32_t *primeSums, const uint16_t *perms,
+                                         const uint64_t *primeMagic, uint64_t index, int dim) {
+    return ScrambledRadicalInverseBase(primes[dim], primeMagic[dim], &perms[primeSums[dim]], index);
+}
+DEV float SampleDimensionFrom2(const DScene &s, uint64_t index, int dim) {
+    return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, index, dim);
+}
 
 // ------------------------------------------------------------------ lights
 DEV float SpecYBinAccum(const DScene &s, int bin, float v) { return s.cieY[bin] * v; }
@@ -321,6 +330,20 @@ template <unsigned TM>
 DEV float LiBin(const DScene &s, const mi_light &l, const LightSample &ls, int bin) {
     if (TM_LIGHT(TM, MI_LIGHT_INFINITE) && ls.isEnv) return IllumBin(s, ls.env, bin);
     return ls.divide ? (l.L[bin] * ls.liMul) / ls.liScale : l.L[bin];
+}
+
+// Quad c (bins 4c..4c+3) of Li; the light's spectrum is one 16-B load (see EvalQuad).
+template <unsigned TM>
+DEV float4 LiQuad(const DScene &s, const mi_light &l, const LightSample &ls, int c) {
+    if (TM_LIGHT(TM, MI_LIGHT_INFINITE) && ls.isEnv) {
+        const int b = 4 * c;
+        return make_float4(IllumBin(s, ls.env, b), IllumBin(s, ls.env, b + 1), IllumBin(s, ls.env, b + 2),
+                           IllumBin(s, ls.env, min(b + 3, MI_NSPEC - 1)));
+    }
+    const float4 L = LoadSpec4(l.L, c);
+    if (!ls.divide) return L;
+    return make_float4((L.x * ls.liMul) / ls.liScale, (L.y * ls.liMul) / ls.liScale, (L.z * ls.liMul) / ls.liScale,
+                       (L.w * ls.liMul) / ls.liScale);
 }
 
 // ------------------------------------------------------------------ Distribution1D

@@ -1004,7 +1004,8 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
     else { float t; SphereInteraction(s.spheres[~p.shape], ro, rd, kInfinity, si, &t); }
 }
 
-DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimension(s, index, dim++); }
+// (the shading kernel's dimensions start after the camera sample's, so dim >= 5 here)
+DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimensionFrom2(s, index, dim++); }
 
 // ------------------------------------------------------------------ shade
 // One path vertex per lane, for the slots of one material class (queue built by
@@ -1023,6 +1024,7 @@ DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
 #ifndef MIPT_SHADE_WAVES_PER_EU
 #define MIPT_SHADE_WAVES_PER_EU 4
 #endif
+
 template <int NL, unsigned TM>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_SHADE_WAVES_PER_EU, 8))) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
     // the grid covers the queues of `classes` back to back, each padded to whole blocks
@@ -1046,6 +1048,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         const int bounces = pool.I(I_BOUNCES, slot);
         const int prim = pool.I(I_HITPRIM, slot);
         const bool found = prim >= 0;
+        auto loadBeta = [&](int c) -> float4 { return LoadBeta(pool, c, slot, betaOne); };
         const float4 ray0 = pool.R(R_RAY0, slot), ray1 = pool.R(R_RAY1, slot);
         V3 ro(ray0.x, ray0.y, ray0.z), rd(ray1.x, ray1.y, ray1.z);
         SurfaceInteraction isect;
@@ -1060,13 +1063,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 {
 #pragma unroll 1
                     for (int c = 0; c < NQ; ++c) {
-                        const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                        const float4 bt = loadBeta(c);
                         float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (!lZero) L4 = pool.Q(Q_L + c, slot);
+                        const float4 Le = LoadSpec4(l.L, c);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
-                            if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * l.L[b]);
+                            if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * Get4(Le, k));
                         }
                         pool.Q(Q_L + c, slot) = L4;
                     }
@@ -1079,7 +1083,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 const IllumRGB le = InfiniteLe(s, s.lights[s.infiniteLights[il]], rd);
 #pragma unroll 1
                 for (int c = 0; c < NQ; ++c) {
-                    const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                    const float4 bt = loadBeta(c);
                     float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (!lZero) L4 = pool.Q(Q_L + c, slot);
 #pragma unroll
@@ -1136,14 +1140,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             bool fNonBlack = false, liNonBlack = false;
 #pragma unroll 1
                             for (int c = 0; c < NQ; ++c) {
-                                const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                                const float4 bt = loadBeta(c);
                                 float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+                                const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c), Lq = LiQuad<TM>(s, light, ls, c);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const int b = 4 * c + k;
                                     if (b < MI_NSPEC) {
-                                        const float f = EvalBin<NL, TM>(ev, mat->bxdf, b) * absdot;
-                                        const float Li = LiBin<TM>(s, light, ls, b);
+                                        const float f = Get4(fq, k) * absdot;
+                                        const float Li = Get4(Lq, k);
                                         fNonBlack |= (f != 0.f);
                                         liNonBlack |= (Li != 0.f);
                                         float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
@@ -1187,15 +1192,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // nothing reads the spectrum then, so it is not formed)
 #pragma unroll 1
                                 for (int c = 0; go && c < NQ; ++c) {
-                                    const float4 bt = LoadBeta(pool, c, slot, betaOne);
+                                    const float4 bt = loadBeta(c);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c);
+                                    float4 Lq = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    if (!isEnvLight) Lq = LoadSpec4(light.L, c);
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
                                         const int b = 4 * c + k;
                                         if (b < MI_NSPEC) {
-                                            const float f = EvalBin<NL, TM>(ev, mat->bxdf, b) * absdot;
+                                            const float f = Get4(fq, k) * absdot;
                                             fNonBlack |= (f != 0.f);
-                                            const float LiB = isEnvLight ? IllumBin(s, envLe, b) : light.L[b];   // Le of the light if the ray reaches it
+                                            const float LiB = isEnvLight ? IllumBin(s, envLe, b) : Get4(Lq, k);   // Le of the light if the ray reaches it
                                             float Ld = DivBy((f * LiB) * weight, spDiv);  // f * Li * Tr(=1) * weight / scatteringPdf
                                             if (!selIsOne) Ld = DivBy(Ld, selDiv);
                                             Set4(out, k, Get4(bt, k) * Ld);
@@ -1235,12 +1243,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     float maxRR = 0;
 #pragma unroll 1
                     for (int c = 0; c < NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
-                        float4 bt = LoadBeta(pool, c, slot, betaOne);
+                        float4 bt = loadBeta(c);
+                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
                             if (b < MI_NSPEC) {
-                                const float f = EvalBin<NL, TM>(ev, mat->bxdf, b);
+                                const float f = Get4(fq, k);
                                 fNonBlack |= (f != 0.f);
                                 const float nb = Get4(bt, k) * DivBy(f * absdot, pdfDiv);
                                 Set4(bt, k, nb);
@@ -1432,7 +1441,7 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
         return MI_OK;
     }
     void *p = nullptr;
-    HIPCHK(hipMalloc(&p, count * sizeof(T)));
+    HIPCHK(hipMalloc(&p, count * sizeof(T) + 16));   // (16 B of slack: the kernels read spectra as 16-B quads)
     pt->allocs.push_back(p);
     HIPCHK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
     *dst = (const T *)p;
@@ -1756,7 +1765,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     if (hipMalloc((void **)&pt->film, pt->nPix * 32 * sizeof(float)) != hipSuccess) { g_err = "hipMalloc(film) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
     hipMemset(pt->film, 0, pt->nPix * 32 * sizeof(float));
     {
-        int nSub = 4;  // concurrent sub-renderers (MIPT_STREAMS overrides, 1..8)
+        int nSub = 1;  // sub-renderers running concurrently on their own streams (MIPT_STREAMS overrides, 1..8)
         if (const char *e = getenv("MIPT_STREAMS")) nSub = std::max(1, std::min(8, atoi(e)));
         pt->subs.resize(nSub);
         for (SubRenderer &sub : pt->subs) {

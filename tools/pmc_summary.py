@@ -14,4 +14,4 @@ for k in sorted(agg):
     print(k)
     for c in sorted(agg[k]):
         s, n = agg[k][c]
-        print("   %-32s mean/dispatch %.4g   (n=%d)" % (c, s / n, n))
+        print("   %-32s mean/dispatch %.4g   total %.5g   (n=%d)" % (c, s / n, s, n))
