@@ -64,9 +64,12 @@ def main():
 
     # concurrent sub-renderer streams need their own hardware queues (HIP maps streams onto 4 by default)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # N = 1: one sub-renderer, so that every timed launch has the GPU to itself (the roofline figure).
+    # N > 1: a rank's shard is 1/N of the frame, launches are short and their tails weigh more; four
+    # concurrent sub-renderers per GPU hide them (tools/shard_tune.py: 0.174 s -> 0.162 s for an 1/8 shard).
     if a.streams > 0:
         os.environ["MIPT_STREAMS"] = str(a.streams)
-    os.environ.setdefault("MIPT_STREAMS", "1")
+    os.environ.setdefault("MIPT_STREAMS", "1" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "4")
     import torch
     import pbrt_v3_spectral_amd as pt
     import importlib.util
