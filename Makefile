@@ -15,7 +15,7 @@ hip: $(PKG)/libmipt_hip.so
 cli: $(PKG)/pbrt_amd
 
 $(PKG)/libmipt_host.so: $(HOSTSRC) $(wildcard $(PKG)/csrc/host/*.h) $(wildcard $(PKG)/csrc/host/*.inc) include/mi_pt.h include/mi_scene.h
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) -ldl
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOSTSRC) -ldl -lz
 
 $(PKG)/libmipt_hip.so: $(wildcard $(PKG)/csrc/device/*.hip) $(wildcard $(PKG)/csrc/device/*.h) include/mi_pt.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard $(PKG)/csrc/device/*.hip)

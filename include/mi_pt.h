@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -78,8 +78,8 @@ typedef struct mi_sphere {
     int32_t reverse_orientation, swaps_handedness;
 } mi_sphere;
 
-/* ---- materials: textures are constants (src/textures/constant.h:49-58), so a
- * Material::ComputeScatteringFunctions result is a fixed BxDF list. */
+/* ---- materials: with constant textures (src/textures/constant.h:49-58) a
+ * Material::ComputeScatteringFunctions result is a fixed BxDF list; image textures bind to lobes through mi_lobe_tex. */
 typedef enum mi_bxdf_type {
     MI_BXDF_LAMBERTIAN_REFLECTION = 0, /* R */
     MI_BXDF_OREN_NAYAR,                /* R, p[0]=A, p[1]=B */
@@ -124,13 +124,53 @@ typedef struct mi_bxdf {
     float scale[MI_NSPEC]; /* ScaledBxDF::scale */
 } mi_bxdf;
 
+/* A lobe whose spectrum comes from an image texture (ABI v5). The lobe list of a material stays fixed; at a hit the
+ * texture value T = Clamp(Spectrum::FromRGB(mipmap lookup)) (imagemap.h:82-93,113-117; FromRGB's default type is
+ * Illuminant, spectrum.h:428-429, so the conversion uses rgb_illum like the environment light's) replaces R (or S), or scales
+ * the constant stored there when MI_LOBE_TEX_MUL_* is set (uber: `op * Kd->Evaluate(si).Clamp()`, uber.cpp:71-72;
+ * translucent: `r * kd`, translucent.cpp:62), and the lobe is left out of the BSDF at that hit when the spectrum the
+ * material tests with IsBlack() is black (`if (!r.IsBlack()) bsdf->Add(...)`, matte.cpp:58-63). */
+#define MI_LOBE_TEX_MUL_R 1u
+#define MI_LOBE_TEX_MUL_S 2u
+typedef enum mi_lobe_rule {
+    MI_LOBE_IF_R = 0,      /* present iff the lobe's R (after the multiplier) is not black */
+    MI_LOBE_IF_R_OR_S = 1, /* present iff R or S is not black (FresnelSpecular glass.cpp:70-72,78-80; FresnelBlend substrate.cpp:53) */
+    MI_LOBE_IF_TEX = 2     /* present iff the texture value itself is not black (translucent.cpp:59-60,68-69) */
+} mi_lobe_rule;
+typedef struct mi_lobe_tex {
+    int32_t tex_R, tex_S; /* index into mi_scene_desc.textures, -1 = the constant in mi_bxdf */
+    uint32_t flags;       /* MI_LOBE_TEX_MUL_* */
+    int32_t rule;         /* mi_lobe_rule */
+} mi_lobe_tex;
+
 typedef struct mi_material {
     int32_t n_bxdfs;
     float eta; /* BSDF::eta, src/core/reflection.h:189 */
     int32_t kind; /* informational: 0 matte 1 plastic 2 glass 3 uber 4 disney 5 mirror 6 metal 7 substrate 8 translucent 9 mix */
-    int32_t pad;
+    int32_t textured; /* != 0: some lobe has tex_R / tex_S >= 0 */
     mi_bxdf bxdf[MI_MAX_BXDFS];
+    mi_lobe_tex tex[MI_MAX_BXDFS];
 } mi_material;
+
+/* ImageTexture<RGBSpectrum, Spectrum> with UVMapping2D (src/textures/imagemap.h, src/core/texture.cpp:91-99) over a
+ * MIPMap<RGBSpectrum> (src/core/mipmap.h). The pyramid is built on the host exactly as the reference builds it (y flip,
+ * scale, inverse gamma, power-of-two Lanczos resampling, 2x2 box levels); the render side filters it per hit with the
+ * reference's EWA / trilinear lookup from the hit's (u, v) and its screen-space derivatives. */
+#define MI_MAX_MIP_LEVELS 16
+typedef struct mi_mipmap {
+    int32_t n_levels;
+    int32_t wrap;           /* 0 repeat, 1 black, 2 clamp (ImageWrap, mipmap.h:50) */
+    int32_t width, height;  /* level 0; level l is max(1, width >> l) x max(1, height >> l) */
+    const float *texels;    /* RGB triples, all levels back to back, rows from t = 0 */
+    uint32_t level_offset[MI_MAX_MIP_LEVELS]; /* first texel of level l */
+} mi_mipmap;
+typedef enum mi_tex_filter { MI_TEX_EWA = 0, MI_TEX_TRILINEAR = 1, MI_TEX_NONE = 2 /* "noFiltering" */ } mi_tex_filter;
+typedef struct mi_texture {
+    int32_t mipmap;         /* index into mi_scene_desc.mipmaps */
+    int32_t filter;         /* mi_tex_filter */
+    float max_aniso;        /* "maxanisotropy" */
+    float su, sv, du, dv;   /* UVMapping2D */
+} mi_texture;
 
 /* ---- lights */
 typedef enum mi_light_type {
@@ -252,6 +292,8 @@ typedef struct mi_scene_desc {
     float cie_y[MI_NSPEC]; /* SampledSpectrum::Y, for y() guards */
     uint32_t n_envmaps; const mi_envmap *envmaps;
     float rgb_illum[7][MI_NSPEC]; /* rgbIllum2Spect{White,Cyan,Magenta,Yellow,Red,Green,Blue} (spectrum.h:322-398) */
+    uint32_t n_textures; const mi_texture *textures;   /* ABI v5 */
+    uint32_t n_mipmaps;  const mi_mipmap *mipmaps;
 } mi_scene_desc;
 
 /* Counters with the reference's STAT names (src/core/integrator.cpp:48,

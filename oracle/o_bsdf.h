@@ -7,6 +7,7 @@
 #include "../include/mi_pt.h"
 #include "o_math.h"
 #include "o_shapes.h"
+#include "o_texture.h"
 
 namespace orc {
 
@@ -175,8 +176,10 @@ inline Spec FrConductor(Float cosThetaI, const Spec &etai, const Spec &etat, con
 
 struct BxDF {
     const mi_bxdf *b;
-    Spec R() const { return Spec::From(b->R); }
-    Spec S() const { return Spec::From(b->S); }
+    bool texR = false, texS = false;   // the spectrum of this hit comes from an image texture (mi_lobe_tex)
+    Spec Rtex, Stex;
+    Spec R() const { return texR ? Rtex : Spec::From(b->R); }
+    Spec S() const { return texS ? Stex : Spec::From(b->S); }
     Spec K() const { return Spec::From(b->K); }
     Spec Scale() const { return Spec::From(b->scale); }
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
@@ -444,14 +447,42 @@ struct BSDF {
     int nBxDFs;
     BxDF bxdfs[MI_MAX_BXDFS];
 
-    BSDF(const SurfaceInteraction &si, const mi_material &m) {  // reflection.h:170-176
+    // d / td: scene and the hit's texture differentials, for materials with image-textured lobes
+    // (Material::ComputeScatteringFunctions evaluates its textures at the hit and adds a lobe only when the
+    // spectrum it tests is not black, e.g. matte.cpp:55-63, uber.cpp:60-100)
+    BSDF(const SurfaceInteraction &si, const mi_material &m, const mi_scene_desc *d = nullptr, const TexDifferentials *td = nullptr) {  // reflection.h:170-176
         eta = m.eta;
         ns = si.shading.n;
         ng = si.n;
         ss = Normalize(si.shading.dpdu);
         ts = Cross(ns, ss);
-        nBxDFs = m.n_bxdfs;
-        for (int i = 0; i < nBxDFs; ++i) bxdfs[i].b = &m.bxdf[i];
+        nBxDFs = 0;
+        for (int i = 0; i < m.n_bxdfs; ++i) {
+            BxDF bx;
+            bx.b = &m.bxdf[i];
+            const mi_lobe_tex &lt = m.tex[i];
+            if (m.textured && d && td && (lt.tex_R >= 0 || lt.tex_S >= 0)) {
+                bool texBlack = true;
+                if (lt.tex_R >= 0) {
+                    const Spec T = EvalImageTexture(*d, lt.tex_R, si, *td);
+                    texBlack = texBlack && T.IsBlack();
+                    bx.texR = true;
+                    bx.Rtex = (lt.flags & MI_LOBE_TEX_MUL_R) ? Spec::From(bx.b->R) * T : T;
+                }
+                if (lt.tex_S >= 0) {
+                    const Spec T = EvalImageTexture(*d, lt.tex_S, si, *td);
+                    texBlack = texBlack && T.IsBlack();
+                    bx.texS = true;
+                    bx.Stex = (lt.flags & MI_LOBE_TEX_MUL_S) ? Spec::From(bx.b->S) * T : T;
+                }
+                bool present;
+                if (lt.rule == MI_LOBE_IF_R_OR_S) present = !bx.R().IsBlack() || !bx.S().IsBlack();
+                else if (lt.rule == MI_LOBE_IF_TEX) present = !texBlack;
+                else present = !bx.R().IsBlack();
+                if (!present) continue;
+            }
+            bxdfs[nBxDFs++] = bx;
+        }
     }
     int NumComponents(int flags) const {
         int num = 0;

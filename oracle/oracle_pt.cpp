@@ -326,28 +326,6 @@ static void EnvLookup(const mi_envmap &e, const Float st[2], Float rgb[3]) {
                  ds * dt * texel(s0 + 1, t0 + 1, k);
 }
 // Spectrum(rgb, SpectrumType::Illuminant): SampledSpectrum::FromRGB, spectrum.cpp:98-180
-static Spec SpecFromRGBIllum(const mi_scene_desc &d, const Float rgb[3]) {
-    const Spec white = Spec::From(d.rgb_illum[0]), cyan = Spec::From(d.rgb_illum[1]), magenta = Spec::From(d.rgb_illum[2]),
-               yellow = Spec::From(d.rgb_illum[3]), red = Spec::From(d.rgb_illum[4]), green = Spec::From(d.rgb_illum[5]),
-               blue = Spec::From(d.rgb_illum[6]);
-    Spec r;
-    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
-        r += rgb[0] * white;
-        if (rgb[1] <= rgb[2]) { r += (rgb[1] - rgb[0]) * cyan; r += (rgb[2] - rgb[1]) * blue; }
-        else { r += (rgb[2] - rgb[0]) * cyan; r += (rgb[1] - rgb[2]) * green; }
-    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
-        r += rgb[1] * white;
-        if (rgb[0] <= rgb[2]) { r += (rgb[0] - rgb[1]) * magenta; r += (rgb[2] - rgb[0]) * blue; }
-        else { r += (rgb[2] - rgb[1]) * magenta; r += (rgb[0] - rgb[2]) * red; }
-    } else {
-        r += rgb[2] * white;
-        if (rgb[0] <= rgb[1]) { r += (rgb[0] - rgb[2]) * yellow; r += (rgb[1] - rgb[0]) * green; }
-        else { r += (rgb[1] - rgb[2]) * yellow; r += (rgb[0] - rgb[1]) * red; }
-    }
-    r *= .86445f;
-    for (int i = 0; i < NS; ++i) r.c[i] = Clamp(r.c[i], 0, Infinity);
-    return r;
-}
 static V3 Mul3(const float m[9], const V3 &v) {  // Transform::operator()(Vector3f), transform.h:235-240
     return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
 }
@@ -619,13 +597,15 @@ static Spec EstimateDirect(const Scene &scene, const SurfaceInteraction &it, con
     return Ld;
 }
 
-static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r, Sampler &sampler, Counters &c) {
+static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r, Sampler &sampler, Counters &c,
+               const RayDifferential &camDiff = RayDifferential()) {
     // path.cpp:64-188
     const mi_scene_desc &d = scene.d;
     const int maxDepth = d.integrator.max_depth;
     const Float rrThreshold = d.integrator.rr_threshold;
     Spec L(0.f), beta(1.f);
     Ray ray(r);
+    RayDifferential diff = camDiff;   // only the camera ray carries differentials; SpawnRay() returns a plain Ray
     bool specularBounce = false;
     int bounces;
     Float etaScale = 1;
@@ -642,10 +622,14 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
         int matIdx = d.prims[isect.prim].material;
         if (matIdx < 0) {  // !isect.bsdf, path.cpp:108-113
             ray = SpawnRay(isect, ray.d);
+            diff.hasDifferentials = false;
             bounces--;
             continue;
         }
-        BSDF bsdf(isect, d.materials[matIdx]);
+        const mi_material &mat = d.materials[matIdx];
+        TexDifferentials td;
+        if (mat.textured) td = ComputeDifferentials(isect, diff);   // isect.ComputeScatteringFunctions(ray, ...), interaction.cpp:91-97
+        BSDF bsdf(isect, mat, &d, &td);
         const Distribution1D *distrib = lightDistrib.Lookup(isect.p);
         if (bsdf.NumComponents(MI_BSDF_ALL & ~MI_BSDF_SPECULAR) > 0) {
             ++c.totalPaths;
@@ -679,6 +663,7 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
             etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
         }
         ray = SpawnRay(isect, wi);
+        diff.hasDifferentials = false;
         Spec rrBeta = beta * etaScale;
         if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
             Float q = std::max((Float).05, 1 - rrBeta.MaxComponentValue());
@@ -691,8 +676,8 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
 }
 
 // ------------------------------------------------------------------ camera
-static Ray GenerateRay(const mi_scene_desc &d, const Float pFilm[2], const Float pLens[2]) {
-    // perspective.cpp:95-146 (differentials are only consumed by textures; constant here)
+static Ray GenerateRay(const mi_scene_desc &d, const Float pFilm[2], const Float pLens[2], RayDifferential *rd = nullptr) {
+    // PerspectiveCamera::GenerateRayDifferential, perspective.cpp:95-146
     const mi_camera &cam = d.camera;
     V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilm[0], pFilm[1], 0));
     V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
@@ -705,6 +690,37 @@ static Ray GenerateRay(const mi_scene_desc &d, const Float pFilm[2], const Float
         V3 pFocus = ray(ft);
         ray.o = V3(lx, ly, 0);
         ray.d = Normalize(pFocus - ray.o);
+    }
+    if (rd) {
+        // dxCamera, dyCamera: perspective.cpp:54-58
+        const V3 r0 = XfPoint(cam.raster_to_camera, V3(0, 0, 0));
+        const V3 dxCamera = XfPoint(cam.raster_to_camera, V3(1, 0, 0)) - r0, dyCamera = XfPoint(cam.raster_to_camera, V3(0, 1, 0)) - r0;
+        V3 rxO, ryO, rxD, ryD;
+        if (cam.lens_radius > 0) {
+            Float dl[2];
+            ConcentricSampleDisk(pLens, dl);
+            Float lx = cam.lens_radius * dl[0], ly = cam.lens_radius * dl[1];
+            V3 dx = Normalize(V3(pCamera + dxCamera));
+            Float ft = cam.focal_distance / dx.z;
+            V3 pFocus = V3(0, 0, 0) + (ft * dx);
+            rxO = V3(lx, ly, 0);
+            rxD = Normalize(pFocus - rxO);
+            V3 dy = Normalize(V3(pCamera + dyCamera));
+            ft = cam.focal_distance / dy.z;
+            pFocus = V3(0, 0, 0) + (ft * dy);
+            ryO = V3(lx, ly, 0);
+            ryD = Normalize(pFocus - ryO);
+        } else {
+            rxO = ryO = ray.o;
+            rxD = Normalize(V3(pCamera) + dxCamera);
+            ryD = Normalize(V3(pCamera) + dyCamera);
+        }
+        // Transform::operator()(RayDifferential), transform.h:268-277
+        rd->rxOrigin = XfPoint(cam.camera_to_world, rxO);
+        rd->ryOrigin = XfPoint(cam.camera_to_world, ryO);
+        rd->rxDirection = XfVector(cam.camera_to_world, rxD);
+        rd->ryDirection = XfVector(cam.camera_to_world, ryD);
+        rd->hasDifferentials = true;
     }
     return XfRay(cam.camera_to_world, ray);
 }
@@ -803,9 +819,11 @@ struct RenderJob {
                     const int deltaIndex = (int)std::round((float)NS / (float)nBands);
                     Spec L(0.f);
                     for (int band = 0; band < nBands; ++band) {
-                        Ray ray = GenerateRay(d, pFilm, pLens);
+                        RayDifferential rd;
+                        Ray ray = GenerateRay(d, pFilm, pLens, &rd);
+                        rd.ScaleDifferentials(ray.o, ray.d, 1 / std::sqrt((Float)d.sampler.samples_per_pixel));  // integrator.cpp:286-287
                         ++c.cameraRays;
-                        Spec Ls = Li(scene, lightDistrib, ray, sampler, c);
+                        Spec Ls = Li(scene, lightDistrib, ray, sampler, c, rd);
                         if (Ls.HasNaNs()) { Ls = Spec(0.f); ++c.badSamples; }
                         else if (SpecY(d, Ls) < -1e-5) { Ls = Spec(0.f); ++c.badSamples; }
                         else if (std::isinf(SpecY(d, Ls))) { Ls = Spec(0.f); ++c.badSamples; }
@@ -893,9 +911,11 @@ void oracle_li(const mi_scene_desc *desc, const int32_t *samples, int n, float *
         Float pFilm[2] = {(Float)px + u[0], (Float)py + u[1]};
         (void)sampler.Get1D();
         sampler.Get2D(pLens);
-        Ray ray = GenerateRay(*desc, pFilm, pLens);
+        RayDifferential rd;
+        Ray ray = GenerateRay(*desc, pFilm, pLens, &rd);
+        rd.ScaleDifferentials(ray.o, ray.d, 1 / std::sqrt((Float)desc->sampler.samples_per_pixel));
         ++c.cameraRays;
-        Spec L = Li(scene, ld, ray, sampler, c);
+        Spec L = Li(scene, ld, ray, sampler, c, rd);
         for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = L.c[k];
     }
     FillCounters(c, counters);
@@ -1024,6 +1044,18 @@ void oracle_distribution1d(const float *func, int n, float u, int mode, float *o
         const int index = (int)u;
         out[0] = dist.func[index] / (dist.funcInt * dist.Count());
     }
+}
+
+// MIPMap<RGBSpectrum>::Lookup(st, dstdx, dstdy) of image texture `tex` (mipmap.h:281-319), and the spectrum
+// ImageTexture::Evaluate makes of it (imagemap.h:82-93): out[0..2] = RGB, out[3..33] = Spectrum::FromRGB(rgb).
+void oracle_texture_lookup(const mi_scene_desc *desc, int tex, const float *st2, const float *d4, float *out34) {
+    const mi_texture &t = desc->textures[tex];
+    MipView mip{desc->mipmaps[t.mipmap]};
+    const Float st[2] = {st2[0], st2[1]}, dx[2] = {d4[0], d4[1]}, dy[2] = {d4[2], d4[3]};
+    const RGB3 v = mip.Lookup(st, dx, dy, t.filter, t.max_aniso);
+    for (int i = 0; i < 3; ++i) out34[i] = v.c[i];
+    const Spec sp = SpecFromRGBIllum(*desc, v.c);
+    for (int i = 0; i < NS; ++i) out34[3 + i] = sp.c[i];
 }
 
 }  // extern "C"

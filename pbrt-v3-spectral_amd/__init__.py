@@ -49,9 +49,26 @@ class Bxdf(C.Structure):
                 ("K", C.c_float * NSPEC), ("scale", C.c_float * NSPEC)]
 
 
+class LobeTex(C.Structure):
+    _fields_ = [("tex_R", C.c_int32), ("tex_S", C.c_int32), ("flags", C.c_uint32), ("rule", C.c_int32)]
+
+
 class Material(C.Structure):
-    _fields_ = [("n_bxdfs", C.c_int32), ("eta", C.c_float), ("kind", C.c_int32), ("pad", C.c_int32),
-                ("bxdf", Bxdf * MAX_BXDFS)]
+    _fields_ = [("n_bxdfs", C.c_int32), ("eta", C.c_float), ("kind", C.c_int32), ("textured", C.c_int32),
+                ("bxdf", Bxdf * MAX_BXDFS), ("tex", LobeTex * MAX_BXDFS)]
+
+
+MAX_MIP_LEVELS = 16
+
+
+class MipMap(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("wrap", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("texels", C.POINTER(C.c_float)), ("level_offset", C.c_uint32 * MAX_MIP_LEVELS)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("mipmap", C.c_int32), ("filter", C.c_int32), ("max_aniso", C.c_float),
+                ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float)]
 
 
 class Light(C.Structure):
@@ -109,7 +126,9 @@ class SceneDesc(C.Structure):
                 ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
                 ("light_distrib", LightDistrib), ("camera", Camera), ("film", Film), ("sampler", Sampler),
                 ("integrator", Integrator), ("cie_y", C.c_float * NSPEC),
-                ("n_envmaps", C.c_uint32), ("envmaps", C.POINTER(EnvMap)), ("rgb_illum", (C.c_float * NSPEC) * 7)]
+                ("n_envmaps", C.c_uint32), ("envmaps", C.POINTER(EnvMap)), ("rgb_illum", (C.c_float * NSPEC) * 7),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture)),
+                ("n_mipmaps", C.c_uint32), ("mipmaps", C.POINTER(MipMap))]
 
 
 class Counters(C.Structure):

@@ -197,6 +197,56 @@ DEV float FrConductorBin(float cos2, float sin2, float twoCos, float etaT, float
     return (Rp + Rs) * 0.5f;
 }
 
+// Spectrum::FromRGB(rgb, type) (SampledSpectrum::FromRGB, spectrum.cpp:98-180) reduced to scalars:
+// bin value = Clamp(((0 + white*w0) + basis[i1]*w1) + basis[i2]*w2) * .86445f, 0, inf).
+struct IllumRGB {
+    int i1, i2;
+    float w0, w1, w2;
+};
+DEV IllumRGB MakeIllumRGB(const float rgb[3]) {
+    IllumRGB q;
+    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
+        q.w0 = rgb[0];
+        if (rgb[1] <= rgb[2]) { q.i1 = 1; q.w1 = rgb[1] - rgb[0]; q.i2 = 6; q.w2 = rgb[2] - rgb[1]; }
+        else { q.i1 = 1; q.w1 = rgb[2] - rgb[0]; q.i2 = 5; q.w2 = rgb[1] - rgb[2]; }
+    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
+        q.w0 = rgb[1];
+        if (rgb[0] <= rgb[2]) { q.i1 = 2; q.w1 = rgb[0] - rgb[1]; q.i2 = 6; q.w2 = rgb[2] - rgb[0]; }
+        else { q.i1 = 2; q.w1 = rgb[2] - rgb[1]; q.i2 = 4; q.w2 = rgb[0] - rgb[2]; }
+    } else {
+        q.w0 = rgb[2];
+        if (rgb[0] <= rgb[1]) { q.i1 = 3; q.w1 = rgb[0] - rgb[2]; q.i2 = 5; q.w2 = rgb[1] - rgb[0]; }
+        else { q.i1 = 3; q.w1 = rgb[1] - rgb[2]; q.i2 = 4; q.w2 = rgb[0] - rgb[1]; }
+    }
+    return q;
+}
+
+// Image-textured lobes of the material at this vertex (mi_lobe_tex): per material lobe the texture value in FromRGB's
+// compact form; bit i of hasR / hasS: lobe i takes R / S from it, of mulR / mulS: multiplied onto the constant.
+template <int NL>
+struct LobeTexT {
+    unsigned hasR, hasS, mulR, mulS;
+    IllumRGB r[NL], s[NL];
+    const float *basis;     // rgbIllum2Spect{White..Blue}, [7][31]: FromRGB's default type is Illuminant (spectrum.h:428-429)
+};
+// Bin of Spectrum::FromRGB(rgb).Clamp(): Clamp((((0 + white*w0) + basis[i1]*w1) + basis[i2]*w2) * .86445f, 0, inf)
+DEV float TexBin(const float *basis, const IllumRGB &q, int bin) {
+    float r = 0.f;
+    r += basis[bin] * q.w0;
+    r += basis[q.i1 * MI_NSPEC + bin] * q.w1;
+    r += basis[q.i2 * MI_NSPEC + bin] * q.w2;
+    r *= .86445f;
+    return clampf(r, 0.f, kInfinity);
+}
+// R (which = 0) or S (which = 1) of material lobe li at a bin, with the texture applied
+template <int NL>
+DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int bin) {
+    const float c = which ? b.S[bin] : b.R[bin];
+    if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return c;
+    const float T = TexBin(lt.basis, which ? lt.s[li] : lt.r[li], bin);
+    return (((which ? lt.mulS : lt.mulR) >> li) & 1u) ? c * T : T;
+}
+
 // Lobe-type masks: the shading kernel is instantiated for sets of BxDF types (bit = mi_bxdf_type, bits 16.. =
 // mi_fresnel_type), so that a wave shading matte surfaces carries no microfacet or Disney code and registers.
 // The guards compile the other cases out; a lobe outside the mask cannot occur (the host picks the kernel from
@@ -205,7 +255,8 @@ DEV float FrConductorBin(float cos2, float sin2, float twoCos, float etaT, float
 #define TM_FRESNEL(tm, f) ((((tm) >> (16 + (f))) & 1u) != 0u)
 #define TM_SPECULAR(tm) (TM_HAS(tm, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(tm, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(tm, MI_BXDF_FRESNEL_SPECULAR))
 constexpr unsigned TM_ALL = 0xffffffffu;
-constexpr unsigned TM_SCALED = 1u << 31;   // some lobe is a ScaledBxDF (mix material)
+constexpr unsigned TM_SCALED = 1u << 31;
+constexpr unsigned TM_TEXTURED = 1u << 30;  // some lobe takes its spectrum from an image texture  // some lobe is a ScaledBxDF (mix material)
 #define TM_LIGHT(tm, t) ((((tm) >> (24 + (t))) & 1u) != 0u)   // bits 24..: mi_light_type present in the scene
 constexpr unsigned TM_LIGHTS_ALL = 0x1fu << 24;
 constexpr unsigned TM_LIGHTS_NO_ENV = TM_LIGHTS_ALL & ~(1u << (24 + MI_LIGHT_INFINITE));
@@ -247,19 +298,24 @@ DEV float LobeValueCore(const LobeEval &le, float R, float Sv, float Kv) {  // R
 // Which of a lobe's other spectra its value reads (compile-time, from the kernel's lobe mask).
 #define TM_NEEDS_S(tm) (TM_FRESNEL(tm, MI_FRESNEL_CONDUCTOR) || TM_FRESNEL(tm, MI_FRESNEL_DISNEY) || TM_HAS(tm, MI_BXDF_FRESNEL_BLEND))
 #define TM_NEEDS_K(tm) (TM_FRESNEL(tm, MI_FRESNEL_CONDUCTOR))
-template <unsigned TM>
-DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin) {
+template <int NL, unsigned TM>
+DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin, const LobeTexT<NL> *lt) {
     const int li = le.lobe & 0xff;  // bit 8 set: the lobe's second spectrum (T of FresnelSpecular)
-    const float R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
-    float Sv = 0.f, Kv = 0.f;
-    if constexpr (TM_NEEDS_S(TM)) Sv = bx[li].S[bin];
+    float R, Sv = 0.f, Kv = 0.f;
+    if constexpr ((TM & TM_TEXTURED) != 0) {
+        R = TexturedSpec(*lt, bx[li], li, (le.lobe & 0x100) ? 1 : 0, bin);
+        if constexpr (TM_NEEDS_S(TM)) Sv = TexturedSpec(*lt, bx[li], li, 1, bin);
+    } else {
+        R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
+        if constexpr (TM_NEEDS_S(TM)) Sv = bx[li].S[bin];
+    }
     if constexpr (TM_NEEDS_K(TM)) Kv = bx[li].K[bin];
     return LobeValueCore<TM>(le, R, Sv, Kv);
 }
 // bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
-template <unsigned TM>
-DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
-    const float v = LobeValueInner<TM>(le, bx, bin);
+template <int NL, unsigned TM>
+DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin, const LobeTexT<NL> *lt) {
+    const float v = LobeValueInner<NL, TM>(le, bx, bin, lt);
     if constexpr ((TM & TM_SCALED) == 0) return v;
     return (le.lobe & 0x200) ? bx[le.lobe & 0xff].scale[bin] * v : v;
 }
@@ -267,6 +323,8 @@ DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin) {
 struct BSDFFrame {
     V3 ns, ng, ss, ts;
     const mi_material *m;
+    unsigned mask;   // bit i: lobe i of m is part of the BSDF at this vertex (textured lobes drop out where their texture is black)
+    DEV bool On(int i) const { return ((mask >> i) & 1u) != 0u; }
     DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
     DEV V3 LocalToWorld(const V3 &v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
@@ -274,9 +332,10 @@ struct BSDFFrame {
     }
 };
 DEV bool MatchesFlags(const mi_bxdf &b, int t) { return (b.flags & t) == b.flags; }
-DEV int NumComponents(const mi_material *m, int flags) {
+DEV int NumComponents(const BSDFFrame &fr, int flags) {
+    const mi_material *m = fr.m;
     int num = 0;
-    for (int i = 0; i < m->n_bxdfs; ++i) if (MatchesFlags(m->bxdf[i], flags)) ++num;
+    for (int i = 0; i < m->n_bxdfs; ++i) if (fr.On(i) && MatchesFlags(m->bxdf[i], flags)) ++num;
     return num;
 }
 DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.f}; }
@@ -470,7 +529,7 @@ DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BS
     const mi_material *m = fr.m;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        if (i < m->n_bxdfs) {
+        if (i < m->n_bxdfs && fr.On(i)) {
             const mi_bxdf &b = m->bxdf[i];
             if (MatchesFlags(b, flags) &&
                 ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION)))) {
@@ -483,22 +542,22 @@ DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BS
 template <unsigned TM>
 DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags) {  // reflection.cpp:770-785
     const mi_material *m = fr.m;
-    if (m->n_bxdfs == 0) return 0.f;
+    if (m->n_bxdfs == 0 || (fr.mask & ((1u << m->n_bxdfs) - 1u)) == 0u) return 0.f;
     V3 wo = fr.WorldToLocal(woW), wi = fr.WorldToLocal(wiW);
     if (wo.z == 0) return 0.;
     float pdf = 0.f;
     int matchingComps = 0;
     for (int i = 0; i < m->n_bxdfs; ++i)
-        if (MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf<TM>(m->bxdf[i], wo, wi); }
+        if (fr.On(i) && MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf<TM>(m->bxdf[i], wo, wi); }
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 
 template <int NL, unsigned TM>
-DEV float EvalBin(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int bin) {
+DEV float EvalBin(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int bin, const LobeTexT<NL> *lt) {
     float f = 0.f;
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-        if (i < ev.n) f += LobeValue<TM>(ev.lobes[i], bx, bin);
+        if (i < ev.n) f += LobeValue<NL, TM>(ev.lobes[i], bx, bin, lt);
     return f;
 }
 
@@ -513,11 +572,11 @@ DEV float4 LoadSpec4(const float *spec, int c) {
 }
 DEV float Quad(const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 template <int NL, unsigned TM>
-DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c) {
-    if constexpr (NL > 2) {   // long lobe lists: the quads of all lobes would not fit the register file
+DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c, const LobeTexT<NL> *lt) {
+    if constexpr (NL > 2 || (TM & TM_TEXTURED) != 0) {   // long lobe lists: the quads of all lobes would not fit the register file
         const int b = 4 * c;
-        return make_float4(EvalBin<NL, TM>(ev, bx, b), EvalBin<NL, TM>(ev, bx, b + 1), EvalBin<NL, TM>(ev, bx, b + 2),
-                           (b + 3 < MI_NSPEC) ? EvalBin<NL, TM>(ev, bx, b + 3) : 0.f);
+        return make_float4(EvalBin<NL, TM>(ev, bx, b, lt), EvalBin<NL, TM>(ev, bx, b + 1, lt), EvalBin<NL, TM>(ev, bx, b + 2, lt),
+                           (b + 3 < MI_NSPEC) ? EvalBin<NL, TM>(ev, bx, b + 3, lt) : 0.f);
     }
     float4 R[NL], Sv[NL], Kv[NL], Sc[NL];
 #pragma unroll
@@ -554,12 +613,12 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
                        int *sampledType, BSDFEvalT<NL> *ev) {
     const mi_material *m = fr.m;
     ev->n = 0;
-    int matchingComps = NumComponents(m, type);
+    int matchingComps = NumComponents(fr, type);
     if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return false; }
     int comp = min((int)floorf(u0 * matchingComps), matchingComps - 1);
     int bi = -1, count = comp;
     for (int i = 0; i < m->n_bxdfs; ++i)
-        if (MatchesFlags(m->bxdf[i], type) && count-- == 0) { bi = i; break; }
+        if (fr.On(i) && MatchesFlags(m->bxdf[i], type) && count-- == 0) { bi = i; break; }
     const mi_bxdf &b = m->bxdf[bi];
     float ur0 = minf(u0 * matchingComps - comp, kOneMinusEpsilon), ur1 = u1;
     V3 wi, wo = fr.WorldToLocal(woWorld);
@@ -665,7 +724,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *wiWorld = fr.LocalToWorld(wi);
     if (!isSpecular && matchingComps > 1)
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (i != bi && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi);
+            if (i != bi && fr.On(i) && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi);
     if (matchingComps > 1) *pdf /= matchingComps;
     if (isSpecular) {
         ev->n = 1;
@@ -674,7 +733,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
         bool reflect = Dot(*wiWorld, fr.ng) * Dot(woWorld, fr.ng) > 0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            if (i < m->n_bxdfs) {
+            if (i < m->n_bxdfs && fr.On(i)) {
                 const mi_bxdf &bb = m->bxdf[i];
                 if (MatchesFlags(bb, type) &&
                     ((reflect && (bb.flags & MI_BSDF_REFLECTION)) || (!reflect && (bb.flags & MI_BSDF_TRANSMISSION)))) {

@@ -165,30 +165,7 @@ DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &re
 
 DEV bool IsDeltaLight(const mi_light &l) { return l.type == MI_LIGHT_POINT || l.type == MI_LIGHT_DISTANT || l.type == MI_LIGHT_SPOT; }
 
-// ---- InfiniteAreaLight (src/lights/infinite.cpp:85-141)
-// Spectrum(rgb, SpectrumType::Illuminant) (SampledSpectrum::FromRGB, spectrum.cpp:98-180) reduced to scalars:
-// bin value = Clamp(((0 + white*w0) + basis[i1]*w1) + basis[i2]*w2) * .86445f, 0, inf).
-struct IllumRGB {
-    int i1, i2;
-    float w0, w1, w2;
-};
-DEV IllumRGB MakeIllumRGB(const float rgb[3]) {
-    IllumRGB q;
-    if (rgb[0] <= rgb[1] && rgb[0] <= rgb[2]) {
-        q.w0 = rgb[0];
-        if (rgb[1] <= rgb[2]) { q.i1 = 1; q.w1 = rgb[1] - rgb[0]; q.i2 = 6; q.w2 = rgb[2] - rgb[1]; }
-        else { q.i1 = 1; q.w1 = rgb[2] - rgb[0]; q.i2 = 5; q.w2 = rgb[1] - rgb[2]; }
-    } else if (rgb[1] <= rgb[0] && rgb[1] <= rgb[2]) {
-        q.w0 = rgb[1];
-        if (rgb[0] <= rgb[2]) { q.i1 = 2; q.w1 = rgb[0] - rgb[1]; q.i2 = 6; q.w2 = rgb[2] - rgb[0]; }
-        else { q.i1 = 2; q.w1 = rgb[2] - rgb[1]; q.i2 = 4; q.w2 = rgb[0] - rgb[2]; }
-    } else {
-        q.w0 = rgb[2];
-        if (rgb[0] <= rgb[1]) { q.i1 = 3; q.w1 = rgb[0] - rgb[2]; q.i2 = 5; q.w2 = rgb[1] - rgb[0]; }
-        else { q.i1 = 3; q.w1 = rgb[1] - rgb[2]; q.i2 = 4; q.w2 = rgb[0] - rgb[1]; }
-    }
-    return q;
-}
+// ---- InfiniteAreaLight (src/lights/infinite.cpp:85-141); IllumRGB / MakeIllumRGB: d_bsdf.h
 DEV float IllumBin(const DScene &s, const IllumRGB &q, int bin) {
     float r = 0.f;
     r += s.rgbIllum[bin] * q.w0;

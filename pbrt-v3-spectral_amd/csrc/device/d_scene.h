@@ -48,6 +48,12 @@ struct DScene {
     const uint16_t *perms;
     const uint64_t *primeMagic;        // ceil(2^64 / prime): a / prime == umul64hi(a, magic) for a < 2^32
     const uint32_t *pixelOffsetTable;  // 128x128 Halton per-pixel index offsets (halton.cpp:98-118)
+    // image textures (ABI v5): device copies of mi_texture / mi_mipmap (texel pointers in HBM),
+    // MIPMap::weightLut (mipmap.h:199-206, tabulated by the host), 1 / sqrt(samplesPerPixel) for ScaleDifferentials
+    const mi_texture *textures;
+    const mi_mipmap *mipmaps;
+    const float *ewaWeights;
+    float invSqrtSpp;
     const float *filterTable;  // 256 floats
     float cieY[MI_NSPEC];
     const mi_envmap *envmaps;      // device copies: the pointers inside point to device memory

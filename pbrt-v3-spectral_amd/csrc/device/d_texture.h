@@ -1,0 +1,212 @@
+// d_texture.h -- image textures at a path vertex (ABI v5: mi_texture / mi_mipmap / mi_lobe_tex).
+//   SurfaceInteraction::ComputeDifferentials          src/core/interaction.cpp:99-143
+//   UVMapping2D::Map                                  src/core/texture.cpp:91-99
+//   MIPMap::Lookup (trilinear, EWA), triangle, Texel  src/core/mipmap.h:213-385
+//   convertOut + SampledSpectrum::FromRGB (Illuminant, its default) src/textures/imagemap.h:113-117, src/core/spectrum.cpp:98-180
+// The pyramid is the host's (the reference's own construction); only the per-hit lookup runs here. A texture value
+// stays in the compact form of FromRGB (two basis indices, three weights) and its 31 bins are formed where the
+// spectral loops need them, like every other spectrum on this path.
+#pragma once
+#include "d_sampling.h"
+
+namespace dpt {
+
+struct CamDifferentials {  // RayDifferential's offset rays (geometry.h:897-931)
+    V3 rxOrigin, ryOrigin, rxDirection, ryDirection;
+};
+
+// PerspectiveCamera::GenerateRayDifferential (perspective.cpp:95-146) + ScaleDifferentials(s) (geometry.h:917-922)
+// for the camera sample (pFilm, lens) whose main ray is (o, d) in world space.
+DEV CamDifferentials CameraDifferentials(const DScene &s, float pFilmX, float pFilmY, float lensU, float lensV, const V3 &o, const V3 &d,
+                                         float scale) {
+    const mi_camera &cam = s.camera;
+    const V3 pCamera = XfPoint(cam.raster_to_camera, V3(pFilmX, pFilmY, 0));
+    const V3 r0 = XfPoint(cam.raster_to_camera, V3(0, 0, 0));
+    const V3 dxCamera = XfPoint(cam.raster_to_camera, V3(1, 0, 0)) - r0, dyCamera = XfPoint(cam.raster_to_camera, V3(0, 1, 0)) - r0;
+    V3 rxO, ryO, rxD, ryD;
+    if (cam.lens_radius > 0) {
+        float lx, ly;
+        ConcentricSampleDisk(lensU, lensV, &lx, &ly);
+        lx = cam.lens_radius * lx; ly = cam.lens_radius * ly;
+        V3 dx = Normalize(pCamera + dxCamera);
+        float ft = cam.focal_distance / dx.z;
+        V3 pFocus = V3(0, 0, 0) + (ft * dx);
+        rxO = V3(lx, ly, 0);
+        rxD = Normalize(pFocus - rxO);
+        V3 dy = Normalize(pCamera + dyCamera);
+        ft = cam.focal_distance / dy.z;
+        pFocus = V3(0, 0, 0) + (ft * dy);
+        ryO = V3(lx, ly, 0);
+        ryD = Normalize(pFocus - ryO);
+    } else {
+        rxO = ryO = V3(0, 0, 0);
+        rxD = Normalize(pCamera + dxCamera);
+        ryD = Normalize(pCamera + dyCamera);
+    }
+    CamDifferentials c;
+    c.rxOrigin = XfPoint(cam.camera_to_world, rxO);
+    c.ryOrigin = XfPoint(cam.camera_to_world, ryO);
+    c.rxDirection = XfVector(cam.camera_to_world, rxD);
+    c.ryDirection = XfVector(cam.camera_to_world, ryD);
+    c.rxOrigin = o + (c.rxOrigin - o) * scale;
+    c.ryOrigin = o + (c.ryOrigin - o) * scale;
+    c.rxDirection = d + (c.rxDirection - d) * scale;
+    c.ryDirection = d + (c.ryDirection - d) * scale;
+    return c;
+}
+
+struct TexDifferentials { float dudx, dvdx, dudy, dvdy; };
+
+DEV bool SolveLinearSystem2x2(const float A[2][2], const float B[2], float *x0, float *x1) {  // transform.cpp:41-49
+    float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    if (absf(det) < 1e-10f) return false;
+    *x0 = (A[1][1] * B[0] - A[0][1] * B[1]) / det;
+    *x1 = (A[0][0] * B[1] - A[1][0] * B[0]) / det;
+    if (isnanf_(*x0) || isnanf_(*x1)) return false;
+    return true;
+}
+
+DEV TexDifferentials ComputeDifferentials(const V3 &p, const V3 &n, const V3 &dpdu, const V3 &dpdv, const CamDifferentials &ray) {
+    TexDifferentials t;
+    t.dudx = t.dvdx = t.dudy = t.dvdy = 0;
+    float d = Dot(n, V3(p.x, p.y, p.z));
+    float tx = -(Dot(n, ray.rxOrigin) - d) / Dot(n, ray.rxDirection);
+    if (isinff(tx) || isnanf_(tx)) return t;
+    V3 px = ray.rxOrigin + tx * ray.rxDirection;
+    float ty = -(Dot(n, ray.ryOrigin) - d) / Dot(n, ray.ryDirection);
+    if (isinff(ty) || isnanf_(ty)) return t;
+    V3 py = ray.ryOrigin + ty * ray.ryDirection;
+    int dim0, dim1;
+    if (absf(n.x) > absf(n.y) && absf(n.x) > absf(n.z)) { dim0 = 1; dim1 = 2; }
+    else if (absf(n.y) > absf(n.z)) { dim0 = 0; dim1 = 2; }
+    else { dim0 = 0; dim1 = 1; }
+    float A[2][2] = {{dpdu[dim0], dpdv[dim0]}, {dpdu[dim1], dpdv[dim1]}};
+    float Bx[2] = {px[dim0] - p[dim0], px[dim1] - p[dim1]};
+    float By[2] = {py[dim0] - p[dim0], py[dim1] - p[dim1]};
+    if (!SolveLinearSystem2x2(A, Bx, &t.dudx, &t.dvdx)) t.dudx = t.dvdx = 0;
+    if (!SolveLinearSystem2x2(A, By, &t.dudy, &t.dvdy)) t.dudy = t.dvdy = 0;
+    return t;
+}
+
+// (u, v) of a triangle hit and the geometric dpdv that goes with TriInteraction's dpdu (triangle.cpp:293-330)
+DEV void TriTexCoords(const DScene &s, int tri, float b0, float b1, float b2, float *u, float *v, V3 *dpdv) {
+    const int32_t *vi = &s.triIndices[3 * tri];
+    V3 p0 = LoadV3(s.P, vi[0]), p1 = LoadV3(s.P, vi[1]), p2 = LoadV3(s.P, vi[2]);
+    const mi_mesh m = s.meshes[s.triMesh[tri]];
+    float uv[3][2];
+    GetUVs(s, tri, m, uv);
+    V3 dpdu;
+    TriPartials(p0, p1, p2, uv, &dpdu, dpdv);
+    *u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+    *v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+}
+
+struct RGB3 {
+    float r, g, b;
+    DEV RGB3() : r(0), g(0), b(0) {}
+    DEV RGB3(float r, float g, float b) : r(r), g(g), b(b) {}
+    DEV RGB3 operator+(const RGB3 &o) const { return RGB3(r + o.r, g + o.g, b + o.b); }
+    DEV RGB3 operator*(float a) const { return RGB3(r * a, g * a, b * a); }
+};
+DEV RGB3 operator*(float a, const RGB3 &s) { return s * a; }
+
+DEV int MipUSize(const mi_mipmap &m, int level) { return max(1, m.width >> level); }
+DEV int MipVSize(const mi_mipmap &m, int level) { return max(1, m.height >> level); }
+DEV RGB3 MipTexel(const mi_mipmap &m, int level, int s, int t) {  // mipmap.h:213-235
+    const int w = MipUSize(m, level), h = MipVSize(m, level);
+    if (m.wrap == 0) { s = ModI(s, w); t = ModI(t, h); }
+    else if (m.wrap == 2) { s = min(max(s, 0), w - 1); t = min(max(t, 0), h - 1); }
+    else if (s < 0 || s >= w || t < 0 || t >= h) return RGB3();
+    const float *px = m.texels + 3 * ((size_t)m.level_offset[level] + (size_t)t * w + s);
+    return RGB3(px[0], px[1], px[2]);
+}
+DEV RGB3 MipTriangle(const mi_mipmap &m, int level, float st0, float st1) {  // mipmap.h:268-279
+    level = min(max(level, 0), m.n_levels - 1);
+    float s = st0 * MipUSize(m, level) - 0.5f;
+    float t = st1 * MipVSize(m, level) - 0.5f;
+    int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    float ds = s - s0, dt = t - t0;
+    return (1 - ds) * (1 - dt) * MipTexel(m, level, s0, t0) + (1 - ds) * dt * MipTexel(m, level, s0, t0 + 1) +
+           ds * (1 - dt) * MipTexel(m, level, s0 + 1, t0) + ds * dt * MipTexel(m, level, s0 + 1, t0 + 1);
+}
+DEV float Log2F(float x) { const float invLog2 = 1.442695040888963387004650940071; return logF(x) * invLog2; }
+DEV RGB3 MipLookupWidth(const mi_mipmap &m, float st0, float st1, float width, bool noFiltering) {  // mipmap.h:238-266
+    if (noFiltering) {
+        float s = st0 * MipUSize(m, 0) - 0.5f;
+        float t = st1 * MipVSize(m, 0) - 0.5f;
+        return MipTexel(m, 0, (int)roundf(s), (int)roundf(t));
+    }
+    float level = m.n_levels - 1 + Log2F(maxf(width, 1e-8f));
+    if (level < 0) return MipTriangle(m, 0, st0, st1);
+    else if (level >= m.n_levels - 1) return MipTexel(m, m.n_levels - 1, 0, 0);
+    int iLevel = (int)floorf(level);
+    float delta = level - iLevel;
+    return (1 - delta) * MipTriangle(m, iLevel, st0, st1) + delta * MipTriangle(m, iLevel + 1, st0, st1);
+}
+DEV RGB3 MipEWA(const DScene &s, const mi_mipmap &m, int level, float st0, float st1, float d00, float d01, float d10, float d11) {  // mipmap.h:321-380
+    if (level >= m.n_levels) return MipTexel(m, m.n_levels - 1, 0, 0);
+    const int us = MipUSize(m, level), vs = MipVSize(m, level);
+    st0 = st0 * us - 0.5f;
+    st1 = st1 * vs - 0.5f;
+    d00 *= us; d01 *= vs; d10 *= us; d11 *= vs;
+    float A = d01 * d01 + d11 * d11 + 1;
+    float B = -2 * (d00 * d01 + d10 * d11);
+    float C = d00 * d00 + d10 * d10 + 1;
+    float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    float det = -B * B + 4 * A * C;
+    float invDet = 1 / det;
+    float uSqrt = __builtin_sqrtf(det * C), vSqrt = __builtin_sqrtf(A * det);
+    int s0 = (int)ceilf(st0 - 2 * invDet * uSqrt);
+    int s1 = (int)floorf(st0 + 2 * invDet * uSqrt);
+    int t0 = (int)ceilf(st1 - 2 * invDet * vSqrt);
+    int t1 = (int)floorf(st1 + 2 * invDet * vSqrt);
+    RGB3 sum;
+    float sumWts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        float tt = it - st1;
+        for (int is = s0; is <= s1; ++is) {
+            float ss = is - st0;
+            float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = min((int)(r2 * 128), 128 - 1);
+                float weight = s.ewaWeights[index];
+                sum = sum + MipTexel(m, level, is, it) * weight;
+                sumWts += weight;
+            }
+        }
+    }
+    return RGB3(sum.r / sumWts, sum.g / sumWts, sum.b / sumWts);
+}
+DEV RGB3 MipLookup(const DScene &s, const mi_mipmap &m, float st0, float st1, float dx0, float dx1, float dy0, float dy1, int filter,
+                   float maxAnisotropy) {  // mipmap.h:281-319
+    if (filter != MI_TEX_EWA) {
+        float width = maxf(maxf(absf(dx0), absf(dx1)), maxf(absf(dy0), absf(dy1)));
+        return MipLookupWidth(m, st0, st1, 2 * width, filter == MI_TEX_NONE);
+    }
+    float a0 = dx0, a1 = dx1, b0 = dy0, b1 = dy1;   // dst0 = a, dst1 = b
+    if (a0 * a0 + a1 * a1 < b0 * b0 + b1 * b1) { float t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }
+    float majorLength = __builtin_sqrtf(a0 * a0 + a1 * a1);
+    float minorLength = __builtin_sqrtf(b0 * b0 + b1 * b1);
+    if (minorLength * maxAnisotropy < majorLength && minorLength > 0) {
+        float scale = majorLength / (minorLength * maxAnisotropy);
+        b0 *= scale; b1 *= scale;
+        minorLength *= scale;
+    }
+    if (minorLength == 0) return MipTriangle(m, 0, st0, st1);
+    float lod = maxf(0.f, m.n_levels - 1.f + Log2F(minorLength));
+    int ilod = (int)floorf(lod);
+    float t = lod - ilod;
+    return (1 - t) * MipEWA(s, m, ilod, st0, st1, a0, a1, b0, b1) + t * MipEWA(s, m, ilod + 1, st0, st1, a0, a1, b0, b1);
+}
+
+// Texture<Spectrum>::Evaluate(si) of image texture `tex` in FromRGB's compact form (see IllumRGB)
+DEV IllumRGB EvalImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
+    const mi_texture &t = s.textures[tex];
+    const mi_mipmap &m = s.mipmaps[t.mipmap];
+    const RGB3 mem = MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy,
+                               t.filter, t.max_aniso);
+    const float rgb[3] = {mem.r, mem.g, mem.b};
+    return MakeIllumRGB(rgb);
+}
+}  // namespace dpt

@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 #include "d_sampling.h"
+#include "d_texture.h"
 
 using namespace dpt;
 
@@ -100,7 +101,8 @@ enum : int {
     // A new path has L = 0 and beta = 1. Writing those 16 quads into freshly (sparsely) refilled slots cost as
     // much as the rest of k_generate, so they stay implicit until something else is written there:
     F_L_ZERO = 256,     // Q_L holds no value yet; it reads as 0 (0 + x == x)
-    F_BETA_ONE = 512    // Q_BETA holds no value yet; it reads as 1 (1 * x == x)
+    F_BETA_ONE = 512,   // Q_BETA holds no value yet; it reads as 1 (1 * x == x)
+    F_DIFF = 1024       // the path ray is still the camera ray: it has ray differentials (RayDifferential::hasDifferentials)
 };
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
@@ -982,7 +984,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         pool.I(I_BOUNCES, slot) = 0;
-        flags = F_ALIVE | F_L_ZERO | F_BETA_ONE;   // L = 0, beta = 1, not stored
+        flags = F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF;   // L = 0, beta = 1, not stored
     }
     if (valid) pool.I(I_FLAGS, slot) = flags;
     __shared__ unsigned sAlive[5], sPrim[5], sCont[5];
@@ -1101,18 +1103,70 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         if (!finished && s.prims[prim].material < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
             Ray r = SpawnRay(isect, rd);
             pool.R(R_RAY0, slot) = make_float4(r.o.x, r.o.y, r.o.z, r.tMax);
-            passThrough = true;  // flags and bounce count stay as they are
+            passThrough = true;  // flags and bounce count stay as they are (but the spawned ray has no differentials)
+            if (flags & F_DIFF) pool.I(I_FLAGS, slot) = flags & ~F_DIFF;
         }
         if (!finished && !passThrough) {
             const mi_material *mat = &s.materials[s.prims[prim].material];
             BSDFFrame fr;  // BSDF ctor, reflection.h:170-176
             fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
             fr.m = mat;
+            fr.mask = 0xffu;
+            LobeTexT<NL> lt;
+            const LobeTexT<NL> *ltp = nullptr;
+            if constexpr ((TM & TM_TEXTURED) != 0) {
+                // Material::ComputeScatteringFunctions with image textures: evaluate them at the hit, keep the lobes
+                // whose tested spectrum is not black (matte.cpp:55-63, plastic.cpp:52-68, uber.cpp:60-100, ...)
+                lt.hasR = lt.hasS = lt.mulR = lt.mulS = 0u;
+                lt.basis = s.rgbIllum;
+                ltp = &lt;
+                if (mat->textured && s.prims[prim].shape >= 0) {
+                    const float4 hr = pool.R(R_HIT, slot);
+                    float u, v;
+                    V3 dpdv;
+                    TriTexCoords(s, s.prims[prim].shape, hr.y, hr.z, hr.w, &u, &v, &dpdv);
+                    TexDifferentials td;
+                    td.dudx = td.dvdx = td.dudy = td.dvdy = 0;
+                    if (flags & F_DIFF) {   // SurfaceInteraction::ComputeDifferentials, interaction.cpp:99-143
+                        const uint64_t idx = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
+                        float lu = 0.f, lv = 0.f;
+                        if (s.camera.lens_radius > 0) { lu = SampleDimension(s, idx, 3); lv = SampleDimension(s, idx, 4); }
+                        const CamDifferentials cd = CameraDifferentials(s, pool.F(P_FILMX, slot), pool.F(P_FILMY, slot), lu, lv, ro, rd, s.invSqrtSpp);
+                        td = ComputeDifferentials(isect.p, isect.n, isect.dpdu, dpdv, cd);
+                    }
+                    unsigned mask = 0u;
+                    for (int i = 0; i < mat->n_bxdfs; ++i) {
+                        const mi_lobe_tex ltx = mat->tex[i];
+                        if (ltx.tex_R < 0 && ltx.tex_S < 0) { mask |= 1u << i; continue; }
+                        if (i >= NL) continue;
+                        if (ltx.tex_R >= 0) {
+                            lt.r[i] = EvalImageTexture(s, ltx.tex_R, u, v, td);
+                            lt.hasR |= 1u << i;
+                            if (ltx.flags & MI_LOBE_TEX_MUL_R) lt.mulR |= 1u << i;
+                        }
+                        if (ltx.tex_S >= 0) {
+                            lt.s[i] = EvalImageTexture(s, ltx.tex_S, u, v, td);
+                            lt.hasS |= 1u << i;
+                            if (ltx.flags & MI_LOBE_TEX_MUL_S) lt.mulS |= 1u << i;
+                        }
+                        bool rNonBlack = false, sNonBlack = false, texNonBlack = false;
+                        for (int b = 0; b < MI_NSPEC; ++b) {
+                            rNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 0, b) != 0.f;
+                            sNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 1, b) != 0.f;
+                            if (ltx.tex_R >= 0) texNonBlack |= TexBin(lt.basis, lt.r[i], b) != 0.f;
+                            if (ltx.tex_S >= 0) texNonBlack |= TexBin(lt.basis, lt.s[i], b) != 0.f;
+                        }
+                        const bool present = ltx.rule == MI_LOBE_IF_R_OR_S ? (rNonBlack || sNonBlack) : (ltx.rule == MI_LOBE_IF_TEX ? texNonBlack : rNonBlack);
+                        if (present) mask |= 1u << i;
+                    }
+                    fr.mask = mask;
+                }
+            }
             const uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
             int dim = pool.I(I_DIM, slot);
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
             // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
-            if (NumComponents(mat, nonSpec) > 0) {
+            if (NumComponents(fr, nonSpec) > 0) {
                 ++totalPaths;
                 newFlags |= F_NEE;
                 if (s.nLights > 0) {
@@ -1142,7 +1196,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             for (int c = 0; c < NQ; ++c) {
                                 const float4 bt = loadBeta(c);
                                 float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-                                const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c), Lq = LiQuad<TM>(s, light, ls, c);
+                                const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), Lq = LiQuad<TM>(s, light, ls, c);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const int b = 4 * c + k;
@@ -1194,7 +1248,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 for (int c = 0; go && c < NQ; ++c) {
                                     const float4 bt = loadBeta(c);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-                                    const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c);
+                                    const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
                                     float4 Lq = make_float4(0.f, 0.f, 0.f, 0.f);
                                     if (!isEnvLight) Lq = LoadSpec4(light.L, c);
 #pragma unroll
@@ -1244,7 +1298,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 #pragma unroll 1
                     for (int c = 0; c < NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
                         float4 bt = loadBeta(c);
-                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c);
+                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
@@ -1424,7 +1478,8 @@ struct mi_pt {
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
-    unsigned diffuseClasses = 0, plasticClasses = 0;              // subsets of smallClasses run by the lobe-specialised kernels
+    unsigned diffuseClasses = 0, plasticClasses = 0;
+    unsigned texturedSmall = 0, texturedLarge = 0;               // classes of image-textured materials (taken out of small / largeClasses)              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
 };
 
@@ -1564,6 +1619,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             const mi_material &m = d->materials[i];
             std::vector<int> sig;
             for (int j = 0; j < m.n_bxdfs; ++j) { sig.push_back(m.bxdf[j].type); sig.push_back(m.bxdf[j].fresnel); }
+            sig.push_back(m.textured ? 1 : 0);
             size_t c = 0;
             while (c < signatures.size() && signatures[c] != sig) ++c;
             if (c == signatures.size()) signatures.push_back(sig);
@@ -1573,6 +1629,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 classTypes[matClass[i]] |= (1u << m.bxdf[j].type) | (1u << (16 + m.bxdf[j].fresnel));
                 if (m.bxdf[j].scaled) classTypes[matClass[i]] |= TM_SCALED;
             }
+            if (m.textured) classTypes[matClass[i]] |= TM_TEXTURED;
         }
         pt->smallClasses &= ~pt->largeClasses;   // a shared overflow class runs the 8-lobe kernel
         pt->smallClasses |= 1u << MISS_CLASS;
@@ -1587,6 +1644,11 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = 0;
         if (getenv("MIPT_ALL_LIGHTS")) pt->hasInfiniteLight = true;
         pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses);
+        for (int c = 0; c < MISS_CLASS; ++c)
+            if (classTypes[c] & TM_TEXTURED) {
+                if ((pt->smallClasses >> c) & 1u) { pt->texturedSmall |= 1u << c; pt->smallClasses &= ~(1u << c); }
+                if ((pt->largeClasses >> c) & 1u) { pt->texturedLarge |= 1u << c; pt->largeClasses &= ~(1u << c); }
+            }
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
     {
@@ -1713,6 +1775,35 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         s.envmaps = nullptr;
         if (!envs.empty()) UP(envs.data(), envs.size(), s.envmaps);
         UP(&d->rgb_illum[0][0], (size_t)7 * MI_NSPEC, s.rgbIllum);
+        {   // image textures: pyramids into HBM, mi_mipmap records with device texel pointers
+            std::vector<mi_mipmap> mips(d->n_mipmaps);
+            for (uint32_t i = 0; i < d->n_mipmaps; ++i) {
+                mi_mipmap m = d->mipmaps[i];
+                if (m.n_levels < 1 || m.n_levels > MI_MAX_MIP_LEVELS || !m.texels || m.width < 1 || m.height < 1) { g_err = "malformed mi_mipmap"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+                size_t nTexels = 0;
+                for (int l = 0; l < m.n_levels; ++l) nTexels = std::max<size_t>(nTexels, (size_t)m.level_offset[l] + (size_t)std::max(1, m.width >> l) * std::max(1, m.height >> l));
+                UP(d->mipmaps[i].texels, nTexels * 3, m.texels);
+                mips[i] = m;
+            }
+            s.mipmaps = nullptr; s.textures = nullptr;
+            if (!mips.empty()) UP(mips.data(), mips.size(), s.mipmaps);
+            for (uint32_t i = 0; i < d->n_textures; ++i)
+                if ((uint32_t)d->textures[i].mipmap >= d->n_mipmaps) { g_err = "mi_texture.mipmap out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+            if (d->n_textures) UP(d->textures, (size_t)d->n_textures, s.textures);
+            float lut[128];   // MIPMap::weightLut, mipmap.h:199-206
+            for (int i = 0; i < 128; ++i) {
+                float alpha = 2;
+                float r2 = float(i) / float(128 - 1);
+                lut[i] = std::exp(-alpha * r2) - std::exp(-alpha);
+            }
+            UP(lut, (size_t)128, s.ewaWeights);
+            s.invSqrtSpp = 1 / std::sqrt((float)d->sampler.samples_per_pixel);
+            for (uint32_t i = 0; i < d->n_materials; ++i)
+                for (int j = 0; d->materials[i].textured && j < d->materials[i].n_bxdfs; ++j) {
+                    const mi_lobe_tex &t = d->materials[i].tex[j];
+                    if (t.tex_R >= (int)d->n_textures || t.tex_S >= (int)d->n_textures) { g_err = "mi_lobe_tex texture index out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+                }
+        }
         s.nInfiniteLights = 0;
         for (int k = 0; k < 4; ++k) s.infiniteLights[k] = -1;
         for (uint32_t i = 0; i < d->n_lights; ++i)
@@ -1848,17 +1939,18 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         const dim3 shadeGrid(grid.x + MAX_CLASSES);
+        constexpr unsigned TM_GENERIC = TM_ALL & ~TM_TEXTURED;
         if (pt->hasInfiniteLight) {
             if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
             if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-            if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
-            if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
         } else {
             if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
             if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-            if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_ALL & ~TM_LIGHTS_ALL | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
-            if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL & ~TM_LIGHTS_ALL | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
         }
+        if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+        if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
+        if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
         HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);

@@ -391,6 +391,8 @@ struct Api {
             material = gs.currentMaterial->material;
         if (sphereIdx >= 0) {
             const mi_sphere &s = scene->spheres[sphereIdx];
+            if (material >= 0 && scene->materials[material].textured)
+                Err("image-textured material on a \"sphere\": this path evaluates image textures on triangle meshes only; the texture is ignored there");
             PendingPrim pp;
             pp.shape = ~sphereIdx;
             pp.material = material;
@@ -486,14 +488,43 @@ struct Api {
     void Texture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &ps) {
         // Every texture on this path evaluates to a constant, so "scale" and "mix" of such textures fold into
         // constants with the reference's arithmetic (src/textures/scale.h:56-58, mix.h:57-61, scale.cpp, mix.cpp).
-        if (texname != "constant" && texname != "scale" && texname != "mix") {
-            Err("Texture class \"" + texname + "\" is outside the hot-path scope (only \"constant\", \"scale\", \"mix\" of constants, SURVEY 2 row 29)");
+        if (texname != "constant" && texname != "scale" && texname != "mix" && texname != "imagemap") {
+            Err("Texture class \"" + texname + "\" is outside the hot-path scope (\"constant\", \"scale\" / \"mix\" of constants, spectrum \"imagemap\")");
             return;
         }
         ParamSet empty;
         TextureParams tp(ps, empty, gs.textures, &scene->errors);
         const bool isFloat = type == "float", isSpec = type == "color" || type == "spectrum";
         if (!isFloat && !isSpec) { Err("Texture type \"" + type + "\" unknown."); return; }
+        if (texname == "imagemap") {  // CreateImageSpectrumTexture, imagemap.cpp:152-197
+            if (isFloat) { Err("Texture \"" + name + "\": float image textures are outside the hot-path scope (spectrum \"imagemap\" only)"); return; }
+            const std::string mapping = ps.FindOneString("mapping", "uv");
+            if (mapping != "uv") { Err("Texture \"" + name + "\": 2D texture mapping \"" + mapping + "\" is outside the hot-path scope (\"uv\" only)"); return; }
+            mi_texture t{};
+            t.su = ps.FindOneFloat("uscale", 1.f); t.sv = ps.FindOneFloat("vscale", 1.f);
+            t.du = ps.FindOneFloat("udelta", 0.f); t.dv = ps.FindOneFloat("vdelta", 0.f);
+            t.max_aniso = ps.FindOneFloat("maxanisotropy", 8.f);
+            const bool trilerp = ps.FindOneBool("trilinear", false), noFilt = ps.FindOneBool("noFiltering", false);
+            const std::string wrap = ps.FindOneString("wrap", "repeat");
+            const int wrapMode = wrap == "black" ? 1 : (wrap == "clamp" ? 2 : 0);
+            const float scale = ps.FindOneFloat("scale", 1.f);
+            std::string filename = ps.FindOneString("filename", "");
+            std::string ext = filename.size() >= 4 ? filename.substr(filename.size() - 4) : "";
+            for (char &c : ext) c = (char)tolower(c);
+            const bool gamma = ps.FindOneBool("gamma", ext == ".tga" || ext == ".png");
+            if (ps.FindOneBool("useSPD", false)) Warn("Texture \"" + name + "\": \"useSPD\" (display primaries) is not implemented on this path; reflectance conversion used");
+            if (!filename.empty() && filename[0] != '/') filename = baseDir + "/" + filename;   // FindOneFilename
+            // (MIPMap::Lookup: noFiltering takes the trilinear entry point, mipmap.h:283-288)
+            t.filter = noFilt ? MI_TEX_NONE : (trilerp ? MI_TEX_TRILINEAR : MI_TEX_EWA);
+            t.mipmap = BuildTextureMipMap(scene, filename, trilerp, noFilt, t.max_aniso, wrapMode, scale, gamma);
+            gs.textures.spectrumTex.erase(name);
+            gs.textures.imageTex[name] = (int)scene->textures.size();
+            scene->textures.push_back(t);
+            std::vector<std::string> unused;
+            ps.ReportUnused(&unused);
+            for (auto &u : unused) Warn("Parameter \"" + u + "\" not used");
+            return;
+        }
         if (texname == "constant") {
             if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("value", 1.f);
             else gs.textures.spectrumTex[name] = tp.GetSpectrum("value", Spectrum(1.f));
@@ -771,6 +802,18 @@ void Api::WorldEnd() {
         const float *basis = Spectrum::RGBIllumBasis(k);
         for (int i = 0; i < MI_NSPEC; ++i) d.rgb_illum[k][i] = basis[i];
     }
+    scene->mipmaps.clear();
+    for (const HostMipMap &h : scene->mipStore) {
+        mi_mipmap m{};
+        m.n_levels = (int)h.levelOffset.size(); m.wrap = h.wrap; m.width = h.width; m.height = h.height;
+        m.texels = h.texels.data();
+        for (size_t l = 0; l < h.levelOffset.size() && l < MI_MAX_MIP_LEVELS; ++l) m.level_offset[l] = h.levelOffset[l];
+        scene->mipmaps.push_back(m);
+    }
+    d.n_mipmaps = (uint32_t)scene->mipmaps.size();
+    d.mipmaps = scene->mipmaps.empty() ? nullptr : scene->mipmaps.data();
+    d.n_textures = (uint32_t)scene->textures.size();
+    d.textures = scene->textures.empty() ? nullptr : scene->textures.data();
     scene->envmaps.clear();
     for (const HostEnvMap &e : scene->envStore) {
         mi_envmap m{};

@@ -3,134 +3,16 @@
 // Lanczos resampling, mipmap.h:118-196), the Distribution2D over the 2W x 2H luminance image that the
 // constructor filters out of the map with Lookup(st, fwidth) (trilinear between pyramid levels,
 // mipmap.h:252-281), and the value Power() is built from (infinite.cpp:85-89).
-//   image reading     ReadImagePFM, src/core/imageio.cpp:349-435 (EXR / PNG / TGA need libraries or code this
-//                     build does not carry; such a map is reported as an error and the light becomes constant)
+//   image reading     image.cpp (PFM, TGA, PNG; an EXR map is reported as an error and the light becomes constant)
 //   Distribution1D/2D src/core/sampling.h:55-109,123-147, sampling.cpp:41-56
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include "scene.h"
+#include "image.h"
 
 namespace mipt {
 namespace {
-
-struct RGB {
-    float c[3];
-    RGB(float v = 0.f) { c[0] = c[1] = c[2] = v; }
-    RGB operator+(const RGB &o) const { RGB r; for (int i = 0; i < 3; ++i) r.c[i] = c[i] + o.c[i]; return r; }
-    RGB &operator+=(const RGB &o) { for (int i = 0; i < 3; ++i) c[i] += o.c[i]; return *this; }
-    RGB operator*(float a) const { RGB r; for (int i = 0; i < 3; ++i) r.c[i] = c[i] * a; return r; }
-    RGB operator*(const RGB &o) const { RGB r; for (int i = 0; i < 3; ++i) r.c[i] = c[i] * o.c[i]; return r; }
-    RGB Clamp() const { RGB r; for (int i = 0; i < 3; ++i) r.c[i] = std::min(std::max(c[i], 0.f), INFINITY); return r; }
-    float y() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }  // spectrum.h:535-538
-};
-inline RGB operator*(float a, const RGB &s) { return s * a; }
-
-inline int Mod(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
-inline bool IsPowerOf2(int v) { return v && !(v & (v - 1)); }
-inline int RoundUpPow2(int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
-inline int Log2Int(uint32_t v) { return 31 - __builtin_clz(v); }
-inline float Log2(float x) { const float invLog2 = 1.442695040888963387004650940071; return std::log(x) * invLog2; }
-inline float Lanczos(float x, float tau = 2) {  // texture.cpp:254-262
-    x = std::abs(x);
-    if (x < 1e-5f) return 1;
-    if (x > 1.f) return 0;
-    x *= kPi;
-    float s = std::sin(x * tau) / (x * tau);
-    float lanczos = std::sin(x) / x;
-    return s * lanczos;
-}
-
-struct MIPMap {  // MIPMap<RGBSpectrum>, wrap mode Repeat, mipmap.h
-    struct Level { int w, h; std::vector<RGB> t; };
-    std::vector<Level> pyramid;
-    int Levels() const { return (int)pyramid.size(); }
-    int Width() const { return pyramid[0].w; }
-    int Height() const { return pyramid[0].h; }
-    const RGB &Texel(int level, int s, int t) const {
-        const Level &l = pyramid[level];
-        s = Mod(s, l.w);
-        t = Mod(t, l.h);
-        return l.t[(size_t)t * l.w + s];
-    }
-    RGB triangle(int level, const float st[2]) const {
-        level = std::min(std::max(level, 0), Levels() - 1);
-        float s = st[0] * pyramid[level].w - 0.5f;
-        float t = st[1] * pyramid[level].h - 0.5f;
-        int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
-        float ds = s - s0, dt = t - t0;
-        return (1 - ds) * (1 - dt) * Texel(level, s0, t0) + (1 - ds) * dt * Texel(level, s0, t0 + 1) +
-               ds * (1 - dt) * Texel(level, s0 + 1, t0) + ds * dt * Texel(level, s0 + 1, t0 + 1);
-    }
-    RGB Lookup(const float st[2], float width) const {
-        float level = Levels() - 1 + Log2(std::max(width, (float)1e-8));
-        if (level < 0) return triangle(0, st);
-        else if (level >= Levels() - 1) return Texel(Levels() - 1, 0, 0);
-        int iLevel = (int)std::floor(level);
-        float delta = level - iLevel;
-        return (1 - delta) * triangle(iLevel, st) + delta * triangle(iLevel + 1, st);  // Lerp, pbrt.h:420
-    }
-    MIPMap(int rx, int ry, const std::vector<RGB> &img) {
-        std::vector<RGB> base = img;
-        if (!IsPowerOf2(rx) || !IsPowerOf2(ry)) {
-            const int px = RoundUpPow2(rx), py = RoundUpPow2(ry);
-            struct W { int first; float w[4]; };
-            auto weights = [](int oldRes, int newRes) {
-                std::vector<W> wt(newRes);
-                const float filterwidth = 2.f;
-                for (int i = 0; i < newRes; ++i) {
-                    float center = (i + .5f) * oldRes / newRes;
-                    wt[i].first = (int)std::floor((center - filterwidth) + 0.5f);
-                    for (int j = 0; j < 4; ++j) {
-                        float pos = wt[i].first + j + .5f;
-                        wt[i].w[j] = Lanczos((pos - center) / filterwidth);
-                    }
-                    float invSumWts = 1 / (wt[i].w[0] + wt[i].w[1] + wt[i].w[2] + wt[i].w[3]);
-                    for (int j = 0; j < 4; ++j) wt[i].w[j] *= invSumWts;
-                }
-                return wt;
-            };
-            std::vector<RGB> res((size_t)px * py);
-            std::vector<W> sW = weights(rx, px);
-            for (int t = 0; t < ry; ++t)
-                for (int s = 0; s < px; ++s) {
-                    RGB &o = res[(size_t)t * px + s];
-                    o = RGB(0.f);
-                    for (int j = 0; j < 4; ++j) {
-                        int origS = Mod(sW[s].first + j, rx);
-                        if (origS >= 0 && origS < rx) o += sW[s].w[j] * img[(size_t)t * rx + origS];
-                    }
-                }
-            std::vector<W> tW = weights(ry, py);
-            std::vector<RGB> work(py);
-            for (int s = 0; s < px; ++s) {
-                for (int t = 0; t < py; ++t) {
-                    work[t] = RGB(0.f);
-                    for (int j = 0; j < 4; ++j) {
-                        int offset = Mod(tW[t].first + j, ry);
-                        if (offset >= 0 && offset < ry) work[t] += tW[t].w[j] * res[(size_t)offset * px + s];
-                    }
-                }
-                for (int t = 0; t < py; ++t) res[(size_t)t * px + s] = work[t].Clamp();
-            }
-            base.swap(res);
-            rx = px; ry = py;
-        }
-        int nLevels = 1 + Log2Int((uint32_t)std::max(rx, ry));
-        pyramid.resize(nLevels);
-        pyramid[0] = Level{rx, ry, base};
-        for (int i = 1; i < nLevels; ++i) {
-            int sRes = std::max(1, pyramid[i - 1].w / 2), tRes = std::max(1, pyramid[i - 1].h / 2);
-            pyramid[i].w = sRes; pyramid[i].h = tRes;
-            pyramid[i].t.resize((size_t)sRes * tRes);
-            for (int t = 0; t < tRes; ++t)
-                for (int s = 0; s < sRes; ++s)
-                    pyramid[i].t[(size_t)t * sRes + s] =
-                        .25f * (Texel(i - 1, 2 * s, 2 * t) + Texel(i - 1, 2 * s + 1, 2 * t) + Texel(i - 1, 2 * s, 2 * t + 1) +
-                                Texel(i - 1, 2 * s + 1, 2 * t + 1));
-        }
-    }
-};
 
 void MakeDistribution1D(const float *f, int n, float *func, float *cdf, float *funcInt) {  // sampling.h:57-70
     for (int i = 0; i < n; ++i) func[i] = f[i];
@@ -139,42 +21,6 @@ void MakeDistribution1D(const float *f, int n, float *func, float *cdf, float *f
     *funcInt = cdf[n];
     if (*funcInt == 0) { for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n); }
     else { for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt; }
-}
-
-bool ReadPFM(const std::string &filename, int *xres, int *yres, std::vector<RGB> *out) {  // imageio.cpp:349-435
-    FILE *fp = fopen(filename.c_str(), "rb");
-    if (!fp) return false;
-    auto readWord = [&](char *buf, int len) {
-        int n = 0, c;
-        while ((c = fgetc(fp)) != EOF && !isspace(c) && n < len - 1) buf[n++] = (char)c;
-        buf[n] = 0;
-        return (c == EOF && n == 0) ? -1 : n;
-    };
-    char buf[80];
-    int nChannels = 0;
-    bool ok = readWord(buf, 80) != -1;
-    if (ok) { if (!strcmp(buf, "Pf")) nChannels = 1; else if (!strcmp(buf, "PF")) nChannels = 3; else ok = false; }
-    int width = 0, height = 0;
-    float scale = 1;
-    if (ok && readWord(buf, 80) != -1) width = atoi(buf); else ok = false;
-    if (ok && readWord(buf, 80) != -1) height = atoi(buf); else ok = false;
-    if (ok && readWord(buf, 80) != -1) sscanf(buf, "%f", &scale); else ok = false;
-    if (!ok || width <= 0 || height <= 0) { fclose(fp); return false; }
-    std::vector<float> data((size_t)nChannels * width * height);
-    for (int y = height - 1; y >= 0 && ok; --y)   // P*M has its origin at the lower left
-        ok = fread(&data[(size_t)y * nChannels * width], sizeof(float), (size_t)nChannels * width, fp) == (size_t)nChannels * width;
-    fclose(fp);
-    if (!ok) return false;
-    if (!(scale < 0.f))   // big-endian file on this little-endian host
-        for (float &v : data) { unsigned char b[4]; memcpy(b, &v, 4); std::swap(b[0], b[3]); std::swap(b[1], b[2]); memcpy(&v, b, 4); }
-    if (std::abs(scale) != 1.f) for (float &v : data) v *= std::abs(scale);
-    out->resize((size_t)width * height);
-    for (size_t i = 0; i < out->size(); ++i) {
-        if (nChannels == 1) (*out)[i] = RGB(data[i]);
-        else { (*out)[i].c[0] = data[3 * i]; (*out)[i].c[1] = data[3 * i + 1]; (*out)[i].c[2] = data[3 * i + 2]; }
-    }
-    *xres = width; *yres = height;
-    return true;
 }
 
 }  // namespace
@@ -196,13 +42,8 @@ bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store
     int rx = 0, ry = 0;
     std::vector<RGB> texels;
     if (!texmap.empty()) {
-        const size_t dot = texmap.find_last_of('.');
-        std::string ext = dot == std::string::npos ? "" : texmap.substr(dot);
-        for (char &c : ext) c = (char)tolower(c);
-        if (ext != ".pfm")
-            errors->push_back("Unable to load image stored in format \"" + (ext.empty() ? std::string("(unknown)") : ext.substr(1)) +
-                              "\" for filename \"" + texmap + "\" (this build reads PFM environment maps only).");
-        else if (!ReadPFM(texmap, &rx, &ry, &texels)) errors->push_back("Error reading PFM file \"" + texmap + "\"");
+        std::string ioErr;
+        if (!ReadImage(texmap, &rx, &ry, &texels, &ioErr)) { errors->push_back(ioErr); texels.clear(); }
         if (!texels.empty()) for (RGB &t : texels) t = t * Lrgb;
     }
     if (texels.empty()) { rx = ry = 1; texels.assign(1, Lrgb); }
@@ -238,6 +79,41 @@ bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store
     const RGB c = mip.Lookup(half, .5f);
     *centre = Spectrum::FromRGB(c.c, SpectrumType::Illuminant);
     return true;
+}
+
+int BuildTextureMipMap(HostScene *scene, const std::string &filename, bool trilinear, bool noFiltering, float maxAniso,
+                       int wrap, float scale, bool gamma) {
+    char keyBuf[128];
+    snprintf(keyBuf, sizeof keyBuf, "|%d|%d|%a|%d|%a|%d", (int)trilinear, (int)noFiltering, maxAniso, wrap, scale, (int)gamma);
+    const std::string key = filename + keyBuf;
+    for (size_t i = 0; i < scene->mipStore.size(); ++i) if (scene->mipStore[i].key == key) return (int)i;
+    int rx = 0, ry = 0;
+    std::vector<RGB> texels;
+    std::string ioErr;
+    if (!ReadImage(filename, &rx, &ry, &texels, &ioErr)) {
+        scene->errors.push_back(ioErr);
+        scene->warnings.push_back("Creating a constant grey texture to replace \"" + filename + "\".");
+        rx = ry = 1;
+        texels.assign(1, RGB(0.5f));
+    }
+    // flip in y: texture space has (0,0) at the lower left corner (imagemap.cpp:79-86)
+    for (int y = 0; y < ry / 2; ++y)
+        for (int x = 0; x < rx; ++x) std::swap(texels[(size_t)y * rx + x], texels[(size_t)(ry - 1 - y) * rx + x]);
+    auto inverseGamma = [](float value) {  // pbrt.h:301-304
+        if (value <= 0.04045f) return value * 1.f / 12.92f;
+        return std::pow((value + 0.055f) * 1.f / 1.055f, (float)2.4f);
+    };
+    for (RGB &t : texels) for (int k = 0; k < 3; ++k) t.c[k] = scale * (gamma ? inverseGamma(t.c[k]) : t.c[k]);  // convertIn
+    MIPMap mip(rx, ry, texels, (ImageWrap)wrap);
+    HostMipMap h;
+    h.key = key;
+    h.width = mip.Width(); h.height = mip.Height(); h.wrap = wrap;
+    for (const MIPMap::Level &l : mip.pyramid) {
+        h.levelOffset.push_back((uint32_t)(h.texels.size() / 3));
+        for (const RGB &t : l.t) for (int k = 0; k < 3; ++k) h.texels.push_back(t.c[k]);
+    }
+    scene->mipStore.push_back(std::move(h));
+    return (int)scene->mipStore.size() - 1;
 }
 
 }  // namespace mipt

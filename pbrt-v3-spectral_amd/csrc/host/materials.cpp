@@ -30,9 +30,21 @@ void SetS(mi_bxdf &b, const Spectrum &S) { for (int i = 0; i < MI_NSPEC; ++i) b.
 
 bool Add(mi_material *m, const mi_bxdf &b, std::vector<std::string> *errs) {
     if (m->n_bxdfs >= MI_MAX_BXDFS) { errs->push_back("more than 8 BxDFs in a BSDF"); return false; }
+    m->tex[m->n_bxdfs] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     m->bxdf[m->n_bxdfs++] = b;
     return true;
 }
+// The lobe just added takes R (and S) from image textures at each hit (mi_lobe_tex, mi_pt.h).
+void Bind(mi_material *m, int texR, bool mulR, int texS = -1, bool mulS = false, int rule = MI_LOBE_IF_R) {
+    if (m->n_bxdfs == 0 || (texR < 0 && texS < 0)) return;
+    mi_lobe_tex &t = m->tex[m->n_bxdfs - 1];
+    t.tex_R = texR; t.tex_S = texS;
+    t.flags = (texR >= 0 && mulR ? MI_LOBE_TEX_MUL_R : 0u) | (texS >= 0 && mulS ? MI_LOBE_TEX_MUL_S : 0u);
+    t.rule = rule;
+    m->textured = 1;
+}
+// Whether a parameter can make its lobe appear: a constant must not be black, a texture may be anything.
+inline bool MayBeNonBlack(const SpectrumParam &p, const Spectrum &clamped) { return p.tex >= 0 || !clamped.IsBlack(); }
 
 mi_bxdf Lambertian(const Spectrum &R) {
     return MakeBxDF(MI_BXDF_LAMBERTIAN_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_DIFFUSE, R);
@@ -74,41 +86,48 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
                      std::vector<std::string> *warnings, std::vector<std::string> *errs) {
     *m = mi_material{};
     m->eta = 1.f;
+    for (int i = 0; i < MI_MAX_BXDFS; ++i) m->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     float bump;
     if (mp.GetFloatOrNull("bumpmap", &bump))
         warnings->push_back("bumpmap ignored: Material::Bump is outside the hot-path scope (SURVEY 8f)");
 
     if (type == "matte") {  // src/materials/matte.cpp:45-62,64-71
         m->kind = 0;
-        Spectrum r = mp.GetSpectrum("Kd", Spectrum(0.5f)).Clamp();
+        const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(0.5f));
+        Spectrum r = Kd.s.Clamp();
         float sig = Clamp(mp.GetFloat("sigma", 0.f), 0, 90);
-        if (!r.IsBlack()) {
+        if (MayBeNonBlack(Kd, r)) {
             if (sig == 0) Add(m, Lambertian(r), errs);
             else Add(m, OrenNayar(r, sig), errs);
+            Bind(m, Kd.tex, false);
         }
         return true;
     }
     if (type == "plastic") {  // src/materials/plastic.cpp:45-70,72-84
         m->kind = 1;
-        Spectrum kd = mp.GetSpectrum("Kd", Spectrum(0.25f)).Clamp();
-        Spectrum ks = mp.GetSpectrum("Ks", Spectrum(0.25f)).Clamp();
+        const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(0.25f)), Ks = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
+        Spectrum kd = Kd.s.Clamp();
+        Spectrum ks = Ks.s.Clamp();
         float rough = mp.GetFloat("roughness", .1f);
         bool remap = mp.FindBool("remaproughness", true);
-        if (!kd.IsBlack()) Add(m, Lambertian(kd), errs);
-        if (!ks.IsBlack()) {
+        if (MayBeNonBlack(Kd, kd)) { Add(m, Lambertian(kd), errs); Bind(m, Kd.tex, false); }
+        if (MayBeNonBlack(Ks, ks)) {
             if (remap) rough = RoughnessToAlpha(rough);
             // FresnelDielectric(1.5f, 1.f): plastic.cpp:59
             Add(m, MicrofacetReflectionDielectric(ks, rough, rough, 1.5f, 1.f), errs);
+            Bind(m, Ks.tex, false);
         }
         return true;
     }
     if (type == "mirror") {  // src/materials/mirror.cpp: SpecularReflection(R, FresnelNoOp)
         m->kind = 5;
-        Spectrum R = mp.GetSpectrum("Kr", Spectrum(0.9f)).Clamp();
-        if (!R.IsBlack()) {
+        const SpectrumParam Kr = mp.GetSpectrumParam("Kr", Spectrum(0.9f));
+        Spectrum R = Kr.s.Clamp();
+        if (MayBeNonBlack(Kr, R)) {
             mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_SPECULAR, R);
             b.fresnel = MI_FRESNEL_NOOP;
             Add(m, b, errs);
+            Bind(m, Kr.tex, false);
         }
         return true;
     }
@@ -133,16 +152,18 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     }
     if (type == "substrate") {  // src/materials/substrate.cpp:45-64,66-81: FresnelBlend(Kd, Ks, TR)
         m->kind = 7;
-        Spectrum d = mp.GetSpectrum("Kd", Spectrum(.5f)).Clamp();
-        Spectrum s = mp.GetSpectrum("Ks", Spectrum(.5f)).Clamp();
+        const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(.5f)), Ks = mp.GetSpectrumParam("Ks", Spectrum(.5f));
+        Spectrum d = Kd.s.Clamp();
+        Spectrum s = Ks.s.Clamp();
         float roughu = mp.GetFloat("uroughness", .1f);
         float roughv = mp.GetFloat("vroughness", .1f);
-        if (!d.IsBlack() || !s.IsBlack()) {
+        if (MayBeNonBlack(Kd, d) || MayBeNonBlack(Ks, s)) {
             if (mp.FindBool("remaproughness", true)) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
             mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_BLEND, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, d);
             SetS(b, s);
             b.p[0] = roughu; b.p[1] = roughv;
             Add(m, b, errs);
+            Bind(m, Kd.tex, false, Ks.tex, false, MI_LOBE_IF_R_OR_S);
         }
         return true;
     }
@@ -153,32 +174,38 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         Spectrum r = mp.GetSpectrum("reflect", Spectrum(0.5f)).Clamp();
         Spectrum t = mp.GetSpectrum("transmit", Spectrum(0.5f)).Clamp();
         if (r.IsBlack() && t.IsBlack()) return true;
-        Spectrum kd = mp.GetSpectrum("Kd", Spectrum(0.25f)).Clamp();
-        if (!kd.IsBlack()) {
-            if (!r.IsBlack()) Add(m, Lambertian(r * kd), errs);
-            if (!t.IsBlack())
+        // (a textured Kd / Ks: the lobe keeps r or t as its constant and the texture value multiplies it at the hit)
+        const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(0.25f));
+        Spectrum kd = Kd.s.Clamp();
+        if (MayBeNonBlack(Kd, kd)) {
+            if (!r.IsBlack()) { Add(m, Lambertian(r * kd), errs); Bind(m, Kd.tex, true, -1, false, MI_LOBE_IF_TEX); }
+            if (!t.IsBlack()) {
                 Add(m, MakeBxDF(MI_BXDF_LAMBERTIAN_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_DIFFUSE, t * kd), errs);
+                Bind(m, Kd.tex, true, -1, false, MI_LOBE_IF_TEX);
+            }
         }
-        Spectrum ks = mp.GetSpectrum("Ks", Spectrum(0.25f)).Clamp();
-        if (!ks.IsBlack() && (!r.IsBlack() || !t.IsBlack())) {
+        const SpectrumParam Ks = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
+        Spectrum ks = Ks.s.Clamp();
+        if (MayBeNonBlack(Ks, ks) && (!r.IsBlack() || !t.IsBlack())) {
             float rough = mp.GetFloat("roughness", .1f);
             if (mp.FindBool("remaproughness", true)) rough = RoughnessToAlpha(rough);
-            if (!r.IsBlack()) Add(m, MicrofacetReflectionDielectric(r * ks, rough, rough, 1.f, eta), errs);
-            if (!t.IsBlack()) Add(m, MicrofacetTransmission(t * ks, rough, rough, 1.f, eta, false), errs);
+            if (!r.IsBlack()) { Add(m, MicrofacetReflectionDielectric(r * ks, rough, rough, 1.f, eta), errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX); }
+            if (!t.IsBlack()) { Add(m, MicrofacetTransmission(t * ks, rough, rough, 1.f, eta, false), errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX); }
         }
         return true;
     }
     if (type == "glass") {  // src/materials/glass.cpp:45-92,94-111 (allowMultipleLobes = true)
         m->kind = 2;
-        Spectrum R = mp.GetSpectrum("Kr", Spectrum(1.f)).Clamp();
-        Spectrum T = mp.GetSpectrum("Kt", Spectrum(1.f)).Clamp();
+        const SpectrumParam Kr = mp.GetSpectrumParam("Kr", Spectrum(1.f)), Kt = mp.GetSpectrumParam("Kt", Spectrum(1.f));
+        Spectrum R = Kr.s.Clamp();
+        Spectrum T = Kt.s.Clamp();
         float eta;
         if (!mp.GetFloatOrNull("eta", &eta)) eta = mp.GetFloat("index", 1.5f);
         float urough = mp.GetFloat("uroughness", 0.f);
         float vrough = mp.GetFloat("vroughness", 0.f);
         bool remap = mp.FindBool("remaproughness", true);
         m->eta = eta;
-        if (R.IsBlack() && T.IsBlack()) return true;
+        if (!MayBeNonBlack(Kr, R) && !MayBeNonBlack(Kt, T)) return true;
         bool isSpecular = urough == 0 && vrough == 0;
         if (isSpecular) {
             mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_SPECULAR,
@@ -186,7 +213,14 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             SetS(b, T);
             b.p[0] = 1.f; b.p[1] = eta;
             Add(m, b, errs);
+            Bind(m, Kr.tex, false, Kt.tex, false, MI_LOBE_IF_R_OR_S);
         } else {
+            if ((Kr.tex >= 0) != (Kt.tex >= 0) || (Kr.tex >= 0 && Kt.tex >= 0)) {
+                // rough glass adds its lobes only `if (R.IsBlack() && T.IsBlack()) return` has not fired (glass.cpp:70-72):
+                // with one side textured that early-out couples the two lobes, which mi_lobe_tex does not express
+                errs->push_back("rough \"glass\" with image-textured Kr / Kt is outside the hot-path scope");
+                return false;
+            }
             if (remap) { urough = RoughnessToAlpha(urough); vrough = RoughnessToAlpha(vrough); }
             if (!R.IsBlack()) Add(m, MicrofacetReflectionDielectric(R, urough, vrough, 1.f, eta), errs);
             if (!T.IsBlack()) Add(m, MicrofacetTransmission(T, urough, vrough, 1.f, eta, false), errs);
@@ -195,10 +229,9 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     }
     if (type == "uber") {  // src/materials/uber.cpp:45-101,103-128
         m->kind = 3;
-        Spectrum Kd = mp.GetSpectrum("Kd", Spectrum(0.25f));
-        Spectrum Ks = mp.GetSpectrum("Ks", Spectrum(0.25f));
-        Spectrum Kr = mp.GetSpectrum("Kr", Spectrum(0.f));
-        Spectrum Kt = mp.GetSpectrum("Kt", Spectrum(0.f));
+        const SpectrumParam pKd = mp.GetSpectrumParam("Kd", Spectrum(0.25f)), pKs = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
+        const SpectrumParam pKr = mp.GetSpectrumParam("Kr", Spectrum(0.f)), pKt = mp.GetSpectrumParam("Kt", Spectrum(0.f));
+        const Spectrum Kd = pKd.s, Ks = pKs.s, Kr = pKr.s, Kt = pKt.s;   // (textured: 1, so that op * K below leaves op as the lobe's constant)
         float roughness = mp.GetFloat("roughness", .1f);
         float ur, vr;
         bool hasU = mp.GetFloatOrNull("uroughness", &ur);
@@ -216,18 +249,19 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         } else
             m->eta = e;
         Spectrum kd = op * Kd.Clamp();
-        if (!kd.IsBlack()) Add(m, Lambertian(kd), errs);
+        if (!kd.IsBlack()) { Add(m, Lambertian(kd), errs); Bind(m, pKd.tex, true); }
         Spectrum ks = op * Ks.Clamp();
         if (!ks.IsBlack()) {
             float roughu = hasU ? ur : roughness;
             float roughv = hasV ? vr : roughu;
             if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
             Add(m, MicrofacetReflectionDielectric(ks, roughu, roughv, 1.f, e), errs);
+            Bind(m, pKs.tex, true);
         }
         Spectrum kr = op * Kr.Clamp();
-        if (!kr.IsBlack()) Add(m, SpecularReflectionDielectric(kr, 1.f, e), errs);
+        if (!kr.IsBlack()) { Add(m, SpecularReflectionDielectric(kr, 1.f, e), errs); Bind(m, pKr.tex, true); }
         Spectrum kt = op * Kt.Clamp();
-        if (!kt.IsBlack()) Add(m, SpecularTransmission(kt, 1.f, e), errs);
+        if (!kt.IsBlack()) { Add(m, SpecularTransmission(kt, 1.f, e), errs); Bind(m, pKt.tex, true); }
         return true;
     }
     if (type == "disney") {  // src/materials/disney.cpp:474-587,589-624
@@ -319,6 +353,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
 bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spectrum &amount, mi_material *out,
                         std::vector<std::string> *errs) {
     *out = mi_material{};
+    for (int i = 0; i < MI_MAX_BXDFS; ++i) out->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     out->kind = 9;
     out->eta = m1.eta;
     const Spectrum s1 = amount.Clamp();
@@ -328,6 +363,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < src[k]->n_bxdfs; ++i) {
             mi_bxdf b = src[k]->bxdf[i];
+            if (src[k]->textured) { errs->push_back("a \"mix\" of image-textured materials is outside the hot-path scope"); return false; }
             if (b.scaled) { errs->push_back("a \"mix\" of \"mix\" materials (nested ScaledBxDF) is not built on this path"); return false; }
             b.scaled = 1;
             for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j];

@@ -73,6 +73,14 @@ struct ParamSet {
 struct TextureMaps {
     std::map<std::string, float> floatTex;
     std::map<std::string, Spectrum> spectrumTex;
+    std::map<std::string, int> imageTex;   // Texture "name" "spectrum" "imagemap": index into HostScene::textures
+};
+// A spectrum material parameter: a constant, or an image texture evaluated per hit.
+struct SpectrumParam {
+    Spectrum s;
+    int tex = -1;
+    SpectrumParam() {}
+    SpectrumParam(const Spectrum &v) : s(v) {}
 };
 
 // TextureParams (paramset.cpp:700-790): geometry params shadow material params.
@@ -97,8 +105,23 @@ struct TextureParams {
         }
         auto it = tex.spectrumTex.find(name);
         if (it != tex.spectrumTex.end()) { *out = it->second; return true; }
+        if (tex.imageTex.count(name)) {
+            if (errors) errors->push_back("Image texture \"" + name + "\" on parameter \"" + n + "\": this path evaluates image textures "
+                                          "for Kd / Ks / Kr / Kt of matte, plastic, mirror, glass, uber, substrate and translucent only");
+            return false;
+        }
         if (errors) errors->push_back("Couldn't find spectrum texture named \"" + name + "\" for parameter \"" + n + "\"");
         return false;
+    }
+    // The same lookup for a parameter that may be bound to an image texture.
+    SpectrumParam GetSpectrumParam(const std::string &n, const Spectrum &def) const {
+        std::string name = geom.FindTexture(n);
+        if (name == "" && !ParamSet::Find(geom.spectra, n)) name = mat.FindTexture(n);
+        if (name != "") {
+            auto it = tex.imageTex.find(name);
+            if (it != tex.imageTex.end()) { SpectrumParam p; p.s = Spectrum(1.f); p.tex = it->second; return p; }
+        }
+        return SpectrumParam(GetSpectrum(n, def));
     }
     Spectrum GetSpectrum(const std::string &n, const Spectrum &def) const {
         Spectrum s;

@@ -24,6 +24,14 @@ struct HostEnvMap {
     float margFuncInt = 0;
 };
 
+// Texture "..." "spectrum" "imagemap": one MIPMap pyramid per distinct TexInfo (imagemap.h:50-76)
+struct HostMipMap {
+    std::string key;           // filename + filter parameters (the reference's texture cache key)
+    int width = 0, height = 0, wrap = 0;
+    std::vector<float> texels; // RGB, all levels
+    std::vector<uint32_t> levelOffset;
+};
+
 struct HostScene {
     // geometry
     std::vector<mi_bvh_node> nodes;
@@ -37,6 +45,9 @@ struct HostScene {
     std::vector<mi_light> lights;
     std::vector<HostEnvMap> envStore;   // storage behind desc.envmaps
     std::vector<mi_envmap> envmaps;
+    std::vector<HostMipMap> mipStore;   // storage behind desc.mipmaps
+    std::vector<mi_mipmap> mipmaps;
+    std::vector<mi_texture> textures;
     // light distribution
     std::vector<float> ldFunc, ldCdf, ldFuncInt;
     // sampler tables
@@ -85,6 +96,10 @@ struct PLYMeshData {
 };
 bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std::string> *warnings, std::string *err);
 
+// ImageTexture<RGBSpectrum, Spectrum>::GetTexture (imagemap.cpp:58-106): read, flip, convertIn, build the pyramid.
+// Returns the index into scene->mipStore (cached by TexInfo).
+int BuildTextureMipMap(HostScene *scene, const std::string &filename, bool trilinear, bool noFiltering, float maxAniso,
+                       int wrap, float scale, bool gamma);
 bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store, Spectrum *centre, std::vector<std::string> *errors);
 bool WriteRGBImage(const std::string &filename, int w, int h, const float *filmSum, const float *weightSum, float scale,
                    std::string *written, std::string *err);

@@ -25,6 +25,7 @@ def lib():
         l.oracle_li.argtypes = [D, C.POINTER(C.c_int32), C.c_int, F, C.POINTER(pt.Counters)]
         l.oracle_camera_rays.argtypes = [D, C.POINTER(C.c_int32), C.c_int, F]
         l.oracle_trace.argtypes = [D, F, C.c_uint32, C.c_int, F, C.POINTER(pt.Counters)]
+        l.oracle_texture_lookup.argtypes = [D, C.c_int, F, F, F]
         l.oracle_radical_inverse.argtypes = [D, C.c_int, C.c_uint64]
         l.oracle_radical_inverse.restype = C.c_float
         l.oracle_scrambled_radical_inverse.argtypes = [D, C.c_int, C.c_uint64]
@@ -73,3 +74,12 @@ def trace(scene, rays, any_hit=False):
     c = pt.Counters()
     lib().oracle_trace(scene.desc_ptr, _f(rays), len(rays), 1 if any_hit else 0, _f(hits), C.byref(c))
     return hits, c
+
+
+def texture_lookup(scene, tex, st, dstdx=(0, 0), dstdy=(0, 0)):
+    """(rgb[3], spectrum[31]) of MIPMap::Lookup + FromRGB for image texture `tex` of the scene."""
+    st2 = np.asarray(st, np.float32)
+    d4 = np.asarray(list(dstdx) + list(dstdy), np.float32)
+    out = np.zeros(34, np.float32)
+    lib().oracle_texture_lookup(scene.desc_ptr, int(tex), _f(st2), _f(d4), _f(out))
+    return out[:3], out[3:]

@@ -158,3 +158,179 @@ def zoo_with_infinite_light(kind, res=64, spp=16, depth=6, strategy="power"):
     t = t.replace('LightSource "distant" "rgb L" [.4 .4 .5] "point from" [0 10 -4] "point to" [0 0 0]', '')
     t = t.replace('AreaLightSource "diffuse" "rgb L" [18 17 15]', '')
     return t.replace('WorldBegin', 'WorldBegin\nAttributeBegin\nRotate -90 1 0 0\nLightSource "infinite" "string mapname" "env.pfm"\nAttributeEnd')
+
+
+# ------------------------------------------------------------------ image textures
+def _texture_image(w, h, seed):
+    """A procedural 8-bit RGB image with structure at several scales, saturated patches and a pure black region
+    (where a textured lobe drops out of the BSDF)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 3), np.float64)
+    img[..., 0] = 0.5 + 0.5 * np.sin(x * 0.9) * np.cos(y * 0.35)
+    img[..., 1] = ((x // 4 + y // 3) % 2) * 0.8 + 0.1
+    img[..., 2] = rng.random((h, w))
+    img[h // 3:h // 2, w // 4:w // 2] = [1.0, 0.05, 0.02]
+    img[: h // 5, : w // 5] = 0.0
+    return (np.clip(img, 0, 1) * 255 + 0.5).astype(np.uint8)
+
+
+def write_png(path, rgb8, with_alpha=False, filters=True):
+    """Minimal PNG writer (colour type 2 or 6, 8 bit); cycles through the five scanline filters."""
+    import struct, zlib
+    import numpy as np
+    h, w, _ = rgb8.shape
+    px = rgb8
+    if with_alpha:
+        px = np.concatenate([rgb8, np.full((h, w, 1), 200, np.uint8)], axis=2)
+    bpp = px.shape[2]
+    raw = bytearray()
+    prev = np.zeros(w * bpp, np.int32)
+    for yy in range(h):
+        cur = px[yy].reshape(-1).astype(np.int32)
+        ft = (yy % 5) if filters else 0
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0:
+            out = cur
+        elif ft == 1:
+            out = cur - left
+        elif ft == 2:
+            out = cur - prev
+        elif ft == 3:
+            out = cur - (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out = cur - pred
+        raw.append(ft)
+        raw += (out & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6 if with_alpha else 2, 0, 0, 0)))
+        comp = zlib.compress(bytes(raw), 6)
+        half = len(comp) // 2
+        f.write(chunk(b"IDAT", comp[:half]))
+        f.write(chunk(b"IDAT", comp[half:]))
+        f.write(chunk(b"IEND", b""))
+
+
+def write_tga(path, rgb8, rle=False):
+    """Uncompressed or run-length-encoded 24-bit TGA, bottom-up like most writers."""
+    import struct
+    h, w, _ = rgb8.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<BBBHHBHHHHBB", 0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, w, h, 24, 0))
+        rows = rgb8[::-1, :, ::-1]   # bottom-up, BGR
+        if not rle:
+            f.write(rows.tobytes())
+        else:
+            flat = rows.reshape(-1, 3)
+            i = 0
+            while i < len(flat):
+                run = 1
+                while i + run < len(flat) and run < 128 and (flat[i + run] == flat[i]).all():
+                    run += 1
+                if run > 1:
+                    f.write(bytes([0x80 | (run - 1)]) + flat[i].tobytes())
+                    i += run
+                else:
+                    n = 1
+                    while i + n < len(flat) and n < 128 and not (flat[i + n] == flat[i + n - 1]).all():
+                        n += 1
+                    f.write(bytes([n - 1]) + flat[i:i + n].tobytes())
+                    i += n
+
+
+def write_texture_files(base_dir):
+    """The image files of textured_zoo(): a PNG (RGBA, all scanline filters), an RLE TGA, a non-power-of-two PFM."""
+    import os
+    import numpy as np
+    a = _texture_image(32, 16, 1)
+    write_png(os.path.join(base_dir, "tex_a.png"), a, with_alpha=True)
+    b = _texture_image(24, 20, 2)          # not a power of two: the MIPMap resamples it
+    write_tga(os.path.join(base_dir, "tex_b.tga"), b, rle=True)
+    c = (_texture_image(12, 10, 3).astype(np.float32) / 255.0) ** 2 * 1.5
+    with open(os.path.join(base_dir, "tex_c.pfm"), "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (c.shape[1], c.shape[0]))
+        f.write(c[::-1].astype(np.float32).tobytes())
+    return a, b, c
+
+
+TEXTURED_ZOO = """
+LookAt 0 2.2 -7  0 0.3 0  0 1 0
+Camera "perspective" "float fov" [42] %(lens)s
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [16 15 13]
+  Translate 0 5 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 0 -1.5  1.5 0 -1.5  1.5 0 1.5  -1.5 0 1.5]
+AttributeEnd
+LightSource "point" "rgb I" [10 10 12] "point from" [-3 3 -4]
+Texture "ewa_png" "spectrum" "imagemap" "string filename" "tex_a.png" "float uscale" [6] "float vscale" [6]
+Texture "tri_tga" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"] "float udelta" [.25]
+Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string wrap" "clamp" "float uscale" [2] "float vscale" [2] "float scale" [.8]
+Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2] "float maxanisotropy" [4]
+Texture "tga_nofilt" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool noFiltering" ["true"] "bool gamma" ["false"]
+# ground: matte, EWA-filtered at a grazing angle
+AttributeBegin
+  Material "matte" "texture Kd" "ewa_png"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# back wall: plastic with a textured Kd and a constant Ks
+AttributeBegin
+  Material "plastic" "texture Kd" "tri_tga" "rgb Ks" [.3 .3 .3] "float roughness" [.15]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
+AttributeEnd
+# uber with textured Kd and Ks (three lobes) on a tilted panel without uv (default parametrisation)
+AttributeBegin
+  Material "uber" "texture Kd" "pfm_clamp" "texture Ks" "png_black" "rgb Kr" [.1 .1 .1] "float roughness" [.2]
+  Translate -2.2 .8 0
+  Rotate 35 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0]
+AttributeEnd
+# substrate, both spectra textured
+AttributeBegin
+  Material "substrate" "texture Kd" "tga_nofilt" "texture Ks" "pfm_clamp" "float uroughness" [.2] "float vroughness" [.1]
+  Translate 0 .8 1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# mirror and translucent panels
+AttributeBegin
+  Material "mirror" "texture Kr" "png_black"
+  Translate 2.2 .8 0
+  Rotate -35 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+  Material "translucent" "texture Kd" "ewa_png" "rgb Ks" [.2 .2 .2] "rgb reflect" [.4 .5 .4] "rgb transmit" [.5 .4 .5]
+  Translate 0 2.6 2
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 -.5 0  1.5 -.5 0  1.5 .5 0  -1.5 .5 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# specular glass pane with a textured transmittance
+AttributeBegin
+  Material "glass" "texture Kt" "tri_tga" "rgb Kr" [.9 .9 .9]
+  Translate 0 .6 -2.5
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.7 -.6 0  .7 -.6 0  .7 .6 0  -.7 .6 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+WorldEnd
+"""
+
+
+def textured_zoo(res=64, spp=16, depth=5, lens=False):
+    """Quads with image-textured matte / plastic / uber / substrate / mirror / translucent / glass materials: PNG, TGA
+    and PFM files (write_texture_files), EWA / trilinear / unfiltered lookups, the three wrap modes, uv scale / offset,
+    black texels (lobes leave the BSDF), meshes with and without uv; lens=True adds a thin lens (differentials with
+    lens samples)."""
+    return TEXTURED_ZOO % dict(res=res, spp=spp, depth=depth,
+                               lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")

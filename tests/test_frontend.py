@@ -423,3 +423,88 @@ def test_spot_light_is_parsed(pt):
     w2l = np.array(list(l.w2l)).reshape(3, 3)
     assert np.allclose(w2l @ np.array([0, -1, 0]), [0, 0, 1], atol=1e-6)      # the spot's axis (0,-1,0) is +z in its frame
     assert np.allclose(w2l @ w2l.T, np.eye(3), atol=1e-6)
+
+
+def _mip_level(m, level):
+    w, h = max(1, m.width >> level), max(1, m.height >> level)
+    off = m.level_offset[level]
+    return np.array([m.texels[3 * off + i] for i in range(w * h * 3)], np.float32).reshape(h, w, 3)
+
+
+def test_image_texture_files_and_pyramid(pt, tmp_path):
+    """Texture "imagemap" on the host: PNG (RGBA, all five scanline filters, split IDAT), TGA (raw and run-length) and PFM
+    decode to the pixels that were written (imageio.cpp:216-287,349-435); level 0 is the image flipped in y, scaled, through
+    the inverse sRGB curve for 8-bit formats (imagemap.cpp:79-95); level l+1 is the 2x2 box filter of level l under the
+    wrap mode (mipmap.h:180-196); a 24x20 image is resampled to 32x32 (mipmap.h:130-176)."""
+    a = st._texture_image(32, 16, 1)
+    st.write_png(str(tmp_path / "a.png"), a, with_alpha=True)
+    st.write_tga(str(tmp_path / "b_raw.tga"), a, rle=False)
+    st.write_tga(str(tmp_path / "b_rle.tga"), a, rle=True)
+    pf = (a.astype(np.float32) / 255.0) * 3.0
+    with open(tmp_path / "c.pfm", "wb") as f:
+        f.write(b"PF\n32 16\n-1.0\n")
+        f.write(pf[::-1].tobytes())
+    st.write_tga(str(tmp_path / "odd.tga"), st._texture_image(24, 20, 2))
+    head = 'Camera "perspective"\nWorldBegin\n'
+    body = ""
+    for name, fn, extra in [("a", "a.png", '"bool gamma" ["false"]'), ("braw", "b_raw.tga", '"bool gamma" ["false"]'),
+                            ("brle", "b_rle.tga", '"bool gamma" ["false"]'), ("c", "c.pfm", '"float scale" [.5]'),
+                            ("g", "a.png", '"string wrap" "clamp"'), ("odd", "odd.tga", '"string wrap" "black"')]:
+        body += 'Texture "%s" "spectrum" "imagemap" "string filename" "%s" %s\n' % (name, fn, extra)
+        body += 'Material "matte" "texture Kd" "%s"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n' % name
+    s = pt.Scene(text=head + body + "WorldEnd\n", base_dir=str(tmp_path))
+    d = s.desc
+    assert s.errors == [] and d.n_textures == 6 and d.n_mipmaps == 6
+    want = a[::-1].astype(np.float32) / np.float32(255.0)
+    for i in range(3):   # PNG, raw TGA, RLE TGA: the same pixels
+        m = d.mipmaps[i]
+        assert (m.width, m.height, m.n_levels, m.wrap) == (32, 16, 6, 0)
+        assert np.array_equal(_mip_level(m, 0), want)
+    assert np.array_equal(_mip_level(d.mipmaps[3], 0), np.float32(0.5) * pf[::-1])
+    # inverse gamma (pbrt.h:301-304) on by default for .png / .tga
+    g = _mip_level(d.mipmaps[4], 0)
+    lin = np.where(want <= 0.04045, want / 12.92, ((want + 0.055) / 1.055) ** 2.4)
+    assert d.mipmaps[4].wrap == 2 and np.allclose(g, lin, rtol=2e-6, atol=1e-7)
+    # box-filtered levels, repeat wrap
+    m = d.mipmaps[0]
+    l0, l1 = _mip_level(m, 0), _mip_level(m, 1)
+    box = np.float32(.25) * (((l0[0::2, 0::2] + l0[0::2, 1::2]) + l0[1::2, 0::2]) + l0[1::2, 1::2])
+    assert np.array_equal(l1, box)
+    assert _mip_level(m, 5).shape == (1, 1, 3) and list(m.level_offset[:6]) == [0, 512, 640, 672, 680, 682]
+    # non-power-of-two: resampled up, clamped at 0 by the resampler
+    m = d.mipmaps[5]
+    assert (m.width, m.height, m.n_levels, m.wrap) == (32, 32, 6, 1)
+    up = _mip_level(m, 0)
+    src = st._texture_image(24, 20, 2)[::-1].astype(np.float32) / 255.0
+    src = np.where(src <= 0.04045, src / 12.92, ((src + 0.055) / 1.055) ** 2.4)
+    assert (up >= 0).all() and abs(up.mean() / src.mean() - 1) < 0.05
+    # the materials carry the binding
+    mats = [d.materials[i] for i in range(d.n_materials) if d.materials[i].textured]
+    assert len(mats) == 6 and all(mm.n_bxdfs == 1 and mm.tex[0].tex_R >= 0 and mm.tex[0].tex_S == -1 for mm in mats)
+    t = d.textures[0]
+    assert (t.filter, t.max_aniso, t.su, t.sv, t.du, t.dv) == (0, 8.0, 1.0, 1.0, 0.0, 0.0)
+
+
+def test_image_texture_scope_is_reported(pt, tmp_path):
+    """What this path does not evaluate is an error, not a silent constant."""
+    st.write_png(str(tmp_path / "a.png"), st._texture_image(8, 8, 1))
+    head = 'Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "a.png"\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    cases = {
+        'Texture "f" "float" "imagemap" "string filename" "a.png"\n' + tri: "float image textures",
+        'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
+        'Material "disney" "texture color" "t"\n' + tri: "Image texture",
+        'Material "matte" "texture Kd" "t"\nShape "sphere"\n': "sphere",
+        'Material "glass" "texture Kr" "t" "float uroughness" [.1] "float vroughness" [.1]\n' + tri: "rough",
+        'Texture "m" "spectrum" "imagemap" "string filename" "missing.png"\nMaterial "matte" "texture Kd" "m"\n' + tri: "missing.png",
+        'Texture "e" "spectrum" "imagemap" "string filename" "a.exr"\nMaterial "matte" "texture Kd" "e"\n' + tri: "exr",
+    }
+    for body, needle in cases.items():
+        s = pt.Scene(text=head + body + "WorldEnd\n", base_dir=str(tmp_path))
+        assert any(needle in e for e in s.errors), (needle, s.errors)
+    # a file that cannot be read becomes the reference's constant grey texture (imagemap.cpp:68-75), which then goes
+    # through convertIn like any other texel: .png -> inverse gamma of 0.5
+    s = pt.Scene(text=head + 'Texture "m" "spectrum" "imagemap" "string filename" "missing.png"\nMaterial "matte" "texture Kd" "m"\n' + tri + "WorldEnd\n",
+                 base_dir=str(tmp_path))
+    m = s.desc.mipmaps[s.desc.n_mipmaps - 1]
+    assert (m.width, m.height, m.n_levels) == (1, 1, 1) and all(abs(m.texels[i] - 0.21404114) < 1e-6 for i in range(3))

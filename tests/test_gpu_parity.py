@@ -343,3 +343,24 @@ def test_infinite_area_light_against_oracle(pt, ob, tmp_path, kind, strategy):
     assert _rel_l2(film, ofilm) < (1e-2 if (strategy == "spatial" and kind != "only_env") else 2e-4)
     assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
     assert film[:8].mean() > 0           # the sky is visible above the back wall: escaped camera rays see Le
+
+
+@pytest.mark.parametrize("lens", [False, True])
+def test_image_textures_against_oracle(pt, ob, tmp_path, lens):
+    """Texture "imagemap" (imagemap.cpp, mipmap.h) on Kd / Ks / Kr / Kt of matte, plastic, uber, substrate, mirror,
+    translucent and glass: PNG / TGA / PFM pyramids built by the host, EWA (default), trilinear and unfiltered lookups from
+    the hit's (u, v) and the camera ray's differentials (with and without a lens), wrap modes, uv scale / offset, and
+    lobes that leave the BSDF where their texture is black."""
+    st.write_texture_files(str(tmp_path))
+    s = pt.Scene(text=st.textured_zoo(res=64, spp=16, lens=lens), base_dir=str(tmp_path))
+    assert s.errors == []
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
+    assert np.array_equal(weight, oweight)
+    assert _rel_l2(film, ofilm) < 2e-4
+    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    # the textures show: the ground's chequer pattern makes neighbouring pixels differ far more than noise would
+    ground = film[40:60, 8:56].sum(axis=2)
+    assert ground.std() > 0.2 * ground.mean()

@@ -302,3 +302,74 @@ def test_distribution1d_known_answers(ob):
     o = _dist1d(ob, func, 0.75, 1)
     assert o[0] == pytest.approx(.9, rel=1e-6) and o[1] == pytest.approx(5 * 8. / 16., rel=1e-6) and o[2] == 4
     assert _dist1d(ob, func, 1., 1)[0] == pytest.approx(1., rel=1e-6)
+
+
+def test_mipmap_lookup_known_answers(pt, ob, tmp_path):
+    """MIPMap::Lookup (mipmap.h:238-385) on the oracle side, against values that follow from its definition: a texel
+    centre under the triangle filter is that texel; a constant image is constant under every filter (EWA weights are
+    normalised, mipmap.h:379); a footprint as wide as the image returns the 1x1 level = the mean of a power-of-two image;
+    a zero footprint takes the bilinear branch (mipmap.h:303); and the spectrum is Spectrum::FromRGB of the RGB value with
+    FromRGB's default type (Illuminant, spectrum.h:428-429) -- what a constant "rgb Kd" of that colour compiles to
+    (paramset.cpp:116)."""
+    img = st._texture_image(16, 8, 7)
+    st.write_png(str(tmp_path / "t.png"), img)
+    flat = np.full((8, 8, 3), 77, np.uint8)
+    st.write_png(str(tmp_path / "flat.png"), flat)
+    head = 'Camera "perspective"\nWorldBegin\n'
+    body = ""
+    for name, fn, extra in [("ewa", "t.png", ""), ("tri", "t.png", '"bool trilinear" ["true"]'), ("none", "t.png", '"bool noFiltering" ["true"]'),
+                            ("flat", "flat.png", ""), ("flat_tri", "flat.png", '"bool trilinear" ["true"]')]:
+        body += 'Texture "%s" "spectrum" "imagemap" "string filename" "%s" "bool gamma" ["false"] %s\n' % (name, fn, extra)
+        body += 'Material "matte" "texture Kd" "%s"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n' % name
+    s = pt.Scene(text=head + body + "WorldEnd\n", base_dir=str(tmp_path))
+    assert s.errors == []
+    tex = img[::-1].astype(np.float32) / np.float32(255)
+    for (i, j) in [(0, 0), (5, 3), (15, 7), (9, 6)]:
+        stc = ((i + 0.5) / 16, (j + 0.5) / 8)
+        for t in (0, 1, 2):   # zero footprint: bilinear at level 0 (EWA and trilinear), nearest texel (unfiltered)
+            rgb, _ = ob.texture_lookup(s, t, stc)
+            assert np.allclose(rgb, tex[j, i], rtol=0, atol=1e-7), (t, i, j)
+    # between texels the triangle filter interpolates
+    rgb, _ = ob.texture_lookup(s, 1, (6.0 / 16, 3.5 / 8))
+    assert np.allclose(rgb, 0.5 * (tex[3, 5] + tex[3, 6]), atol=1e-6)
+    # constant image: every filter, any footprint
+    for t in (3, 4):
+        for fp in [((0, 0), (0, 0)), ((.2, .01), (.01, .3)), ((.6, 0), (0, .002)), ((3, 1), (1, 2))]:
+            rgb, spec = ob.texture_lookup(s, t, (.37, .81), *fp)
+            assert np.allclose(rgb, 77 / 255, rtol=2e-6), (t, fp, rgb)
+    # footprint >= the image: the 1x1 level, i.e. the mean
+    rgb, _ = ob.texture_lookup(s, 1, (.3, .3), (.6, 0), (0, .6))
+    assert np.allclose(rgb, tex.reshape(-1, 3).mean(axis=0), rtol=1e-5)
+    rgb, _ = ob.texture_lookup(s, 0, (.3, .3), (2.0, 0), (0, 2.0))
+    assert np.allclose(rgb, tex.reshape(-1, 3).mean(axis=0), rtol=1e-5)
+    # an anisotropic footprint averages along its major axis (u) only: a row mean, not the image mean
+    rgb, _ = ob.texture_lookup(s, 0, (.5, 2.5 / 8), (.5, 0), (0, 1e-4))
+    assert np.abs(rgb - tex[2].mean(axis=0)).max() < 0.1 and np.abs(rgb - tex[2].mean(axis=0)).max() < np.abs(tex[6].mean(axis=0) - tex[2].mean(axis=0)).max()
+    # the same spectrum as the constant parameter path produces
+    rgb, spec = ob.texture_lookup(s, 3, (.5, .5))
+    v = 77 / 255
+    s2 = pt.Scene(text=head + 'Material "matte" "rgb Kd" [%r %r %r]\nShape "sphere"\nWorldEnd\n' % ((float(np.float32(v)),) * 3))
+    R = np.array(list(s2.desc.materials[s2.desc.n_materials - 1].bxdf[0].R), np.float32)
+    assert np.allclose(spec, R, rtol=1e-6)
+
+
+def test_textured_render_equals_the_constant_it_encodes(pt, ob, tmp_path):
+    """A 1x1 image texture is a constant: the oracle's render through the texture path (differentials, lookup, FromRGB,
+    per-hit lobe list) must equal the render with that colour as a plain "rgb" parameter -- same paths, same counters;
+    the values agree to rounding (the bilinear / EWA weights of the one texel sum to 1 only up to an ulp)."""
+    with open(tmp_path / "one.pfm", "wb") as f:
+        f.write(b"PF\n1 1\n-1.0\n")
+        f.write(np.array([.6, .3, .1], np.float32).tobytes())
+    zoo = st.material_zoo(res=24, spp=4, depth=4, strategy="power")
+    assert '"rgb Kd" [.6 .3 .1]' not in zoo
+    first_kd = zoo[zoo.index('Material "'):]
+    const = zoo.replace(first_kd.split("\n")[0], 'Material "plastic" "rgb Kd" [.6 .3 .1] "rgb Ks" [.2 .2 .2]', 1)
+    tex = zoo.replace(first_kd.split("\n")[0], 'Texture "one" "spectrum" "imagemap" "string filename" "one.pfm"\n'
+                      'Material "plastic" "texture Kd" "one" "rgb Ks" [.2 .2 .2]', 1)
+    a = pt.Scene(text=const, base_dir=str(tmp_path))
+    b = pt.Scene(text=tex, base_dir=str(tmp_path))
+    assert a.errors == [] and b.errors == [] and b.desc.n_textures == 1
+    fa, wa, ca, _ = ob.render(a, n_threads=4)
+    fb, wb, cb, _ = ob.render(b, n_threads=4)
+    assert np.array_equal(wa, wb) and ca.as_dict() == cb.as_dict()
+    assert np.allclose(fa, fb, rtol=2e-6, atol=0)
