@@ -142,6 +142,14 @@ struct Api {
     ParamSet filterParams, filmParams, samplerParams, accelParams, integratorParams, cameraParams;
     Transform cameraToWorld;
     std::vector<PendingPrim> pending;
+    // Object instancing (api.cpp:1544-1615). The reference keeps an instance's primitives in their own BVH behind a
+    // TransformedPrimitive and transforms each ray into it; this build has one BVH over world-space geometry,
+    // so an ObjectInstance re-creates the recorded shapes under InstanceToWorld * (the CTM they were declared with):
+    // the same surfaces, hit points that differ from the reference's in rounding only.
+    struct RecordedShape { std::string name; ParamSet params; Transform ctm; GraphicsState gs; };
+    std::map<std::string, std::vector<RecordedShape>> instances;
+    std::vector<RecordedShape> *currentInstance = nullptr;
+    std::map<std::string, std::shared_ptr<PLYMeshData>> plyCache;   // an instanced plymesh is read once
     bool worldEnded = false;
     bool fatal = false;
     std::string fatalMsg;
@@ -297,6 +305,13 @@ struct Api {
 
     void Shape(const std::string &name, const ParamSet &params) {
         if (state != World) { Err("Scene description must be inside world block; \"Shape\" not allowed. Ignoring."); return; }
+        if (currentInstance) {   // api.cpp:1431-1435
+            if (gs.areaLight != "") Warn("Area lights not supported with object instancing");
+            RecordedShape r{name, params, ctm, gs};
+            r.gs.areaLight = "";
+            currentInstance->push_back(std::move(r));
+            return;
+        }
         int firstTri = -1, nTris = 0;
         int sphereIdx = -1;
         if (name == "trianglemesh") {  // CreateTriangleMeshShape, triangle.cpp:642-740
@@ -335,12 +350,16 @@ struct Api {
         } else if (name == "plymesh") {  // CreatePLYMesh, plymesh.cpp:149-283
             std::string fn = params.FindOneString("filename", "");
             if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;  // FindOneFilename -> AbsolutePath(ResolveFilename())
-            PLYMeshData ply;
-            std::vector<std::string> w;
-            std::string e;
-            const bool okPly = ReadPLYMesh(fn, &ply, &w, &e);
-            for (const std::string &m : w) Warn(m);
-            if (!okPly) { Err(e); return; }
+            std::shared_ptr<PLYMeshData> &cached = plyCache[fn];
+            if (!cached) {
+                cached = std::make_shared<PLYMeshData>();
+                std::vector<std::string> w;
+                std::string e;
+                const bool okPly = ReadPLYMesh(fn, cached.get(), &w, &e);
+                for (const std::string &m : w) Warn(m);
+                if (!okPly) { Err(e); cached.reset(); plyCache.erase(fn); return; }
+            }
+            const PLYMeshData &ply = *cached;
             if (params.FindTexture("alpha") != "" || params.FindTexture("shadowalpha") != "" ||
                 params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
                 Err("alpha-mask textures are outside the hot-path scope (SURVEY 8f item 1); ignored");
@@ -410,6 +429,35 @@ struct Api {
         std::vector<std::string> unused;
         params.ReportUnused(&unused);
         for (auto &u : unused) Warn("Parameter \"" + u + "\" not used");
+    }
+
+    void ObjectBegin(const std::string &name) {  // api.cpp:1544-1553
+        gsStack.push_back(gs); transformStack.push_back(ctm); pushKinds.push_back('a');
+        if (currentInstance) Err("ObjectBegin called inside of instance definition");
+        instances[name] = std::vector<RecordedShape>();
+        currentInstance = &instances[name];
+    }
+    void ObjectEnd() {  // api.cpp:1557-1566
+        if (!currentInstance) Err("ObjectEnd called outside of instance definition");
+        currentInstance = nullptr;
+        if (gsStack.empty()) { Err("Unmatched AttributeEnd encountered. Ignoring it."); return; }
+        gs = gsStack.back(); gsStack.pop_back();
+        ctm = transformStack.back(); transformStack.pop_back();
+        pushKinds.pop_back();
+    }
+    void ObjectInstance(const std::string &name) {  // api.cpp:1570-1615
+        if (currentInstance) { Err("ObjectInstance can't be called inside instance definition"); return; }
+        auto it = instances.find(name);
+        if (it == instances.end()) { Err("Unable to find instance named \"" + name + "\""); return; }
+        const Transform instanceToWorld = ctm;
+        const GraphicsState saved = gs;
+        for (const RecordedShape &r : it->second) {
+            ctm = instanceToWorld * r.ctm;
+            gs = r.gs;
+            Shape(r.name, r.params);
+        }
+        ctm = instanceToWorld;
+        gs = saved;
     }
 
     void LightSource(const std::string &name, const ParamSet &ps) {  // MakeLight, api.cpp:747-771
@@ -1092,8 +1140,12 @@ bool Parser::Run() {
             return true;  // one render per file on this path
         } else if (tok == "ObjectBegin" || tok == "ObjectInstance") {
             std::string n; if (!ReadString(&n)) return false;
-            a.Err(tok + " \"" + n + "\": object instancing is outside the hot-path scope (SURVEY 2 row 15)");
-        } else if (tok == "ObjectEnd") { /* paired with the error above */ }
+            if (!needWorld(tok.c_str())) continue;
+            if (tok == "ObjectBegin") a.ObjectBegin(n); else a.ObjectInstance(n);
+        } else if (tok == "ObjectEnd") {
+            if (!needWorld("ObjectEnd")) continue;
+            a.ObjectEnd();
+        }
         else if (tok == "MediumInterface") {
             std::string n; if (!ReadString(&n)) return false;
             std::string t2; bool q2;

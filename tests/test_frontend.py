@@ -119,14 +119,12 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     Material "hair"
     Shape "cylinder"
     LightSource "goniometric"
-    ObjectBegin "o"
-    ObjectEnd
     Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
     WorldEnd
     """
     s = pt.Scene(text=txt)
     errs = "\n".join(s.errors)
-    for word in ("orthographic", "sobol", "bdpt", "hair", "cylinder", "goniometric", "instancing"):
+    for word in ("orthographic", "sobol", "bdpt", "hair", "cylinder", "goniometric"):
         assert word in errs, word
     assert s.stats["n_triangles"] == 1
 
@@ -508,3 +506,43 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
                  base_dir=str(tmp_path))
     m = s.desc.mipmaps[s.desc.n_mipmaps - 1]
     assert (m.width, m.height, m.n_levels) == (1, 1, 1) and all(abs(m.texels[i] - 0.21404114) < 1e-6 for i in range(3))
+
+
+def test_object_instances_expand_to_the_declared_shapes(pt):
+    """ObjectBegin / ObjectEnd / ObjectInstance (api.cpp:1431-1435,1544-1615): an instance re-creates the object's shapes under
+    InstanceToWorld * (CTM at declaration), with the material and orientation bound at declaration; a mirrored instance flips
+    the mesh's handedness flag; misuse is reported with the reference's messages."""
+    head = 'Camera "perspective"\nWorldBegin\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] "normal N" [0 0 1 0 0 1 0 0 1]\n'
+    obj = ('Translate 0 0 1\nObjectBegin "thing"\n  Material "plastic" "rgb Kd" [.1 .2 .3]\n  Translate 1 0 0\n  ' + tri +
+           '  Rotate 30 0 1 0\n  Shape "sphere" "float radius" [.5]\nObjectEnd\n')
+    uses = [("Translate 3 0 0\n", False), ("Rotate 45 0 0 1\nScale 2 2 2\n", False), ("Scale -1 1 1\n", True)]
+    inst = head + obj + 'Material "matte"\n' + "".join("AttributeBegin\n%sObjectInstance \"thing\"\nAttributeEnd\n" % u for u, _ in uses) + "WorldEnd\n"
+    # (the Translate before ObjectBegin is still the CTM at the instances: it applies once there and once in the declaration)
+    flat = head + 'Translate 0 0 1\n' + "".join('AttributeBegin\n%sTranslate 0 0 1\nMaterial "plastic" "rgb Kd" [.1 .2 .3]\nTranslate 1 0 0\n%sRotate 30 0 1 0\n'
+                          'Shape "sphere" "float radius" [.5]\nAttributeEnd\n' % (u, tri) for u, _ in uses) + "WorldEnd\n"
+    a, b = pt.Scene(text=inst), pt.Scene(text=flat)
+    assert a.errors == [] and b.errors == []
+    da, db = a.desc, b.desc
+    assert (da.n_tris, da.n_spheres, da.n_meshes, da.n_prims) == (3, 3, 3, 6) == (db.n_tris, db.n_spheres, db.n_meshes, db.n_prims)
+    Pa = np.array([da.P[i] for i in range(27)]); Pb = np.array([db.P[i] for i in range(27)])
+    Na = np.array([da.N[i] for i in range(27)]); Nb = np.array([db.N[i] for i in range(27)])
+    assert np.allclose(Pa, Pb, rtol=1e-6, atol=1e-6) and np.allclose(Na, Nb, rtol=1e-6, atol=1e-6)
+    assert [da.meshes[i].flags & 4 for i in range(3)] == [0, 0, 4] == [db.meshes[i].flags & 4 for i in range(3)]   # MI_MESH_FLIP
+    for i in range(3):
+        assert np.allclose(list(da.spheres[i].o2w), list(db.spheres[i].o2w), rtol=1e-6, atol=1e-6)
+        assert da.spheres[i].swaps_handedness == db.spheres[i].swaps_handedness == (1 if uses[i][1] else 0)
+    # every primitive carries the material bound inside the object, not the one current at the instance
+    kinds = {da.materials[da.prims[i].material].kind for i in range(da.n_prims)}
+    assert kinds == {1}
+    # the object itself adds nothing to the scene
+    s = pt.Scene(text=head + obj + "WorldEnd\n")
+    assert s.errors == [] and s.desc.n_prims == 0
+    for text, needle in [(head + 'ObjectInstance "nope"\nWorldEnd\n', "Unable to find instance named"),
+                         (head + 'ObjectBegin "a"\nObjectBegin "b"\nObjectEnd\nObjectEnd\nWorldEnd\n', "ObjectBegin called inside of instance definition"),
+                         (head + 'ObjectEnd\nWorldEnd\n', "ObjectEnd called outside of instance definition"),
+                         (head + 'ObjectBegin "a"\nObjectInstance "a"\nObjectEnd\nWorldEnd\n', "ObjectInstance can't be called inside instance definition")]:
+        s = pt.Scene(text=text)
+        assert any(needle in e for e in s.errors), (needle, s.errors)
+    s = pt.Scene(text=head + 'ObjectBegin "l"\nAreaLightSource "diffuse"\n' + tri + 'ObjectEnd\nObjectInstance "l"\nWorldEnd\n')
+    assert any("Area lights not supported with object instancing" in w for w in s.warnings) and s.desc.n_lights == 0
