@@ -150,6 +150,7 @@ struct Api {
     std::map<std::string, std::vector<RecordedShape>> instances;
     std::vector<RecordedShape> *currentInstance = nullptr;
     std::map<std::string, std::shared_ptr<PLYMeshData>> plyCache;   // an instanced plymesh is read once
+    std::map<std::string, Spectrum> cachedSpectra;                  // paramset.cpp:48, SPD files by name
     bool worldEnded = false;
     bool fatal = false;
     std::string fatalMsg;
@@ -876,6 +877,59 @@ void Api::WorldEnd() {
     scene->Finalize();
 }
 
+// ReadFloatFile, src/core/floatfile.cpp:40-83 (including its habit of dropping a number that ends at end-of-file)
+bool ReadFloatFile(const std::string &filename, std::vector<float> *values, Api *api) {
+    FILE *f = fopen(filename.c_str(), "r");
+    if (!f) { api->Err("Unable to open file \"" + filename + "\""); return false; }
+    int c;
+    bool inNumber = false;
+    char curNumber[32];
+    int curNumberPos = 0;
+    int lineNumber = 1;
+    while ((c = getc(f)) != EOF) {
+        if (c == '\n') ++lineNumber;
+        if (inNumber) {
+            if (curNumberPos >= (int)sizeof(curNumber) - 1) { api->Err("Overflowed buffer for parsing number in file: " + filename); fclose(f); return false; }
+            if (isdigit(c) || c == '.' || c == 'e' || c == '-' || c == '+') curNumber[curNumberPos++] = (char)c;
+            else {
+                curNumber[curNumberPos++] = '\0';
+                values->push_back((float)atof(curNumber));
+                inNumber = false;
+                curNumberPos = 0;
+            }
+        } else {
+            if (isdigit(c) || c == '.' || c == '-' || c == '+') { inNumber = true; curNumber[curNumberPos++] = (char)c; }
+            else if (c == '#') {
+                while ((c = getc(f)) != '\n' && c != EOF) {}
+                ++lineNumber;
+            } else if (!isspace(c))
+                api->Warn("Unexpected text found at line " + std::to_string(lineNumber) + " of float file \"" + filename + "\"");
+        }
+    }
+    fclose(f);
+    return true;
+}
+
+// Blackbody / BlackbodyNormalized, src/core/spectrum.cpp:1009-1034
+void Blackbody(const float *lambda, int n, float T, float *Le) {
+    if (T <= 0) { for (int i = 0; i < n; ++i) Le[i] = 0.f; return; }
+    const float c = 299792458;
+    const float h = 6.62606957e-34;
+    const float kb = 1.3806488e-23;
+    for (int i = 0; i < n; ++i) {
+        float l = lambda[i] * 1e-9;
+        float lambda5 = (l * l) * (l * l) * l;
+        Le[i] = (2 * h * c * c) / (lambda5 * (std::exp((h * c) / (l * kb * T)) - 1));
+    }
+}
+void BlackbodyNormalized(const float *lambda, int n, float T, float *Le) {
+    Blackbody(lambda, n, T, Le);
+    float lambdaMax = 2.8977721e-3 / T * 1e9;
+    float maxL;
+    Blackbody(&lambdaMax, 1, T, &maxL);
+    for (int i = 0; i < n; ++i) Le[i] /= maxL;
+}
+
 // ------------------------------------------------------------------ parser
 enum ParamType { PT_INT, PT_BOOL, PT_FLOAT, PT_POINT2, PT_VECTOR2, PT_POINT3, PT_VECTOR3, PT_NORMAL, PT_RGB, PT_XYZ,
                  PT_BLACKBODY, PT_SPECTRUM, PT_STRING, PT_TEXTURE, PT_UNKNOWN };
@@ -968,8 +1022,27 @@ struct Parser {
             } else if (!addVal(val, vq)) return false;
             if (!known) { api->Warn("Type of parameter \"" + decl + "\" is unknown"); continue; }
             bool wantString = (type == PT_STRING || type == PT_TEXTURE || type == PT_BOOL);
-            if (type == PT_SPECTRUM && !strs.empty()) {
-                api->Err("spectrum files (\"spectrum " + name + "\") are outside the hot-path scope"); continue;
+            if (type == PT_SPECTRUM && !strs.empty()) {  // AddSampledSpectrumFiles, paramset.cpp:171-207
+                std::vector<Spectrum> v;
+                for (const std::string &nm : strs) {
+                    const std::string fn = (!nm.empty() && nm[0] != '/') ? api->baseDir + "/" + nm : nm;
+                    auto cached = api->cachedSpectra.find(fn);
+                    if (cached != api->cachedSpectra.end()) { v.push_back(cached->second); continue; }
+                    std::vector<float> vals;
+                    Spectrum sp(0.f);
+                    if (!ReadFloatFile(fn, &vals, api))
+                        api->Warn("Unable to read SPD file \"" + fn + "\".  Using black distribution.");
+                    else {
+                        if (vals.size() % 2) api->Warn("Extra value found in spectrum file \"" + fn + "\". Ignoring it.");
+                        std::vector<float> wls, vv;
+                        for (size_t j = 0; j < vals.size() / 2; ++j) { wls.push_back(vals[2 * j]); vv.push_back(vals[2 * j + 1]); }
+                        if (!wls.empty()) sp = Spectrum::FromSampled(wls.data(), vv.data(), (int)wls.size());
+                    }
+                    api->cachedSpectra[fn] = sp;
+                    v.push_back(sp);
+                }
+                ParamSet::Add(ps->spectra, name, v);
+                continue;
             }
             if (wantString && strs.empty() && !nums.empty()) { api->Err("Expected string parameter value for \"" + name + "\""); continue; }
             if (!wantString && !strs.empty()) { api->Err("Expected numeric parameter value for \"" + name + "\""); continue; }
@@ -1022,8 +1095,19 @@ struct Parser {
                 ParamSet::Add(ps->spectra, name, v);
                 break;
             }
-            case PT_BLACKBODY:
-                api->Err("\"" + decl + "\": blackbody spectra are outside the hot-path scope"); break;
+            case PT_BLACKBODY: {  // AddBlackbodySpectrum, paramset.cpp:133-150: (temperature K, scale) pairs
+                if (n % 2) { api->Warn("Excess value given with blackbody parameter \"" + name + "\". Ignoring extra one."); n -= n % 2; }
+                std::vector<Spectrum> v;
+                const int nCIESamples = 471;   // CIE_lambda = 360 .. 830 nm, spectrum.cpp:543
+                std::vector<float> lambda(nCIESamples), le(nCIESamples);
+                for (int i = 0; i < nCIESamples; ++i) lambda[i] = (float)(360 + i);
+                for (size_t i = 0; i < n / 2; ++i) {
+                    BlackbodyNormalized(lambda.data(), nCIESamples, f(2 * i), le.data());
+                    v.push_back(f(2 * i + 1) * Spectrum::FromSampled(lambda.data(), le.data(), nCIESamples));
+                }
+                ParamSet::Add(ps->spectra, name, v);
+                break;
+            }
             case PT_STRING: ParamSet::Add(ps->strings, name, strs); break;
             case PT_TEXTURE:
                 if (strs.size() == 1) ParamSet::Add(ps->textures, name, strs);

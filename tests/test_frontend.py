@@ -546,3 +546,31 @@ def test_object_instances_expand_to_the_declared_shapes(pt):
         assert any(needle in e for e in s.errors), (needle, s.errors)
     s = pt.Scene(text=head + 'ObjectBegin "l"\nAreaLightSource "diffuse"\n' + tri + 'ObjectEnd\nObjectInstance "l"\nWorldEnd\n')
     assert any("Area lights not supported with object instancing" in w for w in s.warnings) and s.desc.n_lights == 0
+
+
+def test_spectrum_files_and_blackbody_parameters(pt, tmp_path):
+    """ "spectrum name" "file.spd" (AddSampledSpectrumFiles, paramset.cpp:171-207, ReadFloatFile floatfile.cpp:40-83) and
+    "blackbody name" [T scale] (AddBlackbodySpectrum, paramset.cpp:133-150; BlackbodyNormalized, spectrum.cpp:1009-1034)."""
+    (tmp_path / "a.spd").write_text("# wavelength value\n400 1\n500 2 # comment\n600 3\n700 1.5\n")
+    (tmp_path / "cut.spd").write_text("400 1 500 2")   # no trailing whitespace: the reference's reader drops the last number
+    head = 'Camera "perspective"\nWorldBegin\n'
+    def light_L(body):
+        s = pt.Scene(text=head + body + '\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
+        return s, np.array(list(s.desc.lights[0].L), np.float32)
+    s1, from_file = light_L('LightSource "point" "spectrum I" "a.spd"')
+    s2, inline = light_L('LightSource "point" "spectrum I" [400 1 500 2 600 3 700 1.5]')
+    assert s1.errors == [] and np.array_equal(from_file, inline) and from_file[0] > 0.9 and from_file.max() <= 3
+    s3, cut = light_L('LightSource "point" "spectrum I" "cut.spd"')
+    assert any("Extra value found in spectrum file" in w for w in s3.warnings) and np.allclose(cut, 1.0)   # one sample: constant
+    s4, missing = light_L('LightSource "point" "spectrum I" "nope.spd"')
+    assert any("Unable to read SPD file" in w for w in s4.warnings) and not missing.any()
+    # blackbody: Planck's law normalised to its peak (Wien), times the scale
+    s5, bb = light_L('LightSource "point" "blackbody I" [6500 2]')
+    assert s5.errors == []
+    lam = np.arange(360, 831, dtype=np.float64) * 1e-9
+    c, h, kb, T = 299792458.0, 6.62606957e-34, 1.3806488e-23, 6500.0
+    planck = lambda l: (2 * h * c * c) / (l ** 5 * (np.exp((h * c) / (l * kb * T)) - 1))
+    norm = planck(lam) / planck(2.8977721e-3 / T)
+    centres = 395 + 10 * np.arange(31) + 5
+    want = np.array([np.trapezoid(norm[(cc - 5 - 360):(cc + 5 - 360) + 1], dx=1.0) / 10 for cc in centres]) * 2
+    assert np.allclose(bb, want, rtol=2e-4) and abs(bb.max() / 2 - 1) < 0.01 and bb[0] > bb[-1]
