@@ -69,6 +69,10 @@ typedef struct mi_mesh {
     uint32_t flags;
     uint32_t first_vertex, n_vertices;
     uint32_t first_tri, n_tris;
+    /* "alpha" / "shadowalpha" float textures (triangle.cpp:331-338,531-570,716-740): index into textures, -1 = none.
+     * A hit whose texture value is exactly 0 is no hit ("shadowalpha" for IntersectP only). The value is channel 0 of the
+     * texture (float image textures are stored grey), looked up with zero footprint. */
+    int32_t alpha_tex, shadow_alpha_tex;
 } mi_mesh;
 
 /* Sphere (src/shapes/sphere.h:49-66). Matrices row-major, m[r*4+c]. */
@@ -165,7 +169,7 @@ typedef struct mi_mipmap {
     uint32_t level_offset[MI_MAX_MIP_LEVELS]; /* first texel of level l */
 } mi_mipmap;
 typedef enum mi_tex_filter { MI_TEX_EWA = 0, MI_TEX_TRILINEAR = 1, MI_TEX_NONE = 2 /* "noFiltering" */ } mi_tex_filter;
-typedef struct mi_texture {
+typedef struct mi_texture {   /* spectrum textures: RGB pyramid; float textures: the same with r = g = b (convertIn, imagemap.h:107-110) */
     int32_t mipmap;         /* index into mi_scene_desc.mipmaps */
     int32_t filter;         /* mi_tex_filter */
     float max_aniso;        /* "maxanisotropy" */

@@ -121,6 +121,10 @@ inline bool TriTest(const V3 &p0, const V3 &p1, const V3 &p2, const Ray &ray, Tr
     return true;
 }
 
+// Texture<Float>::Evaluate of an "alpha" texture at (u, v) with the zero footprint of Triangle::Intersect's isectLocal
+// (triangle.cpp:331-338); defined in o_texture.h.
+Float AlphaTextureValue(const mi_scene_desc &d, int tex, Float u, Float v);
+
 // dpdu/dpdv for a triangle; false when the triangle itself is degenerate
 // (triangle.cpp:293-317: such an intersection is rejected by Intersect).
 inline bool TriPartials(const mi_scene_desc &d, int tri, const TriVerts &tv, V3 *dpdu, V3 *dpdv) {
@@ -144,7 +148,27 @@ inline bool TriPartials(const mi_scene_desc &d, int tri, const TriVerts &tv, V3 
     return true;
 }
 
-// Triangle::Intersect, triangle.cpp:188-425 (alpha masks out of scope).
+// Triangle::IntersectP, triangle.cpp:427-574: the t test, then -- only for meshes with an alpha mask -- the degenerate-
+// triangle rejection and the "alpha" / "shadowalpha" tests.
+inline bool TriIntersectP(const mi_scene_desc &d, int tri, const Ray &ray) {
+    TriVerts tv = GetTri(d, tri);
+    TriHit h;
+    if (!TriTest(tv.p0, tv.p1, tv.p2, ray, &h)) return false;
+    const mi_mesh &mesh = d.meshes[d.tri_mesh[tri]];
+    if (mesh.alpha_tex >= 0 || mesh.shadow_alpha_tex >= 0) {
+        V3 dpdu, dpdv;
+        if (!TriPartials(d, tri, tv, &dpdu, &dpdv)) return false;
+        Float uv[3][2];
+        GetUVs(d, tri, uv);
+        Float uHit = h.b0 * uv[0][0] + h.b1 * uv[1][0] + h.b2 * uv[2][0];
+        Float vHit = h.b0 * uv[0][1] + h.b1 * uv[1][1] + h.b2 * uv[2][1];
+        if (mesh.alpha_tex >= 0 && AlphaTextureValue(d, mesh.alpha_tex, uHit, vHit) == 0) return false;
+        if (mesh.shadow_alpha_tex >= 0 && AlphaTextureValue(d, mesh.shadow_alpha_tex, uHit, vHit) == 0) return false;
+    }
+    return true;
+}
+
+// Triangle::Intersect, triangle.cpp:188-425.
 inline bool TriIntersect(const mi_scene_desc &d, int tri, const Ray &ray, Float *tHit, SurfaceInteraction *isect) {
     TriVerts tv = GetTri(d, tri);
     TriHit h;
@@ -163,6 +187,7 @@ inline bool TriIntersect(const mi_scene_desc &d, int tri, const Ray &ray, Float 
     Float uHit = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     Float vHit = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
     const mi_mesh &mesh = d.meshes[d.tri_mesh[tri]];
+    if (mesh.alpha_tex >= 0 && AlphaTextureValue(d, mesh.alpha_tex, uHit, vHit) == 0) return false;   // triangle.cpp:331-338
     bool flip = (mesh.flags & MI_MESH_FLIP) != 0;
     InitSurfaceInteraction(isect, pHit, pError, uHit, vHit, -ray.d, dpdu, dpdv, V3(0, 0, 0), V3(0, 0, 0), flip);
     V3 dp02 = p0 - p2, dp12 = p1 - p2;

@@ -204,6 +204,14 @@ inline Spec SpecFromRGBIllum(const mi_scene_desc &d, const Float rgb[3]) {
     return r;
 }
 
+inline Float AlphaTextureValue(const mi_scene_desc &d, int tex, Float u, Float v) {
+    const mi_texture &t = d.textures[tex];
+    const Float zero[2] = {0, 0};
+    const Float st[2] = {t.su * u + t.du, t.sv * v + t.dv};
+    MipView mip{d.mipmaps[t.mipmap]};
+    return mip.Lookup(st, zero, zero, t.filter, t.max_aniso).c[0];
+}
+
 // Texture<Spectrum>::Evaluate(si).Clamp() for image texture `tex`
 inline Spec EvalImageTexture(const mi_scene_desc &d, int tex, const SurfaceInteraction &si, const TexDifferentials &td) {
     const mi_texture &t = d.textures[tex];

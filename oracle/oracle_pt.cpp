@@ -186,9 +186,7 @@ struct Scene {
         const mi_prim &p = d.prims[primIdx];
         if (p.shape >= 0) {
             ++c.triTests;
-            TriVerts tv = GetTri(d, p.shape);
-            TriHit h;
-            return TriTest(tv.p0, tv.p1, tv.p2, ray, &h);
+            return TriIntersectP(d, p.shape, ray);
         }
         return SphereIntersectP(d.spheres[~p.shape], ray);
     }

@@ -34,7 +34,7 @@ class Prim(C.Structure):
 
 class Mesh(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("first_vertex", C.c_uint32), ("n_vertices", C.c_uint32),
-                ("first_tri", C.c_uint32), ("n_tris", C.c_uint32)]
+                ("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("alpha_tex", C.c_int32), ("shadow_alpha_tex", C.c_int32)]
 
 
 class Sphere(C.Structure):

@@ -22,6 +22,7 @@ namespace dpt {
 
 #define PRIM_FLAG_SPHERE 1u
 #define PRIM_FLAG_DEGENERATE 2u
+#define PRIM_FLAG_ALPHA 32u   // the triangle's mesh has an "alpha" / "shadowalpha" mask (mi_mesh.alpha_tex)
 #define PRIM_CLASS_SHIFT 2      /* bits 2-4: shading class of the primitive's material (7 = no BSDF) */
 
 struct DScene {

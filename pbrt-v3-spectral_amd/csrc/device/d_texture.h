@@ -200,6 +200,25 @@ DEV RGB3 MipLookup(const DScene &s, const mi_mipmap &m, float st0, float st1, fl
     return (1 - t) * MipEWA(s, m, ilod, st0, st1, a0, a1, b0, b1) + t * MipEWA(s, m, ilod + 1, st0, st1, a0, a1, b0, b1);
 }
 
+// The alpha tests of Triangle::Intersect / IntersectP (triangle.cpp:331-338, 531-570) for a candidate hit of triangle
+// `tri` at barycentrics (b0, b1, b2): false = the hit does not count. The texture is evaluated as the reference
+// evaluates it on isectLocal: (u, v) of the hit, zero footprint. `shadow`: IntersectP also tests "shadowalpha".
+DEV float AlphaTextureValue(const DScene &s, int tex, float u, float v) {
+    const mi_texture &t = s.textures[tex];
+    const mi_mipmap &m = s.mipmaps[t.mipmap];
+    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, 0.f, 0.f, 0.f, 0.f, t.filter, t.max_aniso).r;
+}
+DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool shadow) {
+    const mi_mesh m = s.meshes[s.triMesh[tri]];
+    float uv[3][2];
+    GetUVs(s, tri, m, uv);
+    const float u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+    const float v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+    if (m.alpha_tex >= 0 && AlphaTextureValue(s, m.alpha_tex, u, v) == 0.f) return false;
+    if (shadow && m.shadow_alpha_tex >= 0 && AlphaTextureValue(s, m.shadow_alpha_tex, u, v) == 0.f) return false;
+    return true;
+}
+
 // Texture<Spectrum>::Evaluate(si) of image texture `tex` in FromRGB's compact form (see IllumRGB)
 DEV IllumRGB EvalImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
     const mi_texture &t = s.textures[tex];

@@ -383,6 +383,8 @@ DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *
             ++triCount;
             TriHit th;
             if (TriTest(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), ro, rd, tMax, &th)) {
+                if ((pf & PRIM_FLAG_ALPHA) &&
+                    ((pf & PRIM_FLAG_DEGENERATE) || !AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY))) continue;
                 if (ANY) return true;
                 if (!(pf & PRIM_FLAG_DEGENERATE)) {
                     tMax = th.t;
@@ -558,7 +560,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     TriHit th;
                     if (TriTestRay(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), V3(r.ox, r.oy, r.oz),
                                    triRay, tMax, &th)) {
-                        if (ANY) { hitPrim = prim; finished = true; }
+                        // meshes with an alpha mask: IntersectP then rejects degenerate triangles too, and both reject
+                        // hits where the mask is 0 (triangle.cpp:331-338, 531-570)
+                        bool counts = true;
+                        if (pf & PRIM_FLAG_ALPHA)
+                            counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
+                        if (!counts) {}
+                        else if (ANY) { hitPrim = prim; finished = true; }
                         else if (!(pf & PRIM_FLAG_DEGENERATE)) {
                             tMax = th.t;
                             hitPrim = prim; hitT = th.t; hitB0 = th.b0; hitB1 = th.b1; hitB2 = th.b2;
@@ -1699,6 +1707,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                     float cx = (float)cr[0], cy = (float)cr[1], cz = (float)cr[2];
                     if (cx * cx + cy * cy + cz * cz == 0) flags |= PRIM_FLAG_DEGENERATE;
                 }
+                if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) flags |= PRIM_FLAG_ALPHA;
             } else {
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
@@ -1798,6 +1807,8 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             }
             UP(lut, (size_t)128, s.ewaWeights);
             s.invSqrtSpp = 1 / std::sqrt((float)d->sampler.samples_per_pixel);
+            for (uint32_t i = 0; i < d->n_meshes; ++i)
+                if (d->meshes[i].alpha_tex >= (int)d->n_textures || d->meshes[i].shadow_alpha_tex >= (int)d->n_textures) { g_err = "mi_mesh alpha texture index out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
             for (uint32_t i = 0; i < d->n_materials; ++i)
                 for (int j = 0; d->materials[i].textured && j < d->materials[i].n_bxdfs; ++j) {
                     const mi_lobe_tex &t = d->materials[i].tex[j];

@@ -233,9 +233,28 @@ struct Api {
 
     // Append a TriangleMesh (src/shapes/triangle.cpp:54-92): world-space P, N.
     // Returns first triangle index.
+    // "alpha" / "shadowalpha" of a mesh (triangle.cpp:716-740): a named float texture or the constant 0
+    int AlphaTexture(const ParamSet &params, const char *param) {
+        const std::string texName = params.FindTexture(param);
+        if (texName != "") {
+            auto it = gs.textures.floatImageTex.find(texName);
+            if (it != gs.textures.floatImageTex.end()) return it->second;
+            auto c = gs.textures.floatTex.find(texName);
+            if (c == gs.textures.floatTex.end()) { Err("Couldn't find float texture \"" + texName + "\" for \"" + param + "\" parameter"); return -1; }
+            if (c->second != 0.f) return -1;   // a constant that is never 0 masks nothing
+        } else if (params.FindOneFloat(param, 1.f) != 0.f)
+            return -1;
+        mi_texture t{};
+        t.mipmap = ConstantFloatMipMap(scene, 0.f);
+        t.filter = MI_TEX_TRILINEAR; t.max_aniso = 8.f; t.su = t.sv = 1.f;
+        scene->textures.push_back(t);
+        return (int)scene->textures.size() - 1;
+    }
+
     int AddTriangleMesh(const std::vector<int> &indices, const std::vector<Vec3> &P,
-                        const std::vector<Vec3> *N, const std::vector<Vec2> *UV) {
+                        const std::vector<Vec3> *N, const std::vector<Vec2> *UV, int alphaTex = -1, int shadowAlphaTex = -1) {
         mi_mesh mesh{};
+        mesh.alpha_tex = alphaTex; mesh.shadow_alpha_tex = shadowAlphaTex;
         mesh.first_vertex = (uint32_t)(scene->P.size() / 3);
         mesh.n_vertices = (uint32_t)P.size();
         mesh.first_tri = (uint32_t)(scene->triIndices.size() / 3);
@@ -343,11 +362,10 @@ struct Api {
             if (N && N->size() != P->size()) { Err("Number of \"N\"s for triangle mesh must match \"P\"s"); N = nullptr; }
             for (int idx : *vi)
                 if (idx >= (int)P->size() || idx < 0) { Err("trianglemesh has out of-bounds vertex index"); return; }
-            if (params.FindTexture("alpha") != "" || params.FindTexture("shadowalpha") != "")
-                Err("alpha-mask textures are outside the hot-path scope (SURVEY 8f item 1); ignored");
             std::vector<int> idx(vi->begin(), vi->begin() + (vi->size() / 3) * 3);
             nTris = (int)idx.size() / 3;
-            firstTri = AddTriangleMesh(idx, *P, N, uvs);
+            const int alphaTex = AlphaTexture(params, "alpha"), shadowAlphaTex = AlphaTexture(params, "shadowalpha");
+            firstTri = AddTriangleMesh(idx, *P, N, uvs, alphaTex, shadowAlphaTex);
         } else if (name == "plymesh") {  // CreatePLYMesh, plymesh.cpp:149-283
             std::string fn = params.FindOneString("filename", "");
             if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;  // FindOneFilename -> AbsolutePath(ResolveFilename())
@@ -361,11 +379,9 @@ struct Api {
                 if (!okPly) { Err(e); cached.reset(); plyCache.erase(fn); return; }
             }
             const PLYMeshData &ply = *cached;
-            if (params.FindTexture("alpha") != "" || params.FindTexture("shadowalpha") != "" ||
-                params.FindOneFloat("alpha", 1.f) == 0.f || params.FindOneFloat("shadowalpha", 1.f) == 0.f)
-                Err("alpha-mask textures are outside the hot-path scope (SURVEY 8f item 1); ignored");
             nTris = (int)ply.indices.size() / 3;
-            firstTri = AddTriangleMesh(ply.indices, ply.P, ply.N.empty() ? nullptr : &ply.N, ply.UV.empty() ? nullptr : &ply.UV);
+            const int alphaTex = AlphaTexture(params, "alpha"), shadowAlphaTex = AlphaTexture(params, "shadowalpha");
+            firstTri = AddTriangleMesh(ply.indices, ply.P, ply.N.empty() ? nullptr : &ply.N, ply.UV.empty() ? nullptr : &ply.UV, alphaTex, shadowAlphaTex);
         } else if (name == "loopsubdiv") {  // CreateLoopSubdiv, loopsubdiv.cpp:402-424
             int nLevels = params.FindOneInt("levels", params.FindOneInt("nlevels", 3));
             const std::vector<int> *vi = ParamSet::Find(params.ints, "indices");
@@ -546,7 +562,6 @@ struct Api {
         const bool isFloat = type == "float", isSpec = type == "color" || type == "spectrum";
         if (!isFloat && !isSpec) { Err("Texture type \"" + type + "\" unknown."); return; }
         if (texname == "imagemap") {  // CreateImageSpectrumTexture, imagemap.cpp:152-197
-            if (isFloat) { Err("Texture \"" + name + "\": float image textures are outside the hot-path scope (spectrum \"imagemap\" only)"); return; }
             const std::string mapping = ps.FindOneString("mapping", "uv");
             if (mapping != "uv") { Err("Texture \"" + name + "\": 2D texture mapping \"" + mapping + "\" is outside the hot-path scope (\"uv\" only)"); return; }
             mi_texture t{};
@@ -565,9 +580,14 @@ struct Api {
             if (!filename.empty() && filename[0] != '/') filename = baseDir + "/" + filename;   // FindOneFilename
             // (MIPMap::Lookup: noFiltering takes the trilinear entry point, mipmap.h:283-288)
             t.filter = noFilt ? MI_TEX_NONE : (trilerp ? MI_TEX_TRILINEAR : MI_TEX_EWA);
-            t.mipmap = BuildTextureMipMap(scene, filename, trilerp, noFilt, t.max_aniso, wrapMode, scale, gamma);
-            gs.textures.spectrumTex.erase(name);
-            gs.textures.imageTex[name] = (int)scene->textures.size();
+            t.mipmap = BuildTextureMipMap(scene, filename, trilerp, noFilt, t.max_aniso, wrapMode, scale, gamma, isFloat);
+            if (isFloat) {   // (on this path a float image texture can be an "alpha" / "shadowalpha" mask of a mesh)
+                gs.textures.floatTex.erase(name);
+                gs.textures.floatImageTex[name] = (int)scene->textures.size();
+            } else {
+                gs.textures.spectrumTex.erase(name);
+                gs.textures.imageTex[name] = (int)scene->textures.size();
+            }
             scene->textures.push_back(t);
             std::vector<std::string> unused;
             ps.ReportUnused(&unused);

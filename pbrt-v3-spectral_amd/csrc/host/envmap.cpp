@@ -81,10 +81,23 @@ bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store
     return true;
 }
 
+int ConstantFloatMipMap(HostScene *scene, float value) {
+    char keyBuf[64];
+    snprintf(keyBuf, sizeof keyBuf, "<constant>|%a", value);
+    for (size_t i = 0; i < scene->mipStore.size(); ++i) if (scene->mipStore[i].key == keyBuf) return (int)i;
+    HostMipMap h;
+    h.key = keyBuf;
+    h.width = h.height = 1; h.wrap = 0;
+    h.levelOffset.push_back(0);
+    h.texels.assign(3, value);
+    scene->mipStore.push_back(std::move(h));
+    return (int)scene->mipStore.size() - 1;
+}
+
 int BuildTextureMipMap(HostScene *scene, const std::string &filename, bool trilinear, bool noFiltering, float maxAniso,
-                       int wrap, float scale, bool gamma) {
+                       int wrap, float scale, bool gamma, bool isFloat) {
     char keyBuf[128];
-    snprintf(keyBuf, sizeof keyBuf, "|%d|%d|%a|%d|%a|%d", (int)trilinear, (int)noFiltering, maxAniso, wrap, scale, (int)gamma);
+    snprintf(keyBuf, sizeof keyBuf, "|%d|%d|%a|%d|%a|%d|%d", (int)trilinear, (int)noFiltering, maxAniso, wrap, scale, (int)gamma, (int)isFloat);
     const std::string key = filename + keyBuf;
     for (size_t i = 0; i < scene->mipStore.size(); ++i) if (scene->mipStore[i].key == key) return (int)i;
     int rx = 0, ry = 0;
@@ -103,7 +116,10 @@ int BuildTextureMipMap(HostScene *scene, const std::string &filename, bool trili
         if (value <= 0.04045f) return value * 1.f / 12.92f;
         return std::pow((value + 0.055f) * 1.f / 1.055f, (float)2.4f);
     };
-    for (RGB &t : texels) for (int k = 0; k < 3; ++k) t.c[k] = scale * (gamma ? inverseGamma(t.c[k]) : t.c[k]);  // convertIn
+    if (isFloat)   // convertIn to Float: scale * (gamma ? InverseGammaCorrect(y) : y), imagemap.h:107-110; kept grey
+        for (RGB &t : texels) { const float y = t.y(); t = RGB(scale * (gamma ? inverseGamma(y) : y)); }
+    else
+        for (RGB &t : texels) for (int k = 0; k < 3; ++k) t.c[k] = scale * (gamma ? inverseGamma(t.c[k]) : t.c[k]);  // convertIn
     MIPMap mip(rx, ry, texels, (ImageWrap)wrap);
     HostMipMap h;
     h.key = key;

@@ -74,6 +74,7 @@ struct TextureMaps {
     std::map<std::string, float> floatTex;
     std::map<std::string, Spectrum> spectrumTex;
     std::map<std::string, int> imageTex;   // Texture "name" "spectrum" "imagemap": index into HostScene::textures
+    std::map<std::string, int> floatImageTex;   // Texture "name" "float" "imagemap" (alpha masks)
 };
 // A spectrum material parameter: a constant, or an image texture evaluated per hit.
 struct SpectrumParam {
@@ -141,6 +142,11 @@ struct TextureParams {
         }
         auto it = tex.floatTex.find(name);
         if (it != tex.floatTex.end()) { *out = it->second; return true; }
+        if (tex.floatImageTex.count(name)) {
+            if (errors) errors->push_back("Float image texture \"" + name + "\" on parameter \"" + n + "\": this path evaluates float image "
+                                          "textures as \"alpha\" / \"shadowalpha\" masks of triangle meshes only");
+            return false;
+        }
         if (errors) errors->push_back("Couldn't find float texture named \"" + name + "\" for parameter \"" + n + "\"");
         return false;
     }

@@ -99,7 +99,8 @@ bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std:
 // ImageTexture<RGBSpectrum, Spectrum>::GetTexture (imagemap.cpp:58-106): read, flip, convertIn, build the pyramid.
 // Returns the index into scene->mipStore (cached by TexInfo).
 int BuildTextureMipMap(HostScene *scene, const std::string &filename, bool trilinear, bool noFiltering, float maxAniso,
-                       int wrap, float scale, bool gamma);
+                       int wrap, float scale, bool gamma, bool isFloat = false);
+int ConstantFloatMipMap(HostScene *scene, float value);   // ConstantTexture<Float> as a 1x1 pyramid
 bool BuildEnvMap(const Spectrum &L, const std::string &texmap, HostEnvMap *store, Spectrum *centre, std::vector<std::string> *errors);
 bool WriteRGBImage(const std::string &filename, int w, int h, const float *filmSum, const float *weightSum, float scale,
                    std::string *written, std::string *err);

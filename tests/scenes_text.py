@@ -334,3 +334,67 @@ def textured_zoo(res=64, spp=16, depth=5, lens=False):
     lens samples)."""
     return TEXTURED_ZOO % dict(res=res, spp=spp, depth=depth,
                                lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
+ALPHA_SCENE = """
+LookAt 0 2.5 -7  0 0.8 0  0 1 0
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [20 19 17]
+  Translate 0 5.5 -1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]
+AttributeEnd
+LightSource "point" "rgb I" [12 12 14] "point from" [-3 4 -5]
+Texture "leaf" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [3] "float vscale" [2]
+Texture "holes" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "bool noFiltering" ["true"]
+Texture "zero" "float" "constant" "float value" [0]
+Material "matte" "rgb Kd" [.6 .6 .6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5 0 4  5 0 4  5 5 4  -5 5 4]
+# a cut-out panel: visible and shadow-casting only where the mask is not 0
+AttributeBegin
+  Material "plastic" "rgb Kd" [.7 .2 .1] "rgb Ks" [.2 .2 .2]
+  Translate -1.6 1.4 0
+  Rotate 20 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.2 -1 0  1.2 -1 0  1.2 1 0  -1.2 1 0] "float uv" [0 0 1 0 1 1 0 1]
+        "texture alpha" "leaf"
+AttributeEnd
+# a panel that is fully visible but lets shadow rays through its holes ("shadowalpha")
+AttributeBegin
+  Material "matte" "rgb Kd" [.1 .3 .7]
+  Translate 1.7 1.4 .5
+  Rotate -25 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.2 -1 0  1.2 -1 0  1.2 1 0  -1.2 1 0] "float uv" [0 0 1 0 1 1 0 1]
+        "texture shadowalpha" "holes"
+AttributeEnd
+# an invisible mesh (alpha = constant 0 by texture, and by value)
+AttributeBegin
+  Material "matte" "rgb Kd" [.9 .9 .1]
+  Translate 0 1 -2
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.8 -.8 0  .8 -.8 0  .8 .8 0  -.8 .8 0] "texture alpha" "zero"
+  Translate 0 0 -1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.8 -.8 0  .8 -.8 0  .8 .8 0  -.8 .8 0] "float alpha" [0]
+AttributeEnd
+WorldEnd
+"""
+
+
+def write_alpha_png(base_dir, w=32, h=32):
+    """A mask with exact zeros (holes), ones and intermediate values."""
+    import os
+    import numpy as np
+    y, x = np.mgrid[0:h, 0:w]
+    m = np.where(((x // 4 + y // 4) % 2) == 0, 255, 0).astype(np.uint8)
+    m[(x - w // 2) ** 2 + (y - h // 2) ** 2 < (w // 5) ** 2] = 128
+    write_png(os.path.join(base_dir, "alpha.png"), np.stack([m, m, m], -1))
+    return m
+
+
+def alpha_scene(res=64, spp=16, depth=4):
+    """Triangle meshes with "alpha" / "shadowalpha" float image textures and constant-zero alpha (triangle.cpp:331-338,
+    531-570, 716-740); the mask file is alpha.png in base_dir (write_alpha_png)."""
+    return ALPHA_SCENE % dict(res=res, spp=spp, depth=depth)

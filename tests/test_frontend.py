@@ -489,7 +489,7 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
     head = 'Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "a.png"\n'
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
     cases = {
-        'Texture "f" "float" "imagemap" "string filename" "a.png"\n' + tri: "float image textures",
+        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "plastic" "texture roughness" "f"\n' + tri: "Float image texture",
         'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
         'Material "disney" "texture color" "t"\n' + tri: "Image texture",
         'Material "matte" "texture Kd" "t"\nShape "sphere"\n': "sphere",
@@ -574,3 +574,30 @@ def test_spectrum_files_and_blackbody_parameters(pt, tmp_path):
     centres = 395 + 10 * np.arange(31) + 5
     want = np.array([np.trapezoid(norm[(cc - 5 - 360):(cc + 5 - 360) + 1], dx=1.0) / 10 for cc in centres]) * 2
     assert np.allclose(bb, want, rtol=2e-4) and abs(bb.max() / 2 - 1) < 0.01 and bb[0] > bb[-1]
+
+
+def test_alpha_mask_bindings(pt, tmp_path):
+    """ "alpha" / "shadowalpha" of a mesh (triangle.cpp:716-740): a float image texture, a constant-0 texture or the value 0 bind
+    a mask; a non-zero constant binds none; a missing texture is the reference's error. Float image texels are
+    scale * y(rgb) (imagemap.h:107-110)."""
+    m = st.write_alpha_png(str(tmp_path), 8, 8)
+    s = pt.Scene(text=st.alpha_scene(res=16, spp=1), base_dir=str(tmp_path))
+    d = s.desc
+    assert s.errors == []
+    masks = [(d.meshes[i].alpha_tex, d.meshes[i].shadow_alpha_tex) for i in range(d.n_meshes)]
+    assert [a >= 0 for a, _ in masks] == [False, False, False, True, False, True, True]
+    assert [b >= 0 for _, b in masks] == [False, False, False, False, True, False, False]
+    t = d.textures[masks[3][0]]
+    assert (t.su, t.sv, t.filter) == (3.0, 2.0, 0)
+    mm = d.mipmaps[t.mipmap]
+    lvl0 = np.array([mm.texels[i] for i in range(8 * 8 * 3)], np.float32).reshape(8, 8, 3)
+    y = np.float32(0.212671) * (m[::-1] / np.float32(255)) + np.float32(0.715160) * (m[::-1] / np.float32(255)) + np.float32(0.072169) * (m[::-1] / np.float32(255))
+    assert np.allclose(lvl0[..., 0], y, rtol=1e-6) and np.array_equal(lvl0[..., 0], lvl0[..., 1]) and (lvl0[..., 0][m[::-1] == 0] == 0).all()
+    zero = d.mipmaps[d.textures[masks[5][0]].mipmap]
+    assert (zero.width, zero.height, zero.n_levels) == (1, 1, 1) and zero.texels[0] == 0.0
+    head = 'Camera "perspective"\nWorldBegin\nTexture "one" "float" "constant" "float value" [.5]\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] '
+    s = pt.Scene(text=head + tri + '"texture alpha" "one" "float shadowalpha" [.3]\nWorldEnd\n')
+    assert s.errors == [] and (s.desc.meshes[0].alpha_tex, s.desc.meshes[0].shadow_alpha_tex) == (-1, -1)
+    s = pt.Scene(text=head + tri + '"texture alpha" "nope"\nWorldEnd\n')
+    assert any("Couldn't find float texture \"nope\" for \"alpha\" parameter" in e for e in s.errors)

@@ -364,3 +364,32 @@ def test_image_textures_against_oracle(pt, ob, tmp_path, lens):
     # the textures show: the ground's chequer pattern makes neighbouring pixels differ far more than noise would
     ground = film[40:60, 8:56].sum(axis=2)
     assert ground.std() > 0.2 * ground.mean()
+
+
+def test_alpha_masks_against_oracle(pt, ob, tmp_path):
+    """ "alpha" / "shadowalpha" textures of triangle meshes (triangle.cpp:331-338, 531-570): hits where the mask is exactly 0
+    do not count -- in the closest-hit traversal ("alpha"), and in the shadow traversal ("alpha" and "shadowalpha")."""
+    st.write_alpha_png(str(tmp_path))
+    s = pt.Scene(text=st.alpha_scene(), base_dir=str(tmp_path))
+    assert s.errors == []
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
+    assert np.array_equal(weight, oweight)
+    assert _rel_l2(film, ofilm) < 2e-4
+    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    # recorded rays through the cut-out panel: same hits on both sides, closest-hit and any-hit
+    rng = np.random.default_rng(3)
+    n = 4000
+    o = np.tile(np.array([0, 2.5, -7], np.float32), (n, 1))
+    tgt = np.stack([rng.uniform(-3.2, 3.2, n), rng.uniform(0.2, 2.6, n), rng.uniform(-0.5, 1.0, n)], -1).astype(np.float32)
+    dirs = tgt - o
+    rays = np.concatenate([o, dirs, np.full((n, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    for any_hit in (False, True):
+        dh = integ.trace(rays, any_hit=any_hit)
+        oh, _ = ob.trace(s, rays, any_hit=any_hit)
+        if any_hit:
+            assert np.array_equal(dh[:, 0].view(np.int32) >= 0, oh[:, 0].view(np.int32) >= 0)
+        else:
+            assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32))
