@@ -151,9 +151,11 @@ typedef struct mi_material {
     int32_t n_bxdfs;
     float eta; /* BSDF::eta, src/core/reflection.h:189 */
     int32_t kind; /* informational: 0 matte 1 plastic 2 glass 3 uber 4 disney 5 mirror 6 metal 7 substrate 8 translucent 9 mix */
-    int32_t textured; /* != 0: some lobe has tex_R / tex_S >= 0 */
+    int32_t textured; /* != 0: some lobe has tex_R / tex_S >= 0, or bump_tex >= 0 */
     mi_bxdf bxdf[MI_MAX_BXDFS];
     mi_lobe_tex tex[MI_MAX_BXDFS];
+    int32_t bump_tex; /* "bumpmap": float image texture displacing the shading geometry (Material::Bump, material.cpp:47-84), -1 = none */
+    int32_t pad[3];
 } mi_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> with UVMapping2D (src/textures/imagemap.h, src/core/texture.cpp:91-99) over a

@@ -18,6 +18,7 @@ struct SurfaceInteraction : Interaction {
     V3 dpdu, dpdv, dndu, dndv;
     struct { V3 n, dpdu, dpdv, dndu, dndv; } shading;
     int prim = -1;  // index into desc.prims
+    bool flip = false;  // shape->reverseOrientation ^ shape->transformSwapsHandedness
 };
 
 inline Ray SpawnRay(const Interaction &it, const V3 &d) {  // interaction.h:64-67
@@ -43,6 +44,7 @@ inline void InitSurfaceInteraction(SurfaceInteraction *si, const V3 &p, const V3
     si->shading.n = si->n;
     si->shading.dpdu = dpdu; si->shading.dpdv = dpdv; si->shading.dndu = dndu; si->shading.dndv = dndv;
     if (flip) { si->n *= -1; si->shading.n *= -1; }
+    si->flip = flip;
 }
 
 // ---------------------------------------------------------------- triangles

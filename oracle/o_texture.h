@@ -212,6 +212,34 @@ inline Float AlphaTextureValue(const mi_scene_desc &d, int tex, Float u, Float v
     return mip.Lookup(st, zero, zero, t.filter, t.max_aniso).c[0];
 }
 
+// Texture<Float>::Evaluate(si) of float image texture `tex` at (u, v) with the hit's differentials
+inline Float EvalFloatImageTexture(const mi_scene_desc &d, int tex, Float u, Float v, const TexDifferentials &td) {
+    const mi_texture &t = d.textures[tex];
+    const Float dstdx[2] = {t.su * td.dudx, t.sv * td.dvdx}, dstdy[2] = {t.su * td.dudy, t.sv * td.dvdy};
+    const Float st[2] = {t.su * u + t.du, t.sv * v + t.dv};
+    MipView mip{d.mipmaps[t.mipmap]};
+    return mip.Lookup(st, dstdx, dstdy, t.filter, t.max_aniso).c[0];
+}
+
+// Material::Bump (material.cpp:47-84) with a uv-mapped displacement texture: only (u, v) of the shifted evaluation
+// points matters to the texture, so their positions and normals are not formed.
+inline void Bump(const mi_scene_desc &d, int tex, SurfaceInteraction *si, const TexDifferentials &td) {
+    Float du = .5f * (std::abs(td.dudx) + std::abs(td.dudy));
+    if (du == 0) du = .0005f;
+    Float uDisplace = EvalFloatImageTexture(d, tex, si->uv[0] + du, si->uv[1], td);
+    Float dv = .5f * (std::abs(td.dvdx) + std::abs(td.dvdy));
+    if (dv == 0) dv = .0005f;
+    Float vDisplace = EvalFloatImageTexture(d, tex, si->uv[0], si->uv[1] + dv, td);
+    Float displace = EvalFloatImageTexture(d, tex, si->uv[0], si->uv[1], td);
+    V3 dpdu = si->shading.dpdu + (uDisplace - displace) / du * V3(si->shading.n) + displace * V3(si->shading.dndu);
+    V3 dpdv = si->shading.dpdv + (vDisplace - displace) / dv * V3(si->shading.n) + displace * V3(si->shading.dndv);
+    // SetShadingGeometry(dpdu, dpdv, shading.dndu, shading.dndv, false), interaction.cpp:76-93
+    si->shading.n = Normalize(Cross(dpdu, dpdv));
+    if (si->flip) si->shading.n = -si->shading.n;
+    si->shading.n = Faceforward(si->shading.n, si->n);
+    si->shading.dpdu = dpdu; si->shading.dpdv = dpdv;
+}
+
 // Texture<Spectrum>::Evaluate(si).Clamp() for image texture `tex`
 inline Spec EvalImageTexture(const mi_scene_desc &d, int tex, const SurfaceInteraction &si, const TexDifferentials &td) {
     const mi_texture &t = d.textures[tex];

@@ -88,17 +88,53 @@ DEV TexDifferentials ComputeDifferentials(const V3 &p, const V3 &n, const V3 &dp
     return t;
 }
 
-// (u, v) of a triangle hit and the geometric dpdv that goes with TriInteraction's dpdu (triangle.cpp:293-330)
-DEV void TriTexCoords(const DScene &s, int tri, float b0, float b1, float b2, float *u, float *v, V3 *dpdv) {
+// (u, v) of a triangle hit, the geometric dpdv that goes with TriInteraction's dpdu (triangle.cpp:293-330), and the rest of
+// the shading geometry Triangle::Intersect sets (triangle.cpp:347-413): shading.dpdv, shading.dndu / dndv, and whether the
+// shape flips normals -- what Material::Bump reads besides what TriInteraction already returned.
+struct TriShading {
+    V3 dpdv;          // geometric
+    V3 shDpdv, dndu, dndv;
+    bool flip;
+};
+DEV void TriTexCoords(const DScene &s, int tri, float b0, float b1, float b2, const SurfaceInteraction &si, float *u, float *v, TriShading *ts) {
     const int32_t *vi = &s.triIndices[3 * tri];
     V3 p0 = LoadV3(s.P, vi[0]), p1 = LoadV3(s.P, vi[1]), p2 = LoadV3(s.P, vi[2]);
     const mi_mesh m = s.meshes[s.triMesh[tri]];
     float uv[3][2];
     GetUVs(s, tri, m, uv);
     V3 dpdu;
-    TriPartials(p0, p1, p2, uv, &dpdu, dpdv);
+    TriPartials(p0, p1, p2, uv, &dpdu, &ts->dpdv);
     *u = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
     *v = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+    ts->flip = (m.flags & MI_MESH_FLIP) != 0;
+    ts->shDpdv = ts->dpdv;
+    ts->dndu = ts->dndv = V3(0, 0, 0);
+    if (m.flags & MI_MESH_HAS_N) {
+        V3 n0 = LoadV3(s.N, vi[0]), n1 = LoadV3(s.N, vi[1]), n2 = LoadV3(s.N, vi[2]);
+        // ts of the (ss, ts) pair: TriInteraction left ss in si.shDpdu; ss = Cross(ts, ns) there, so recompute ts as it did
+        V3 ng = Normalize(Cross(p0 - p2, p1 - p2));
+        V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
+        if (ns.LengthSquared() > 0) ns = Normalize(ns);
+        else ns = ng;
+        V3 ss = Normalize(dpdu);
+        V3 tsv = Cross(ss, ns);
+        if (tsv.LengthSquared() > 0.f) tsv = Normalize(tsv);
+        else CoordinateSystem(ns, &ss, &tsv);
+        ts->shDpdv = tsv;
+        float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]};
+        float duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+        V3 dn1 = n0 - n2, dn2 = n1 - n2;
+        float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+        bool degenerateUV = absf(determinant) < 1e-8;
+        if (degenerateUV) {
+            V3 dn = Cross(n2 - n0, n1 - n0);
+            if (dn.LengthSquared() != 0) CoordinateSystem(dn, &ts->dndu, &ts->dndv);
+        } else {
+            float invDet = 1 / determinant;
+            ts->dndu = (duv12[1] * dn1 - duv02[1] * dn2) * invDet;
+            ts->dndv = (-duv12[0] * dn1 + duv02[0] * dn2) * invDet;
+        }
+    }
 }
 
 struct RGB3 {
@@ -217,6 +253,30 @@ DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool 
     if (m.alpha_tex >= 0 && AlphaTextureValue(s, m.alpha_tex, u, v) == 0.f) return false;
     if (shadow && m.shadow_alpha_tex >= 0 && AlphaTextureValue(s, m.shadow_alpha_tex, u, v) == 0.f) return false;
     return true;
+}
+
+// Texture<Float>::Evaluate(si) of float image texture `tex`
+DEV float EvalFloatImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
+    const mi_texture &t = s.textures[tex];
+    const mi_mipmap &m = s.mipmaps[t.mipmap];
+    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy, t.filter, t.max_aniso).r;
+}
+// Material::Bump (material.cpp:47-84) with a uv-mapped displacement: updates the interaction's shading normal and
+// shading dpdu (what the BSDF frame is built from).
+DEV void Bump(const DScene &s, int tex, float u, float v, const TexDifferentials &td, const TriShading &tsh, SurfaceInteraction *si) {
+    float du = .5f * (absf(td.dudx) + absf(td.dudy));
+    if (du == 0) du = .0005f;
+    const float uDisplace = EvalFloatImageTexture(s, tex, u + du, v, td);
+    float dv = .5f * (absf(td.dvdx) + absf(td.dvdy));
+    if (dv == 0) dv = .0005f;
+    const float vDisplace = EvalFloatImageTexture(s, tex, u, v + dv, td);
+    const float displace = EvalFloatImageTexture(s, tex, u, v, td);
+    const V3 dpdu = si->shDpdu + (uDisplace - displace) / du * si->shN + displace * tsh.dndu;
+    const V3 dpdv = tsh.shDpdv + (vDisplace - displace) / dv * si->shN + displace * tsh.dndv;
+    V3 n = Normalize(Cross(dpdu, dpdv));   // SetShadingGeometry(..., false), interaction.cpp:76-93
+    if (tsh.flip) n = -n;
+    si->shN = Faceforward(n, si->n);
+    si->shDpdu = dpdu;
 }
 
 // Texture<Spectrum>::Evaluate(si) of image texture `tex` in FromRGB's compact form (see IllumRGB)

@@ -1116,8 +1116,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         }
         if (!finished && !passThrough) {
             const mi_material *mat = &s.materials[s.prims[prim].material];
-            BSDFFrame fr;  // BSDF ctor, reflection.h:170-176
-            fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
+            BSDFFrame fr;
             fr.m = mat;
             fr.mask = 0xffu;
             LobeTexT<NL> lt;
@@ -1131,8 +1130,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (mat->textured && s.prims[prim].shape >= 0) {
                     const float4 hr = pool.R(R_HIT, slot);
                     float u, v;
-                    V3 dpdv;
-                    TriTexCoords(s, s.prims[prim].shape, hr.y, hr.z, hr.w, &u, &v, &dpdv);
+                    TriShading tsh;
+                    TriTexCoords(s, s.prims[prim].shape, hr.y, hr.z, hr.w, isect, &u, &v, &tsh);
                     TexDifferentials td;
                     td.dudx = td.dvdx = td.dudy = td.dvdy = 0;
                     if (flags & F_DIFF) {   // SurfaceInteraction::ComputeDifferentials, interaction.cpp:99-143
@@ -1140,8 +1139,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         float lu = 0.f, lv = 0.f;
                         if (s.camera.lens_radius > 0) { lu = SampleDimension(s, idx, 3); lv = SampleDimension(s, idx, 4); }
                         const CamDifferentials cd = CameraDifferentials(s, pool.F(P_FILMX, slot), pool.F(P_FILMY, slot), lu, lv, ro, rd, s.invSqrtSpp);
-                        td = ComputeDifferentials(isect.p, isect.n, isect.dpdu, dpdv, cd);
+                        td = ComputeDifferentials(isect.p, isect.n, isect.dpdu, tsh.dpdv, cd);
                     }
+                    if (mat->bump_tex >= 0) Bump(s, mat->bump_tex, u, v, td, tsh, &isect);   // `if (bumpMap) Bump(bumpMap, si)`
                     unsigned mask = 0u;
                     for (int i = 0; i < mat->n_bxdfs; ++i) {
                         const mi_lobe_tex ltx = mat->tex[i];
@@ -1170,6 +1170,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     fr.mask = mask;
                 }
             }
+            // BSDF ctor, reflection.h:170-176 (after Bump(): it reads the shading geometry)
+            fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
             const uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
             int dim = pool.I(I_DIM, slot);
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;

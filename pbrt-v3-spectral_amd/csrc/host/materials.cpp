@@ -87,9 +87,14 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     *m = mi_material{};
     m->eta = 1.f;
     for (int i = 0; i < MI_MAX_BXDFS; ++i) m->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
-    float bump;
-    if (mp.GetFloatOrNull("bumpmap", &bump))
-        warnings->push_back("bumpmap ignored: Material::Bump is outside the hot-path scope (SURVEY 8f)");
+    m->bump_tex = mp.GetFloatImageTexture("bumpmap");   // `if (bumpMap) Bump(bumpMap, si)`, first line of every ComputeScatteringFunctions
+    if (m->bump_tex >= 0) {
+        if (type == "mix" || type == "disney" || type == "metal") { errs->push_back("\"bumpmap\" on a \"" + type + "\" material is outside the hot-path scope"); return false; }
+    } else {
+        float bump;
+        if (mp.GetFloatOrNull("bumpmap", &bump))
+            warnings->push_back("constant \"bumpmap\" ignored (it displaces along the normal by a constant; only image bump maps are evaluated on this path)");
+    }
 
     if (type == "matte") {  // src/materials/matte.cpp:45-62,64-71
         m->kind = 0;
@@ -354,6 +359,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
                         std::vector<std::string> *errs) {
     *out = mi_material{};
     for (int i = 0; i < MI_MAX_BXDFS; ++i) out->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
+    out->bump_tex = -1;
     out->kind = 9;
     out->eta = m1.eta;
     const Spectrum s1 = amount.Clamp();
@@ -363,7 +369,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < src[k]->n_bxdfs; ++i) {
             mi_bxdf b = src[k]->bxdf[i];
-            if (src[k]->textured) { errs->push_back("a \"mix\" of image-textured materials is outside the hot-path scope"); return false; }
+            if (src[k]->textured || src[k]->bump_tex >= 0) { errs->push_back("a \"mix\" of image-textured materials is outside the hot-path scope"); return false; }
             if (b.scaled) { errs->push_back("a \"mix\" of \"mix\" materials (nested ScaledBxDF) is not built on this path"); return false; }
             b.scaled = 1;
             for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j];

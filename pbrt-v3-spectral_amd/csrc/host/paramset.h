@@ -150,6 +150,14 @@ struct TextureParams {
         if (errors) errors->push_back("Couldn't find float texture named \"" + name + "\" for parameter \"" + n + "\"");
         return false;
     }
+    // index of the float image texture bound to parameter n, or -1
+    int GetFloatImageTexture(const std::string &n) const {
+        std::string name = geom.FindTexture(n);
+        if (name == "" && !ParamSet::Find(geom.floats, n)) name = mat.FindTexture(n);
+        if (name == "") return -1;
+        auto it = tex.floatImageTex.find(name);
+        return it == tex.floatImageTex.end() ? -1 : it->second;
+    }
     float GetFloat(const std::string &n, float def) const {
         float f;
         return GetFloatOrNull(n, &f) ? f : def;

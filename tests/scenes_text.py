@@ -398,3 +398,67 @@ def alpha_scene(res=64, spp=16, depth=4):
     """Triangle meshes with "alpha" / "shadowalpha" float image textures and constant-zero alpha (triangle.cpp:331-338,
     531-570, 716-740); the mask file is alpha.png in base_dir (write_alpha_png)."""
     return ALPHA_SCENE % dict(res=res, spp=spp, depth=depth)
+
+
+def _curved_patch(nx=6, ny=4):
+    """A gently curved grid mesh with per-vertex normals and uv (so that dndu / dndv are not zero)."""
+    import math
+    P, N, UV, idx = [], [], [], []
+    for j in range(ny + 1):
+        for i in range(nx + 1):
+            u, v = i / nx, j / ny
+            ang = (u - 0.5) * 1.2
+            P += [2.0 * math.sin(ang), (v - 0.5) * 1.6, -2.0 * math.cos(ang) + 2.0]
+            N += [-math.sin(ang), 0.0, -math.cos(ang)]
+            UV += [u, v]
+    for j in range(ny):
+        for i in range(nx):
+            a = j * (nx + 1) + i
+            idx += [a, a + 1, a + nx + 2, a, a + nx + 2, a + nx + 1]
+    f = lambda xs: " ".join("%.9g" % x for x in xs)
+    return ('Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]'
+            % (" ".join(map(str, idx)), f(P), f(N), f(UV)))
+
+
+BUMP_SCENE = """
+LookAt 0 1.6 -6  0 0.9 0  0 1 0
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [14 14 13]
+  Translate 2 4.5 -2
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]
+AttributeEnd
+LightSource "point" "rgb I" [14 13 12] "point from" [-3 2.5 -4]
+Texture "bumps" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [3] "float vscale" [3] "float scale" [.04]
+Texture "bumps_tri" "float" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"] "float scale" [.08]
+Texture "colour" "spectrum" "imagemap" "string filename" "tex_c.pfm"
+# ground: flat quad without normals, bump-mapped matte
+AttributeBegin
+  Material "matte" "rgb Kd" [.5 .5 .5] "texture bumpmap" "bumps"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5 0 -5  5 0 -5  5 0 5  -5 0 5] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# curved patch with normals: bump-mapped plastic (dndu, dndv enter)
+AttributeBegin
+  Material "plastic" "rgb Kd" [.2 .4 .7] "rgb Ks" [.4 .4 .4] "float roughness" [.1] "texture bumpmap" "bumps_tri"
+  Translate -1.3 1 0
+  %(patch)s
+AttributeEnd
+# curved patch, mirrored (flipped handedness), bump + textured Kd on uber
+AttributeBegin
+  Material "uber" "texture Kd" "colour" "rgb Ks" [.3 .3 .3] "rgb Kr" [.15 .15 .15] "texture bumpmap" "bumps"
+  Translate 1.5 1 .3
+  Scale -1 1 1
+  %(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def bump_scene(res=64, spp=16, depth=4):
+    """Material::Bump (material.cpp:47-84) with float image textures: a flat quad without normals, a curved patch with
+    vertex normals, a mirrored patch with a textured Kd as well. Uses the files of write_texture_files()."""
+    return BUMP_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch())

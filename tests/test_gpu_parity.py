@@ -393,3 +393,23 @@ def test_alpha_masks_against_oracle(pt, ob, tmp_path):
             assert np.array_equal(dh[:, 0].view(np.int32) >= 0, oh[:, 0].view(np.int32) >= 0)
         else:
             assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32))
+
+
+def test_bump_mapping_against_oracle(pt, ob, tmp_path):
+    """ "texture bumpmap" (Material::Bump, material.cpp:47-84): three displaced lookups per vertex, the bumped shading
+    frame from shading.dpdu / dpdv / dndu / dndv (triangle.cpp:347-413), on meshes with and without normals, mirrored, and
+    together with a textured Kd."""
+    st.write_texture_files(str(tmp_path))
+    s = pt.Scene(text=st.bump_scene(), base_dir=str(tmp_path))
+    assert s.errors == []
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    ofilm, oweight, oc, _ = ob.render(s)
+    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
+    assert np.array_equal(weight, oweight)
+    assert _rel_l2(film, ofilm) < 2e-4
+    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    # and the bump map does something: without it the render differs visibly
+    flat = pt.Scene(text=st.bump_scene().replace('"texture bumpmap" "bumps_tri"', "").replace('"texture bumpmap" "bumps"', ""), base_dir=str(tmp_path))
+    ff, _, _, _ = ob.render(flat)
+    assert _rel_l2(ff, ofilm) > 0.02
