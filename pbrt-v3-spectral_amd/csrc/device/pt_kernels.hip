@@ -1489,6 +1489,7 @@ struct mi_pt {
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
+    unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
     unsigned texturedSmall = 0, texturedLarge = 0;               // classes of image-textured materials (taken out of small / largeClasses)              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
 };
@@ -1656,6 +1657,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses);
         for (int c = 0; c < MISS_CLASS; ++c)
             if (classTypes[c] & TM_TEXTURED) {
+                if (((pt->smallClasses >> c) & 1u) && !getenv("MIPT_NO_SPECIALISE")) {
+                    if ((classTypes[c] & ~(TM_DIFFUSE | TM_TEXTURED)) == 0) { pt->texturedDiffuse |= 1u << c; pt->smallClasses &= ~(1u << c); }
+                    else if ((classTypes[c] & ~(TM_PLASTIC | TM_TEXTURED)) == 0) { pt->texturedPlastic |= 1u << c; pt->smallClasses &= ~(1u << c); }
+                }
                 if ((pt->smallClasses >> c) & 1u) { pt->texturedSmall |= 1u << c; pt->smallClasses &= ~(1u << c); }
                 if ((pt->largeClasses >> c) & 1u) { pt->texturedLarge |= 1u << c; pt->largeClasses &= ~(1u << c); }
             }
@@ -1962,6 +1967,8 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         }
         if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
         if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+        if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
+        if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
         if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
         if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
         HIPCHK(hipEventRecord(ev[3], st));
