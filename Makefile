@@ -5,7 +5,7 @@ HOSTSRC  := $(wildcard $(PKG)/csrc/host/*.cpp)
 HOSTSRC  := $(filter-out $(PKG)/csrc/host/main.cpp,$(HOSTSRC))
 CXX      ?= g++
 HIPCC    ?= /opt/rocm/bin/hipcc
-CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude
+CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -ffp-contract=off -Wall -Wno-unused-function -Iinclude
 HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Iinclude -Wno-unused-result -Wno-unused-value
 
 all: host hip cli oracle

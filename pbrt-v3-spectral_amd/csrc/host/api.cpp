@@ -14,6 +14,7 @@
 // instancing, animated transforms, participating media, non-constant textures,
 // shapes other than trianglemesh / loopsubdiv / sphere.
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -834,7 +835,11 @@ void Api::WorldEnd() {
         std::vector<Bounds3> bounds(pending.size());
         for (size_t i = 0; i < pending.size(); ++i) bounds[i] = pending[i].bounds;
         std::vector<int> order;
+        const auto tb0 = std::chrono::steady_clock::now();
         BuildBVH(bounds, maxPrims, method, &scene->nodes, &order, &scene->stats.interiorNodes, &scene->stats.leafNodes);
+        if (getenv("MIPT_TIMING"))
+            fprintf(stderr, "[mipt] BVH build over %zu primitives: %.3f s\n", bounds.size(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
         scene->prims.resize(order.size());
         for (size_t i = 0; i < order.size(); ++i) {
             const PendingPrim &pp = pending[order[i]];

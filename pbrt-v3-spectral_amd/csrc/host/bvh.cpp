@@ -5,8 +5,17 @@
 // 640-658) so the tree (node count, leaf contents, primitive order) is the
 // reference's tree: killeroo-simple -> 59 188 interior + 59 189 leaf nodes.
 // HLBVH (bvh.cpp:404-638) is a "next" row.
+// The recursion is the reference's, but large builds run it on several threads: the top of the tree is built
+// serially down to ranges of a grain size, those ranges become independent tasks (a range [start, end) of the
+// primitive-info array is private to its subtree, and it always yields end - start ordered primitives, so every
+// leaf's offset into the ordered list is known without waiting for the subtrees to its left), and the flatten
+// pass walks the stitched tree depth first. Same partitions, same node order, same bytes as the serial build.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <memory>
+#include <thread>
 #include "scene.h"
 
 namespace mipt {
@@ -24,24 +33,40 @@ struct BuildNode {
     int splitAxis = 0, firstPrimOffset = 0, nPrimitives = 0;
 };
 
+struct DeferredSubtree { BuildNode **slot; int start, end, orderedBase; };
+
 struct Builder {
     int maxPrimsInNode;
     SplitMethod method;
-    std::vector<std::unique_ptr<BuildNode>> pool;
-    std::vector<int> *ordered;
+    std::vector<std::unique_ptr<BuildNode[]>> chunks;   // nodes in blocks: no per-node allocation
+    size_t chunkUsed = 0;
+    int *ordered;            // [nPrims], written at explicit offsets
+    int orderedNext = 0;     // offset of the next leaf in depth-first order
     int interior = 0, leaves = 0, total = 0;
+    int grain = 0;           // > 0: ranges of at most this many primitives are deferred to tasks
+    std::vector<DeferredSubtree> *deferred = nullptr;
 
     BuildNode *Alloc() {
-        pool.emplace_back(new BuildNode());
-        return pool.back().get();
+        constexpr size_t kChunk = 4096;
+        if (chunks.empty() || chunkUsed == kChunk) { chunks.emplace_back(new BuildNode[kChunk]); chunkUsed = 0; }
+        return &chunks.back()[chunkUsed++];
     }
     void InitLeaf(BuildNode *node, std::vector<PrimInfo> &info, int start, int end, const Bounds3 &b) {
-        int first = (int)ordered->size();
-        for (int i = start; i < end; ++i) ordered->push_back((int)info[i].primitiveNumber);
+        int first = orderedNext;
+        for (int i = start; i < end; ++i) ordered[orderedNext++] = (int)info[i].primitiveNumber;
         node->firstPrimOffset = first;
         node->nPrimitives = end - start;
         node->bounds = b;
         ++leaves;
+    }
+    // a child subtree: built here, or left to a task (its ordered primitives keep their place)
+    void Child(BuildNode **slot, std::vector<PrimInfo> &info, int start, int end) {
+        if (deferred && end - start <= grain && end - start > 1) {
+            deferred->push_back(DeferredSubtree{slot, start, end, orderedNext});
+            orderedNext += end - start;
+            *slot = nullptr;
+        } else
+            *slot = Build(info, start, end);
     }
     BuildNode *Build(std::vector<PrimInfo> &info, int start, int end) {
         BuildNode *node = Alloc();
@@ -115,11 +140,11 @@ struct Builder {
                 }
             }
         }
-        BuildNode *c0 = Build(info, start, mid);
-        BuildNode *c1 = Build(info, mid, end);
-        node->children[0] = c0;
-        node->children[1] = c1;
-        node->bounds = Union(c0->bounds, c1->bounds);
+        Child(&node->children[0], info, start, mid);
+        Child(&node->children[1], info, mid, end);
+        // (= Union(c0->bounds, c1->bounds), InitInterior bvh.cpp:68-69: the union of the children's primitive bounds,
+        // which is the `bounds` computed above; taken from there because a deferred child is not built yet)
+        node->bounds = bounds;
         node->splitAxis = dim;
         node->nPrimitives = 0;
         ++interior;
@@ -161,17 +186,54 @@ void BuildBVH(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, SplitM
         info[i].bounds = primBounds[i];
         info[i].centroid = .5f * primBounds[i].pMin + .5f * primBounds[i].pMax;  // bvh.cpp:56
     }
-    Builder b;
-    b.maxPrimsInNode = std::min(255, maxPrimsInNode);
-    b.method = method;
-    b.ordered = orderedPrims;
-    orderedPrims->reserve(primBounds.size());
-    BuildNode *root = b.Build(info, 0, (int)primBounds.size());
-    nodes->resize(b.total);
+    const int n = (int)primBounds.size();
+    orderedPrims->assign(n, 0);
+    unsigned nThreads = std::max(1u, std::thread::hardware_concurrency());
+    if (const char *e = getenv("MIPT_BUILD_THREADS")) nThreads = (unsigned)std::max(1, atoi(e));
+    nThreads = std::min(nThreads, 64u);
+    if (n < 65536) nThreads = 1;
+    Builder top;
+    top.maxPrimsInNode = std::min(255, maxPrimsInNode);
+    top.method = method;
+    top.ordered = orderedPrims->data();
+    std::vector<DeferredSubtree> deferred;
+    if (nThreads > 1) { top.grain = std::max(4096, n / (int)(nThreads * 8)); top.deferred = &deferred; }
+    BuildNode *root = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    top.Child(&root, info, 0, n);
+    const auto t1 = std::chrono::steady_clock::now();
+    int total = top.total, nInterior = top.interior, nLeaves = top.leaves;
+    std::vector<std::unique_ptr<Builder>> workers(nThreads);   // one per thread (its nodes must outlive the flatten pass)
+    if (!deferred.empty()) {
+        std::atomic<size_t> next{0};
+        auto run = [&](unsigned t) {
+            workers[t].reset(new Builder());
+            Builder &w = *workers[t];
+            w.maxPrimsInNode = top.maxPrimsInNode;
+            w.method = method;
+            w.ordered = orderedPrims->data();
+            for (size_t i; (i = next.fetch_add(1)) < deferred.size();) {
+                w.orderedNext = deferred[i].orderedBase;
+                *deferred[i].slot = w.Build(info, deferred[i].start, deferred[i].end);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(run, t);
+        run(0);
+        for (std::thread &t : pool) t.join();
+        for (const auto &w : workers) if (w) { total += w->total; nInterior += w->interior; nLeaves += w->leaves; }
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    nodes->resize(total);
     int offset = 0;
     Flatten(root, *nodes, &offset);
-    *interior = b.interior;
-    *leaves = b.leaves;
+    if (getenv("MIPT_TIMING")) {
+        auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+        fprintf(stderr, "[mipt] BVH: top %.3f s, %zu subtrees on %u threads %.3f s, flatten %.3f s\n", sec(t0, t1), deferred.size(), nThreads,
+                sec(t1, t2), sec(t2, std::chrono::steady_clock::now()));
+    }
+    *interior = nInterior;
+    *leaves = nLeaves;
 }
 
 }  // namespace mipt

@@ -601,3 +601,27 @@ def test_alpha_mask_bindings(pt, tmp_path):
     assert s.errors == [] and (s.desc.meshes[0].alpha_tex, s.desc.meshes[0].shadow_alpha_tex) == (-1, -1)
     s = pt.Scene(text=head + tri + '"texture alpha" "nope"\nWorldEnd\n')
     assert any("Couldn't find float texture \"nope\" for \"alpha\" parameter" in e for e in s.errors)
+
+
+def test_parallel_bvh_build_is_the_serial_tree(pt, tmp_path, monkeypatch):
+    """Large scenes build their SAH BVH on several threads (bvh.cpp: independent subtrees, precomputed leaf offsets); the
+    node array and the primitive order must be byte-identical to the one-thread build."""
+    import hashlib
+    sys_path = os.path.join(ROOT, "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mps", os.path.join(sys_path, "make_procedural_scene.py"))
+    mps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mps)
+    path = tmp_path / "p.pbrt"
+    with open(path, "w") as fh:
+        mps.write_scene(fh, 100000, 64, 1, 7, 5)
+
+    def digest(threads):
+        monkeypatch.setenv("MIPT_BUILD_THREADS", str(threads))
+        s = pt.Scene(str(path))
+        d = s.desc
+        nodes = bytes(C.cast(d.nodes, C.POINTER(C.c_char * (32 * d.n_nodes))).contents)
+        prims = bytes(C.cast(d.prims, C.POINTER(C.c_char * (C.sizeof(pt.Prim) * d.n_prims))).contents)
+        return d.n_nodes, hashlib.md5(nodes).hexdigest(), hashlib.md5(prims).hexdigest(), s.stats["interior_nodes"], s.stats["leaf_nodes"]
+    one = digest(1)
+    assert one[0] > 100000 and one == digest(4) == digest(13)
