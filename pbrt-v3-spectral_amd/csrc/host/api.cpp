@@ -570,6 +570,10 @@ struct Api {
             t.su = ps.FindOneFloat("uscale", 1.f); t.sv = ps.FindOneFloat("vscale", 1.f);
             t.du = ps.FindOneFloat("udelta", 0.f); t.dv = ps.FindOneFloat("vdelta", 0.f);
             t.max_aniso = ps.FindOneFloat("maxanisotropy", 8.f);
+            if (!(t.max_aniso <= 64.f)) {   // an EWA footprint is up to 2 x maxanisotropy texels long: keep the per-lane loop bounded
+                Warn("Texture \"" + name + "\": \"maxanisotropy\" " + std::to_string(t.max_aniso) + " clamped to 64 on this path");
+                t.max_aniso = 64.f;
+            }
             const bool trilerp = ps.FindOneBool("trilinear", false), noFilt = ps.FindOneBool("noFiltering", false);
             const std::string wrap = ps.FindOneString("wrap", "repeat");
             const int wrapMode = wrap == "black" ? 1 : (wrap == "clamp" ? 2 : 0);
