@@ -437,7 +437,8 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 #ifndef MIPT_TRAV_WAVES_PER_EU
 #define MIPT_TRAV_WAVES_PER_EU 4
 #endif
-template <int MODE>
+// ALPHA: the scene has meshes with alpha masks (the mask test is compiled into this instance only)
+template <int MODE, bool ALPHA>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
     const int lane = threadIdx.x;
@@ -563,8 +564,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         // meshes with an alpha mask: IntersectP then rejects degenerate triangles too, and both reject
                         // hits where the mask is 0 (triangle.cpp:331-338, 531-570)
                         bool counts = true;
-                        if (pf & PRIM_FLAG_ALPHA)
-                            counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
+                        if constexpr (ALPHA)
+                            if (pf & PRIM_FLAG_ALPHA)
+                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
                         if (!counts) {}
                         else if (ANY) { hitPrim = prim; finished = true; }
                         else if (!(pf & PRIM_FLAG_DEGENERATE)) {
@@ -1487,6 +1489,7 @@ struct mi_pt {
     std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
+    bool hasAlphaMasks = false;      // picks the traversal kernels compiled with the alpha-mask test
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
@@ -1714,7 +1717,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                     float cx = (float)cr[0], cy = (float)cr[1], cz = (float)cr[2];
                     if (cx * cx + cy * cy + cz * cz == 0) flags |= PRIM_FLAG_DEGENERATE;
                 }
-                if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) flags |= PRIM_FLAG_ALPHA;
+                if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) { flags |= PRIM_FLAG_ALPHA; pt->hasAlphaMasks = true; }
             } else {
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
@@ -1952,7 +1955,8 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipStreamSynchronize(st));
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
-        hipLaunchKernelGGL(k_trav<0>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<0, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<0, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
@@ -1972,10 +1976,12 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
         if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
         HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_trav<1>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<1, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<1, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_trav<2>, travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<2, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<2, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[5], st));
         havePrev = true; prevFull = true;
