@@ -176,6 +176,8 @@ typedef struct mi_texture {   /* spectrum textures: RGB pyramid; float textures:
     int32_t filter;         /* mi_tex_filter */
     float max_aniso;        /* "maxanisotropy" */
     float su, sv, du, dv;   /* UVMapping2D */
+    float post_scale;       /* float textures: the looked-up value is multiplied by this (1 for a plain image texture; the
+                             * constant operand of a Texture "scale" over an image texture, scale.h:56-58) */
 } mi_texture;
 
 /* ---- lights */

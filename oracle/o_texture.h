@@ -209,7 +209,7 @@ inline Float AlphaTextureValue(const mi_scene_desc &d, int tex, Float u, Float v
     const Float zero[2] = {0, 0};
     const Float st[2] = {t.su * u + t.du, t.sv * v + t.dv};
     MipView mip{d.mipmaps[t.mipmap]};
-    return mip.Lookup(st, zero, zero, t.filter, t.max_aniso).c[0];
+    return mip.Lookup(st, zero, zero, t.filter, t.max_aniso).c[0] * t.post_scale;
 }
 
 // Texture<Float>::Evaluate(si) of float image texture `tex` at (u, v) with the hit's differentials
@@ -218,7 +218,7 @@ inline Float EvalFloatImageTexture(const mi_scene_desc &d, int tex, Float u, Flo
     const Float dstdx[2] = {t.su * td.dudx, t.sv * td.dvdx}, dstdy[2] = {t.su * td.dudy, t.sv * td.dvdy};
     const Float st[2] = {t.su * u + t.du, t.sv * v + t.dv};
     MipView mip{d.mipmaps[t.mipmap]};
-    return mip.Lookup(st, dstdx, dstdy, t.filter, t.max_aniso).c[0];
+    return mip.Lookup(st, dstdx, dstdy, t.filter, t.max_aniso).c[0] * t.post_scale;
 }
 
 // Material::Bump (material.cpp:47-84) with a uv-mapped displacement texture: only (u, v) of the shifted evaluation

@@ -68,7 +68,7 @@ class MipMap(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("mipmap", C.c_int32), ("filter", C.c_int32), ("max_aniso", C.c_float),
-                ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float)]
+                ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float), ("post_scale", C.c_float)]
 
 
 class Light(C.Structure):

@@ -242,7 +242,7 @@ DEV RGB3 MipLookup(const DScene &s, const mi_mipmap &m, float st0, float st1, fl
 DEV float AlphaTextureValue(const DScene &s, int tex, float u, float v) {
     const mi_texture &t = s.textures[tex];
     const mi_mipmap &m = s.mipmaps[t.mipmap];
-    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, 0.f, 0.f, 0.f, 0.f, t.filter, t.max_aniso).r;
+    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, 0.f, 0.f, 0.f, 0.f, t.filter, t.max_aniso).r * t.post_scale;
 }
 DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool shadow) {
     const mi_mesh m = s.meshes[s.triMesh[tri]];
@@ -259,7 +259,7 @@ DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool 
 DEV float EvalFloatImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
     const mi_texture &t = s.textures[tex];
     const mi_mipmap &m = s.mipmaps[t.mipmap];
-    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy, t.filter, t.max_aniso).r;
+    return MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy, t.filter, t.max_aniso).r * t.post_scale;
 }
 // Material::Bump (material.cpp:47-84) with a uv-mapped displacement: updates the interaction's shading normal and
 // shading dpdu (what the BSDF frame is built from).

@@ -248,7 +248,7 @@ struct Api {
             return -1;
         mi_texture t{};
         t.mipmap = ConstantFloatMipMap(scene, 0.f);
-        t.filter = MI_TEX_TRILINEAR; t.max_aniso = 8.f; t.su = t.sv = 1.f;
+        t.filter = MI_TEX_TRILINEAR; t.max_aniso = 8.f; t.su = t.sv = 1.f; t.post_scale = 1.f;
         scene->textures.push_back(t);
         return (int)scene->textures.size() - 1;
     }
@@ -569,6 +569,7 @@ struct Api {
             mi_texture t{};
             t.su = ps.FindOneFloat("uscale", 1.f); t.sv = ps.FindOneFloat("vscale", 1.f);
             t.du = ps.FindOneFloat("udelta", 0.f); t.dv = ps.FindOneFloat("vdelta", 0.f);
+            t.post_scale = 1.f;
             t.max_aniso = ps.FindOneFloat("maxanisotropy", 8.f);
             if (!(t.max_aniso <= 64.f)) {   // an EWA footprint is up to 2 x maxanisotropy texels long: keep the per-lane loop bounded
                 Warn("Texture \"" + name + "\": \"maxanisotropy\" " + std::to_string(t.max_aniso) + " clamped to 64 on this path");
@@ -604,6 +605,18 @@ struct Api {
             if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("value", 1.f);
             else gs.textures.spectrumTex[name] = tp.GetSpectrum("value", Spectrum(1.f));
         } else if (texname == "scale") {
+            // ScaleTexture of a float image texture and a constant (the usual way to size a bump map): the image texture
+            // with the constant as post-lookup factor -- tex1(si) * tex2(si), scale.h:56-58
+            const int img1 = isFloat ? tp.GetFloatImageTexture("tex1") : -1, img2 = isFloat ? tp.GetFloatImageTexture("tex2") : -1;
+            if (img1 >= 0 || img2 >= 0) {
+                if (img1 >= 0 && img2 >= 0) { Err("Texture \"" + name + "\": a \"scale\" of two image textures is outside the hot-path scope"); return; }
+                mi_texture t = scene->textures[img1 >= 0 ? img1 : img2];
+                t.post_scale = t.post_scale * tp.GetFloat(img1 >= 0 ? "tex2" : "tex1", 1.f);
+                gs.textures.floatTex.erase(name);
+                gs.textures.floatImageTex[name] = (int)scene->textures.size();
+                scene->textures.push_back(t);
+                return;
+            }
             if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("tex1", 1.f) * tp.GetFloat("tex2", 1.f);
             else gs.textures.spectrumTex[name] = tp.GetSpectrum("tex1", Spectrum(1.f)) * tp.GetSpectrum("tex2", Spectrum(1.f));
         } else {

@@ -434,7 +434,8 @@ AttributeBegin
 AttributeEnd
 LightSource "point" "rgb I" [14 13 12] "point from" [-3 2.5 -4]
 Texture "bumps" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [3] "float vscale" [3] "float scale" [.04]
-Texture "bumps_tri" "float" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"] "float scale" [.08]
+Texture "bumps_raw" "float" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"]
+Texture "bumps_tri" "float" "scale" "texture tex1" "bumps_raw" "float tex2" [.08]
 Texture "colour" "spectrum" "imagemap" "string filename" "tex_c.pfm"
 # ground: flat quad without normals, bump-mapped matte
 AttributeBegin
