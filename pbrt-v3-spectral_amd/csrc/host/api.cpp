@@ -617,6 +617,16 @@ struct Api {
                 scene->textures.push_back(t);
                 return;
             }
+            if (!isFloat) {   // spectrum: image texture * constant spectrum -> the lobe keeps the constant and multiplies the texture value in
+                const SpectrumParam p1 = tp.GetSpectrumParam("tex1", Spectrum(1.f)), p2 = tp.GetSpectrumParam("tex2", Spectrum(1.f));
+                if (p1.tex >= 0 || p2.tex >= 0) {
+                    if (p1.tex >= 0 && p2.tex >= 0) { Err("Texture \"" + name + "\": a \"scale\" of two image textures is outside the hot-path scope"); return; }
+                    const SpectrumParam &img = p1.tex >= 0 ? p1 : p2, &cst = p1.tex >= 0 ? p2 : p1;
+                    gs.textures.spectrumTex.erase(name);
+                    gs.textures.scaledImageTex[name] = std::make_pair(img.tex, img.scaled ? img.s * cst.s : cst.s);
+                    return;
+                }
+            }
             if (isFloat) gs.textures.floatTex[name] = tp.GetFloat("tex1", 1.f) * tp.GetFloat("tex2", 1.f);
             else gs.textures.spectrumTex[name] = tp.GetSpectrum("tex1", Spectrum(1.f)) * tp.GetSpectrum("tex2", Spectrum(1.f));
         } else {

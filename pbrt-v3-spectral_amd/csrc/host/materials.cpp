@@ -43,6 +43,10 @@ void Bind(mi_material *m, int texR, bool mulR, int texS = -1, bool mulS = false,
     t.rule = rule;
     m->textured = 1;
 }
+// (A parameter bound to `Texture "scale"` of an image texture and a constant c arrives as {s = c, tex, scaled}: the lobe
+// keeps c -- clamped at 0, which for a texture value >= 0 is the clamp of the product -- and multiplies the texture
+// value in at the hit. Where the material multiplies further (uber's opacity, translucent's reflect / transmit) the
+// product is formed as (op * c) * T instead of the reference's op * (T * c): the last bit may differ.)
 // Whether a parameter can make its lobe appear: a constant must not be black, a texture may be anything.
 inline bool MayBeNonBlack(const SpectrumParam &p, const Spectrum &clamped) { return p.tex >= 0 || !clamped.IsBlack(); }
 
@@ -104,7 +108,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         if (MayBeNonBlack(Kd, r)) {
             if (sig == 0) Add(m, Lambertian(r), errs);
             else Add(m, OrenNayar(r, sig), errs);
-            Bind(m, Kd.tex, false);
+            Bind(m, Kd.tex, Kd.scaled);
         }
         return true;
     }
@@ -115,12 +119,12 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         Spectrum ks = Ks.s.Clamp();
         float rough = mp.GetFloat("roughness", .1f);
         bool remap = mp.FindBool("remaproughness", true);
-        if (MayBeNonBlack(Kd, kd)) { Add(m, Lambertian(kd), errs); Bind(m, Kd.tex, false); }
+        if (MayBeNonBlack(Kd, kd)) { Add(m, Lambertian(kd), errs); Bind(m, Kd.tex, Kd.scaled); }
         if (MayBeNonBlack(Ks, ks)) {
             if (remap) rough = RoughnessToAlpha(rough);
             // FresnelDielectric(1.5f, 1.f): plastic.cpp:59
             Add(m, MicrofacetReflectionDielectric(ks, rough, rough, 1.5f, 1.f), errs);
-            Bind(m, Ks.tex, false);
+            Bind(m, Ks.tex, Ks.scaled);
         }
         return true;
     }
@@ -132,7 +136,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             mi_bxdf b = MakeBxDF(MI_BXDF_SPECULAR_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_SPECULAR, R);
             b.fresnel = MI_FRESNEL_NOOP;
             Add(m, b, errs);
-            Bind(m, Kr.tex, false);
+            Bind(m, Kr.tex, Kr.scaled);
         }
         return true;
     }
@@ -168,7 +172,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             SetS(b, s);
             b.p[0] = roughu; b.p[1] = roughv;
             Add(m, b, errs);
-            Bind(m, Kd.tex, false, Ks.tex, false, MI_LOBE_IF_R_OR_S);
+            Bind(m, Kd.tex, Kd.scaled, Ks.tex, Ks.scaled, MI_LOBE_IF_R_OR_S);
         }
         return true;
     }
@@ -218,7 +222,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             SetS(b, T);
             b.p[0] = 1.f; b.p[1] = eta;
             Add(m, b, errs);
-            Bind(m, Kr.tex, false, Kt.tex, false, MI_LOBE_IF_R_OR_S);
+            Bind(m, Kr.tex, Kr.scaled, Kt.tex, Kt.scaled, MI_LOBE_IF_R_OR_S);
         } else {
             if ((Kr.tex >= 0) != (Kt.tex >= 0) || (Kr.tex >= 0 && Kt.tex >= 0)) {
                 // rough glass adds its lobes only `if (R.IsBlack() && T.IsBlack()) return` has not fired (glass.cpp:70-72):

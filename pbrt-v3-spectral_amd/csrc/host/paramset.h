@@ -74,12 +74,14 @@ struct TextureMaps {
     std::map<std::string, float> floatTex;
     std::map<std::string, Spectrum> spectrumTex;
     std::map<std::string, int> imageTex;   // Texture "name" "spectrum" "imagemap": index into HostScene::textures
-    std::map<std::string, int> floatImageTex;   // Texture "name" "float" "imagemap" (alpha masks)
+    std::map<std::string, int> floatImageTex;   // Texture "name" "float" "imagemap" (alpha masks, bump maps)
+    std::map<std::string, std::pair<int, Spectrum>> scaledImageTex;   // spectrum "scale" of an image texture and a constant
 };
 // A spectrum material parameter: a constant, or an image texture evaluated per hit.
 struct SpectrumParam {
-    Spectrum s;
+    Spectrum s;          // the constant; with `scaled`: the constant factor of a "scale" texture over image texture `tex`
     int tex = -1;
+    bool scaled = false;
     SpectrumParam() {}
     SpectrumParam(const Spectrum &v) : s(v) {}
 };
@@ -106,7 +108,7 @@ struct TextureParams {
         }
         auto it = tex.spectrumTex.find(name);
         if (it != tex.spectrumTex.end()) { *out = it->second; return true; }
-        if (tex.imageTex.count(name)) {
+        if (tex.imageTex.count(name) || tex.scaledImageTex.count(name)) {
             if (errors) errors->push_back("Image texture \"" + name + "\" on parameter \"" + n + "\": this path evaluates image textures "
                                           "for Kd / Ks / Kr / Kt of matte, plastic, mirror, glass, uber, substrate and translucent only");
             return false;
@@ -121,6 +123,8 @@ struct TextureParams {
         if (name != "") {
             auto it = tex.imageTex.find(name);
             if (it != tex.imageTex.end()) { SpectrumParam p; p.s = Spectrum(1.f); p.tex = it->second; return p; }
+            auto sc = tex.scaledImageTex.find(name);
+            if (sc != tex.scaledImageTex.end()) { SpectrumParam p; p.s = sc->second.second; p.tex = sc->second.first; p.scaled = true; return p; }
         }
         return SpectrumParam(GetSpectrum(n, def));
     }

@@ -282,6 +282,7 @@ Texture "tri_tga" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool tril
 Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string wrap" "clamp" "float uscale" [2] "float vscale" [2] "float scale" [.8]
 Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2] "float maxanisotropy" [4]
 Texture "tga_nofilt" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool noFiltering" ["true"] "bool gamma" ["false"]
+Texture "tinted" "spectrum" "scale" "texture tex1" "tri_tga" "rgb tex2" [.9 .6 .4]
 # ground: matte, EWA-filtered at a grazing angle
 AttributeBegin
   Material "matte" "texture Kd" "ewa_png"
@@ -289,7 +290,7 @@ AttributeBegin
 AttributeEnd
 # back wall: plastic with a textured Kd and a constant Ks
 AttributeBegin
-  Material "plastic" "texture Kd" "tri_tga" "rgb Ks" [.3 .3 .3] "float roughness" [.15]
+  Material "plastic" "texture Kd" "tinted" "rgb Ks" [.3 .3 .3] "float roughness" [.15]
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
 AttributeEnd
 # uber with textured Kd and Ks (three lobes) on a tilted panel without uv (default parametrisation)
