@@ -361,6 +361,11 @@ const char *mi_pt_last_error(void);
  * semantics (prim = 0/-1 only). Host pointers. */
 int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hits);
 
+/* Parity tool for image textures: MIPMap<RGBSpectrum>::Lookup(st, dstdx, dstdy) (src/core/mipmap.h:281-319) of texture
+ * `tex` for n queries on the device. queries: 6 floats each (s, t, dsdx, dtdx, dsdy, dtdy) in texture space, i.e. after
+ * the UVMapping2D; rgb: 3 floats per query. */
+int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *queries, float *rgb);
+
 #ifdef __cplusplus
 }
 #endif

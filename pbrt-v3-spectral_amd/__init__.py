@@ -209,6 +209,7 @@ def hip_lib():
         lib.mi_pt_destroy.argtypes = [C.c_void_p]
         lib.mi_pt_last_error.restype = C.c_char_p
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+        lib.mi_pt_texture_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _hip = lib
     return _hip
 
@@ -349,6 +350,16 @@ class PathIntegrator:
         if rc != 0:
             raise RuntimeError("mi_pt_trace failed: %s" % hip_lib().mi_pt_last_error().decode())
         return hits
+
+
+    def texture_lookup(self, tex, queries):
+        """MIPMap::Lookup on the device: queries [n, 6] = (s, t, dsdx, dtdx, dsdy, dtdy) -> rgb [n, 3]."""
+        q = np.ascontiguousarray(queries, np.float32)
+        out = np.zeros((q.shape[0], 3), np.float32)
+        rc = hip_lib().mi_pt_texture_lookup(self._h, int(tex), q.shape[0], _fptr(q), _fptr(out))
+        if rc != 0:
+            raise RuntimeError("mi_pt_texture_lookup failed: %s" % hip_lib().mi_pt_last_error().decode())
+        return out
 
 
 def CreatePathIntegrator(scene, device=0):

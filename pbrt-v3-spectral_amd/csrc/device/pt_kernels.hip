@@ -1434,6 +1434,15 @@ __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcIn
     funcInt[vox] = fi;
 }
 
+// ------------------------------------------------------------------ texture lookups on their own (mi_pt_texture_lookup)
+__global__ void k_texture_lookup(DScene s, int tex, const float *q, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mi_texture &t = s.textures[tex];
+    const RGB3 v = MipLookup(s, s.mipmaps[t.mipmap], q[6 * i], q[6 * i + 1], q[6 * i + 2], q[6 * i + 3], q[6 * i + 4], q[6 * i + 5], t.filter, t.max_aniso);
+    out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
+}
+
 // ------------------------------------------------------------------ standalone traversal (mi_pt_trace)
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, uint32_t n, int anyHit, float *hits) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1489,6 +1498,7 @@ struct mi_pt {
     std::vector<SubRenderer> subs;
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
+    uint32_t nTextures = 0;
     bool hasAlphaMasks = false;      // picks the traversal kernels compiled with the alpha-mask test
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
@@ -1809,6 +1819,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             for (uint32_t i = 0; i < d->n_textures; ++i)
                 if ((uint32_t)d->textures[i].mipmap >= d->n_mipmaps) { g_err = "mi_texture.mipmap out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
             if (d->n_textures) UP(d->textures, (size_t)d->n_textures, s.textures);
+            pt->nTextures = d->n_textures;
             float lut[128];   // MIPMap::weightLut, mipmap.h:199-206
             for (int i = 0; i < 128; ++i) {
                 float alpha = 2;
@@ -2069,6 +2080,23 @@ int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats) {
 int mi_pt_last_timings(mi_pt *pt, double *seconds, int n) {
     if (!pt || !seconds) { g_err = "null argument"; return MI_ERR_INVALID; }
     for (int i = 0; i < n && i < 8; ++i) seconds[i] = pt->lastSeconds[i];
+    return MI_OK;
+}
+
+int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *queries, float *rgb) {
+    if (!pt || !queries || !rgb) { g_err = "null argument"; return MI_ERR_INVALID; }
+    if (tex < 0 || (uint32_t)tex >= pt->nTextures) { g_err = "texture index out of range"; return MI_ERR_INVALID; }
+    if (n == 0) return MI_OK;
+    HIPCHK(hipSetDevice(pt->device));
+    float *dq = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&dq, (size_t)n * 6 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 3 * sizeof(float)));
+    HIPCHK(hipMemcpy(dq, queries, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_texture_lookup, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, tex, dq, n, dout);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(rgb, dout, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(dq);
+    hipFree(dout);
     return MI_OK;
 }
 

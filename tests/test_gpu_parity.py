@@ -413,3 +413,27 @@ def test_bump_mapping_against_oracle(pt, ob, tmp_path):
     flat = pt.Scene(text=st.bump_scene().replace('"texture bumpmap" "bumps_tri"', "").replace('"texture bumpmap" "bumps"', ""), base_dir=str(tmp_path))
     ff, _, _, _ = ob.render(flat)
     assert _rel_l2(ff, ofilm) > 0.02
+
+
+def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
+    """MIPMap::Lookup on the device against the oracle, query by query (mi_pt_texture_lookup / oracle_texture_lookup): EWA with
+    random anisotropic footprints, trilinear, unfiltered, the three wrap modes, coordinates outside [0, 1]. Equal bits are
+    expected except where the level of detail rests on logf's last bit (glibc's logf is not correctly rounded everywhere)."""
+    st.write_texture_files(str(tmp_path))
+    s = pt.Scene(text=st.textured_zoo(res=16, spp=1), base_dir=str(tmp_path))
+    assert s.errors == []
+    integ = pt.CreatePathIntegrator(s)
+    rng = np.random.default_rng(11)
+    n = 3000
+    for tex in range(s.desc.n_textures):
+        q = np.zeros((n, 6), np.float32)
+        q[:, 0:2] = rng.uniform(-0.7, 1.8, (n, 2))
+        scale = 10.0 ** rng.uniform(-4, -0.3, (n, 1))
+        q[:, 2:6] = rng.normal(0, 1, (n, 4)) * scale
+        q[: n // 10, 2:6] = 0          # zero footprints
+        q[n // 10: n // 5, 4:6] = 0    # degenerate ellipses
+        dev = integ.texture_lookup(tex, q)
+        ref = np.array([ob.texture_lookup(s, tex, q[i, 0:2], q[i, 2:4], q[i, 4:6])[0] for i in range(n)], np.float32)
+        same = (dev.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
+        assert same.mean() > 0.995, (tex, same.mean())
+        assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
