@@ -464,3 +464,96 @@ def bump_scene(res=64, spp=16, depth=4):
     """Material::Bump (material.cpp:47-84) with float image textures: a flat quad without normals, a curved patch with
     vertex normals, a mirrored patch with a textured Kd as well. Uses the files of write_texture_files()."""
     return BUMP_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch())
+
+
+def random_scene(seed, res=32, spp=8):
+    """A seeded random scene over the supported feature set (fuzzing the HIP path against the oracle): random meshes
+    with / without normals and uv, spheres, every material family with random parameters (image-textured, bump-mapped
+    and alpha-masked ones included), random lights, optional lens. Needs write_texture_files() + write_alpha_png()."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    r = lambda lo, hi: float(rng.uniform(lo, hi))
+    rgb = lambda lo=0.05, hi=0.95: "[%.3f %.3f %.3f]" % (r(lo, hi), r(lo, hi), r(lo, hi))
+    out = []
+    out.append('LookAt %.3f %.3f %.3f  %.3f %.3f 0  0 1 0' % (r(-2, 2), r(1, 4), r(-9, -6), r(-.5, .5), r(.5, 1.5)))
+    lens = ('"float lensradius" [%.3f] "float focaldistance" [%.2f]' % (r(.01, .1), r(5, 9))) if rng.random() < .4 else ""
+    out.append('Camera "perspective" "float fov" [%.1f] %s' % (r(30, 55), lens))
+    filt = rng.choice(["box", "triangle", "gaussian", "mitchell"])
+    out.append('PixelFilter "%s"' % filt)
+    out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (res, res))
+    out.append('Sampler "halton" "integer pixelsamples" [%d]' % spp)
+    integ = "spectralpath" if rng.random() < .25 else "path"
+    extra = ' "integer numCABands" [%d]' % int(rng.integers(2, 5)) if integ == "spectralpath" else ""
+    out.append('Integrator "%s" "integer maxdepth" [%d] "string lightsamplestrategy" "%s"%s'
+               % (integ, int(rng.integers(1, 7)), rng.choice(["uniform", "power", "spatial"]), extra))
+    out.append("WorldBegin")
+    # lights
+    out.append('AttributeBegin\n  AreaLightSource "diffuse" "rgb L" %s %s\n  Translate %.2f %.2f %.2f\n'
+               '  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]\nAttributeEnd'
+               % (rgb(5, 20), '"bool twosided" ["true"]' if rng.random() < .3 else "", r(-2, 2), r(4, 6), r(-2, 2)))
+    if rng.random() < .6:
+        out.append('LightSource "point" "rgb I" %s "point from" [%.2f %.2f %.2f]' % (rgb(3, 15), r(-4, 4), r(2, 5), r(-5, 0)))
+    if rng.random() < .4:
+        out.append('LightSource "spot" "rgb I" %s "point from" [%.2f %.2f %.2f] "point to" [0 0 0] "float coneangle" [%.1f] "float conedeltaangle" [%.1f]'
+                   % (rgb(10, 40), r(-4, 4), r(3, 5), r(-5, -2), r(15, 40), r(2, 10)))
+    if rng.random() < .4:
+        out.append('LightSource "distant" "rgb L" %s "point from" [%.2f 8 %.2f] "point to" [0 0 0]' % (rgb(.2, 1.2), r(-3, 3), r(-6, 0)))
+    if rng.random() < .4:
+        out.append('LightSource "infinite" "rgb L" %s' % rgb(.1, .6))
+    if rng.random() < .3:
+        out.append('AttributeBegin\n  AreaLightSource "diffuse" "rgb L" %s\n  Translate %.2f %.2f %.2f\n  Shape "sphere" "float radius" [%.2f]\nAttributeEnd'
+                   % (rgb(5, 30), r(-3, 3), r(2.5, 4), r(-1, 2), r(.2, .5)))
+    out.append('Texture "img_a" "spectrum" "imagemap" "string filename" "tex_a.png" "float uscale" [%.2f] "float vscale" [%.2f] %s'
+               % (r(.5, 4), r(.5, 4), '"bool trilinear" ["true"]' if rng.random() < .5 else ""))
+    out.append('Texture "img_b" "spectrum" "imagemap" "string filename" "tex_b.tga" "string wrap" "%s"' % rng.choice(["repeat", "black", "clamp"]))
+    out.append('Texture "img_s" "spectrum" "scale" "texture tex1" "img_b" "rgb tex2" %s' % rgb(.3, 1))
+    out.append('Texture "bump_raw" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [2] "float vscale" [2]')
+    out.append('Texture "bump" "float" "scale" "texture tex1" "bump_raw" "float tex2" [%.3f]' % r(.01, .1))
+    out.append('Texture "mask" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [%.1f]' % r(1, 3))
+
+    def material():
+        k = int(rng.integers(0, 14))
+        bump = ' "texture bumpmap" "bump"' if rng.random() < .25 else ""
+        if k == 0: return 'Material "matte" "rgb Kd" %s "float sigma" [%.1f]%s' % (rgb(), r(0, 40) if rng.random() < .5 else 0, bump)
+        if k == 1: return 'Material "plastic" "rgb Kd" %s "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(), rgb(.05, .5), r(.01, .4), bump)
+        if k == 2: return 'Material "glass" "rgb Kr" %s "rgb Kt" %s "float index" [%.2f]' % (rgb(.5, 1), rgb(.5, 1), r(1.2, 1.8))
+        if k == 3: return 'Material "mirror" "rgb Kr" %s' % rgb(.5, .95)
+        if k == 4: return ('Material "uber" "rgb Kd" %s "rgb Ks" %s "rgb Kr" %s "rgb Kt" %s "float roughness" [%.3f] "rgb opacity" %s%s'
+                           % (rgb(), rgb(.05, .4), rgb(0, .3), rgb(0, .3), r(.02, .4), rgb(.6, 1) if rng.random() < .4 else "[1 1 1]", bump))
+        if k == 5: return 'Material "metal" "float roughness" [%.3f]' % r(.005, .2)
+        if k == 6: return 'Material "substrate" "rgb Kd" %s "rgb Ks" %s "float uroughness" [%.3f] "float vroughness" [%.3f]' % (rgb(), rgb(.05, .5), r(.02, .3), r(.02, .3))
+        if k == 7: return 'Material "translucent" "rgb Kd" %s "rgb Ks" %s "rgb reflect" %s "rgb transmit" %s' % (rgb(), rgb(.05, .4), rgb(.2, .7), rgb(.2, .7))
+        if k == 8: return 'Material "disney" "rgb color" %s "float metallic" [%.2f] "float roughness" [%.2f] "float clearcoat" [%.2f] "float sheen" [%.2f]' % (rgb(), r(0, 1), r(.1, .8), r(0, 1), r(0, 1))
+        if k == 9: return 'Material "matte" "texture Kd" "img_a"%s' % bump
+        if k == 10: return 'Material "plastic" "texture Kd" "img_s" "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(.05, .4), r(.02, .3), bump)
+        if k == 11: return 'Material "uber" "texture Kd" "img_b" "texture Ks" "img_a" "rgb Kr" %s "float roughness" [%.3f]' % (rgb(0, .2), r(.05, .3))
+        if k == 12: return 'Material "substrate" "texture Kd" "img_a" "rgb Ks" %s' % rgb(.05, .4)
+        return 'Material "glass" "texture Kt" "img_b" "rgb Kr" %s' % rgb(.5, 1)
+
+    out.append('AttributeBegin\n  %s\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 -8  8 0 -8  8 0 8  -8 0 8] "float uv" [0 0 4 0 4 4 0 4]\nAttributeEnd' % material())
+    out.append('AttributeBegin\n  %s\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 5  8 0 5  8 8 5  -8 8 5] "float uv" [0 0 2 0 2 1 0 1]\nAttributeEnd' % material())
+    for _ in range(int(rng.integers(3, 8))):
+        out.append("AttributeBegin")
+        out.append("  " + material())
+        out.append("  Translate %.2f %.2f %.2f" % (r(-3.5, 3.5), r(.5, 2.5), r(-2, 3)))
+        out.append("  Rotate %.1f %.2f %.2f %.2f" % (r(0, 360), r(-1, 1), r(-1, 1) + 1e-3, r(-1, 1)))
+        if rng.random() < .2:
+            out.append("  Scale -1 1 1")
+        if rng.random() < .2:
+            out.append("  ReverseOrientation")
+        kind = rng.random()
+        if kind < .3:
+            textured = "texture" in out[-3] or "texture" in out[-4] if len(out) > 4 else False
+            mat_line = next(l for l in reversed(out) if l.strip().startswith("Material"))
+            if "texture" in mat_line:
+                out.append("  " + _curved_patch(4, 3))
+            else:
+                out.append('  Shape "sphere" "float radius" [%.2f]' % r(.3, .9))
+        elif kind < .6:
+            out.append("  " + _curved_patch(int(rng.integers(2, 6)), int(rng.integers(2, 5))))
+        else:
+            alpha = ' "texture alpha" "mask"' if rng.random() < .35 else (' "texture shadowalpha" "mask"' if rng.random() < .2 else "")
+            out.append('  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0] "float uv" [0 0 1 0 1 1 0 1]%s' % alpha)
+        out.append("AttributeEnd")
+    out.append("WorldEnd")
+    return "\n".join(out) + "\n"
