@@ -122,7 +122,8 @@ struct Pool {
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
-    DEV float4 &Q(int plane, uint32_t slot) const { return q[(size_t)plane * n + slot]; }
+    // a slot's 8 quads of one spectrum are one 128-B line: [spectrum][slot][quad]
+    DEV float4 &Q(int plane, uint32_t slot) const { return q[(((size_t)(plane >> 3) * n + slot) << 3) + (plane & 7)]; }
     DEV float4 &R(int plane, uint32_t slot) const { return r[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
 };
@@ -686,6 +687,9 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
 __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
+    int myFlags = 0;
+    uint32_t mySlot = 0;
+    bool valid = false, doAdd = false;
     if (qi < ctr->shadowCount.v) {
         const uint32_t slot = pool.shadowQ[qi];
         int flags = pool.I(I_FLAGS, slot);
@@ -696,26 +700,42 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
             Hit h;
             occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
         }
-        bool added = false;
-        if (!occluded) {
-            const bool lZero = (flags & F_L_ZERO) != 0;
-            for (int c = 0; c < NQ; ++c) {
-                const float4 a = pool.Q(Q_LNEE + c, slot);
-                added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!lZero) l = pool.Q(Q_L + c, slot);
-                l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-                pool.Q(Q_L + c, slot) = l;
-            }
-            flags &= ~F_L_ZERO;
+        myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
+    }
+    // L += contribution, eight lanes per path: lane (8j + c) of pass `it` adds quad c of entry 8*it + j, so every
+    // load and store of the wave is eight whole 128-B lines
+    const int lane = threadIdx.x & 63;
+    unsigned addedBits = 0;
+    for (int it = 0; it < 8; ++it) {
+        const int src = it * 8 + (lane >> 3);
+        const uint32_t sSlot = (uint32_t)__shfl((int)mySlot, src);
+        const int sAdd = __shfl(doAdd ? 1 : 0, src);
+        const int sZero = __shfl((myFlags & F_L_ZERO) ? 1 : 0, src);
+        bool nz = false;
+        if (sAdd) {
+            const int c = lane & 7;
+            const float4 a = pool.Q(Q_LNEE + c, sSlot);
+            nz = (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+            float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!sZero) l = pool.Q(Q_L + c, sSlot);
+            l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+            pool.Q(Q_L + c, sSlot) = l;
         }
+        const unsigned long long m = __ballot(nz);
+        if ((lane >> 3) == it) addedBits = (unsigned)((m >> (8 * (lane & 7))) & 0xffull);
+    }
+    if (valid) {
+        int flags = myFlags;
+        const bool added = addedBits != 0;
+        if (doAdd) flags &= ~F_L_ZERO;
         flags &= ~F_SHADOW;
         if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
         else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
-        pool.I(I_FLAGS, slot) = flags;
+        pool.I(I_FLAGS, mySlot) = flags;
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
+
 
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
