@@ -1053,6 +1053,41 @@ DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
     return bt;
 }
 
+// Whole-line stores of a spectrum from a shading wave. The memory side takes a store instruction as it comes: 64 lanes
+// each storing 16 B of its own path's line leave L2 as 64 partial 64-B writes, and a spectrum written quad by quad
+// costs 8 x 64 B of write traffic for 128 B of data (PMC: k_shade wrote 1.66 KB per vertex for 0.36 KB of state). So
+// the lanes park their quads in an LDS tile and the wave stores them eight lanes per path, every store instruction
+// covering whole 128-B lines. Works from divergent code: only the lanes that are active at the call take part, the
+// k-th group of eight active lanes storing the lines of the k-th, (k+G)-th, ... path that has something to store.
+struct SpectrumTile {
+    float4 q[NQ][BLOCK];
+    int slotOf[BLOCK];
+    unsigned char laneOf[BLOCK];
+};
+DEV void StoreSpectrumLines(SpectrumTile &t, const Pool &pool, int spectrum, uint32_t slot, bool wrote) {
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long active = __ballot(1), wmask = __ballot(wrote);
+    const int nW = __popcll(wmask), nGroups = __popcll(active) >> 3;
+    if (nGroups == 0) {   // fewer than eight lanes here: each stores its own quads
+        if (wrote) for (int c = 0; c < NQ; ++c) pool.Q(spectrum + c, slot) = t.q[c][threadIdx.x];
+        return;
+    }
+    if (wrote) {
+        const int rw = __popcll(wmask & lt);
+        t.slotOf[wbase + rw] = (int)slot;
+        t.laneOf[wbase + rw] = (unsigned char)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile and the list are written before they are read
+    __builtin_amdgcn_wave_barrier();
+    const int ra = __popcll(active & lt), g = ra >> 3, c = ra & 7;
+    if (g < nGroups)
+        for (int e = g; e < nW; e += nGroups)
+            pool.Q(spectrum + c, (uint32_t)t.slotOf[wbase + e]) = t.q[c][wbase + t.laneOf[wbase + e]];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... and read before the tile is reused
+    __builtin_amdgcn_wave_barrier();
+}
+
 #ifndef MIPT_SHADE_WAVES_PER_EU
 #define MIPT_SHADE_WAVES_PER_EU 4
 #endif
@@ -1069,6 +1104,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         blk -= nb;
     }
     const uint32_t qi = blk * BLOCK + threadIdx.x;
+    __shared__ SpectrumTile tile;
     unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
     bool wantShadow = false, wantMis = false;
     uint32_t slot = 0;
@@ -1242,8 +1278,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         Set4(out, k, Get4(bt, k) * Ld);
                                     }
                                 }
-                                pool.Q(Q_LNEE + c, slot) = out;
+                                tile.q[c][threadIdx.x] = out;
                             }
+                            StoreSpectrumLines(tile, pool, Q_LNEE, slot, true);
                             if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
                                 pool.R(R_SH0, slot) = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.d.x);
@@ -1343,8 +1380,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 maxRR = (b == 0) ? rr : maxf(maxRR, rr);
                             }
                         }
-                        pool.Q(Q_BETA + c, slot) = bt;
+                        tile.q[c][threadIdx.x] = bt;
                     }
+                    StoreSpectrumLines(tile, pool, Q_BETA, slot, true);
                     betaWritten = true;
                     if (fNonBlack) {
                         Ray nr = SpawnRay(isect, wi);
@@ -1357,7 +1395,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 const Divisor inv = MakeDivisor(1 - q);
 #pragma unroll 1
                                 for (int c = 0; c < NQ; ++c) {
-                                    float4 bt = pool.Q(Q_BETA + c, slot);
+                                    float4 bt = tile.q[c][threadIdx.x];   // (the new beta, still parked in the tile)
 #pragma unroll
                                     for (int k = 0; k < 4; ++k)
                                         if (4 * c + k < MI_NSPEC) Set4(bt, k, DivBy(Get4(bt, k), inv));
