@@ -1,4 +1,4 @@
-// image.cpp -- ReadImage for .pfm / .tga / .png and MIPMap<RGBSpectrum> construction.
+// image.cpp -- ReadImage for .pfm / .tga / .png / .exr and MIPMap<RGBSpectrum> construction.
 //   ReadImagePFM   src/core/imageio.cpp:349-435
 //   ReadImageTGA   src/core/imageio.cpp:216-255 (pixels / 255, BGR order; the reference decodes through ext/targa,
 //                  here the TGA 2.0 layout is read directly: types 1, 2, 3 and their RLE forms 9, 10, 11)
@@ -220,6 +220,158 @@ bool ReadPNG(const std::string &filename, int *xres, int *yres, std::vector<RGB>
     return true;
 }
 
+// ---- OpenEXR, the subset the reference's scenes use: single-part scan-line files, channels R / G / B (HALF or
+// FLOAT, sampling 1), compression NONE, RLE, ZIPS or ZIP. The reference reads through Imf::RgbaInputFile
+// (imageio.cpp:121-160), whose frame buffer is HALF: FLOAT channels are rounded to half on the way in, missing colour
+// channels read as 0. Layout: OpenEXR file layout document ("Structure of a scan-line file", "Predictor and
+// reordering" for the zip / rle codecs).
+inline float HalfToFloat(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {   // subnormal half
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ff) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+inline uint16_t FloatToHalf(float f) {   // round to nearest even, as half(float) does
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000);
+    const uint32_t ax = x & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00);    // NaN
+    if (ax >= 0x47800000u) return (uint16_t)(sign | 0x7c00);   // >= 65536 (and infinity)
+    if (ax < 0x38800000u) {                                     // below 2^-14: a subnormal half, units of 2^-24
+        if (ax < 0x33000000u) return sign;                      // below 2^-25
+        const int shift = 126 - (int)(ax >> 23);                // 14 .. 24
+        const uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+        uint32_t q = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (q & 1u))) ++q;
+        return (uint16_t)(sign | q);                            // (q == 0x400 is the smallest normal half: the encodings join)
+    }
+    uint32_t h = (((ax >> 23) - 112u) << 10) | ((ax & 0x7fffffu) >> 13);
+    const uint32_t rem = ax & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;    // a carry runs into the exponent, up to infinity
+    return (uint16_t)(sign | h);
+}
+
+bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB> *out, std::string *err) {
+    std::vector<unsigned char> f;
+    auto fail = [&](const std::string &why) { *err = "Unable to read image file \"" + filename + "\": " + why; return false; };
+    if (!ReadFile(filename, &f) || f.size() < 16) return fail("cannot open, or not an OpenEXR file");
+    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &f[o], 4); return v; };
+    if ((uint32_t)i32(0) != 20000630u) return fail("not an OpenEXR file");
+    const uint32_t version = (uint32_t)i32(4);
+    if ((version & 0xff) != 2 || (version & 0x1a00)) return fail("tiled, deep or multi-part OpenEXR files are not read by this build");
+    size_t pos = 8;
+    struct Channel { std::string name; int type; };
+    std::vector<Channel> channels;
+    int compression = -1, lineOrder = 0, dw[4] = {0, 0, -1, -1};
+    while (pos < f.size() && f[pos] != 0) {
+        std::string name((const char *)&f[pos]); pos += name.size() + 1;
+        if (pos >= f.size()) return fail("truncated header");
+        std::string type((const char *)&f[pos]); pos += type.size() + 1;
+        if (pos + 4 > f.size()) return fail("truncated header");
+        const int size = i32(pos); pos += 4;
+        if (size < 0 || pos + (size_t)size > f.size()) return fail("truncated header");
+        if (name == "channels") {
+            size_t p = pos;
+            while (p < pos + size && f[p] != 0) {
+                Channel c;
+                c.name = (const char *)&f[p]; p += c.name.size() + 1;
+                c.type = i32(p);
+                const int xs = i32(p + 8), ys = i32(p + 12);
+                p += 16;
+                if (xs != 1 || ys != 1) return fail("subsampled channels are not read by this build");
+                channels.push_back(c);
+            }
+        } else if (name == "compression") compression = f[pos];
+        else if (name == "dataWindow") for (int k = 0; k < 4; ++k) dw[k] = i32(pos + 4 * k);
+        else if (name == "lineOrder") lineOrder = f[pos];
+        pos += size;
+    }
+    ++pos;   // end of header
+    (void)lineOrder;   // every chunk carries its y
+    const int w = dw[2] - dw[0] + 1, h = dw[3] - dw[1] + 1;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || channels.empty()) return fail("bad header");
+    int linesPerBlock;
+    switch (compression) { case 0: case 1: case 2: linesPerBlock = 1; break; case 3: linesPerBlock = 16; break;
+                           default: return fail("compression method " + std::to_string(compression) + " (PIZ, PXR24, B44, DWA) is not read by this build"); }
+    size_t lineBytes = 0;
+    std::vector<size_t> chOffset(channels.size());
+    for (size_t c = 0; c < channels.size(); ++c) {
+        if (channels[c].type < 0 || channels[c].type > 2) return fail("bad channel type");
+        chOffset[c] = lineBytes;
+        lineBytes += (size_t)w * (channels[c].type == 1 ? 2 : 4);
+    }
+    const int nChunks = (h + linesPerBlock - 1) / linesPerBlock;
+    if (pos + (size_t)nChunks * 8 > f.size()) return fail("truncated offset table");
+    std::vector<float> plane[3];
+    int src[3] = {-1, -1, -1};
+    for (size_t c = 0; c < channels.size(); ++c) {
+        if (channels[c].name == "R") src[0] = (int)c; else if (channels[c].name == "G") src[1] = (int)c; else if (channels[c].name == "B") src[2] = (int)c;
+        else if (channels[c].name == "Y" && src[0] < 0) { src[0] = src[1] = src[2] = (int)c; }   // luminance-only file
+    }
+    out->assign((size_t)w * h, RGB(0.f));
+    std::vector<unsigned char> raw, tmp;
+    for (int chunk = 0; chunk < nChunks; ++chunk) {
+        uint64_t off;
+        memcpy(&off, &f[pos + (size_t)chunk * 8], 8);
+        if (off + 8 > f.size()) return fail("truncated chunk");
+        const int y = i32(off), dataSize = i32(off + 4);
+        if (dataSize < 0 || off + 8 + (size_t)dataSize > f.size()) return fail("truncated chunk");
+        const int y0 = y - dw[1], nLines = std::min(linesPerBlock, h - y0);
+        if (y0 < 0 || y0 >= h) return fail("chunk outside the data window");
+        const size_t rawSize = lineBytes * nLines;
+        raw.resize(rawSize);
+        const unsigned char *data = &f[off + 8];
+        if (compression == 0 || (size_t)dataSize == rawSize) memcpy(raw.data(), data, std::min(rawSize, (size_t)dataSize));
+        else {
+            tmp.resize(rawSize);
+            if (compression == 1) {   // run-length
+                size_t o = 0, i = 0;
+                while (i < (size_t)dataSize && o < rawSize) {
+                    const int count = (signed char)data[i++];
+                    if (count < 0) { const size_t n = (size_t)(-count); if (i + n > (size_t)dataSize || o + n > rawSize) return fail("bad RLE data"); memcpy(&tmp[o], &data[i], n); i += n; o += n; }
+                    else { const size_t n = (size_t)count + 1; if (i >= (size_t)dataSize || o + n > rawSize) return fail("bad RLE data"); memset(&tmp[o], data[i++], n); o += n; }
+                }
+                if (o != rawSize) return fail("bad RLE data");
+            } else {
+                uLongf n = (uLongf)rawSize;
+                if (uncompress(tmp.data(), &n, data, (uLong)dataSize) != Z_OK || n != rawSize) return fail("inflate failed");
+            }
+            for (size_t i = 1; i < rawSize; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);   // predictor
+            const size_t halfN = (rawSize + 1) / 2;                                                  // reordering
+            for (size_t i = 0; i < rawSize; ++i) raw[i] = (i & 1) ? tmp[halfN + i / 2] : tmp[i / 2];
+        }
+        for (int l = 0; l < nLines; ++l) {
+            const unsigned char *line = &raw[lineBytes * l];
+            for (int k = 0; k < 3; ++k) {
+                if (src[k] < 0) continue;
+                const Channel &c = channels[src[k]];
+                const unsigned char *p = line + chOffset[src[k]];
+                for (int x = 0; x < w; ++x) {
+                    float v;
+                    if (c.type == 1) { uint16_t hbits; memcpy(&hbits, p + 2 * x, 2); v = HalfToFloat(hbits); }
+                    else if (c.type == 2) { float fv; memcpy(&fv, p + 4 * x, 4); v = HalfToFloat(FloatToHalf(fv)); }
+                    else { uint32_t u; memcpy(&u, p + 4 * x, 4); v = HalfToFloat(FloatToHalf((float)u)); }
+                    (*out)[(size_t)(y0 + l) * w + x].c[k] = v;
+                }
+            }
+        }
+    }
+    *xres = w; *yres = h;
+    return true;
+}
+
 }  // namespace
 
 bool ReadImage(const std::string &filename, int *xres, int *yres, std::vector<RGB> *texels, std::string *err) {
@@ -233,8 +385,9 @@ bool ReadImage(const std::string &filename, int *xres, int *yres, std::vector<RG
     }
     if (ext == ".tga") return ReadTGA(filename, xres, yres, texels, err);
     if (ext == ".png") return ReadPNG(filename, xres, yres, texels, err);
+    if (ext == ".exr") return ReadEXR(filename, xres, yres, texels, err);
     *err = "Unable to load image stored in format \"" + (ext.empty() ? std::string("(unknown)") : ext.substr(1)) + "\" for filename \"" +
-           filename + "\" (this build reads PFM, TGA and PNG).";
+           filename + "\" (this build reads PFM, TGA, PNG and scan-line EXR).";
     return false;
 }
 

@@ -557,3 +557,42 @@ def random_scene(seed, res=32, spp=8):
         out.append("AttributeEnd")
     out.append("WorldEnd")
     return "\n".join(out) + "\n"
+
+
+def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0, 0)):
+    """Minimal scan-line OpenEXR writer for tests: img [h, w, 3] float; channels B, G, R (alphabetical, as the format wants)
+    as HALF or FLOAT; compression "none", "zips" (1 line per chunk) or "zip" (16 lines per chunk)."""
+    import struct, zlib
+    import numpy as np
+    h, w, _ = img.shape
+    px = img.astype(np.float16 if dtype == "half" else np.float32)
+    ptype = 1 if dtype == "half" else 2
+    comp = {"none": 0, "zips": 2, "zip": 3}[compression]
+    lines_per = 16 if comp == 3 else 1
+    x0, y0 = data_window_origin
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in ("B", "G", "R")) + b"\0"
+    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    header = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp])) + attr("dataWindow", "box2i", box) +
+              attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) +
+              attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    chunks = []
+    for c0 in range(0, h, lines_per):
+        raw = b"".join(px[y, :, k].tobytes() for y in range(c0, min(c0 + lines_per, h)) for k in (2, 1, 0))
+        data = raw
+        if comp:
+            t = np.frombuffer(raw, np.uint8)
+            re = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)
+            d = re.copy()
+            d[1:] = (re[1:] - re[:-1] + 128 + 256) & 255
+            z = zlib.compress(d.astype(np.uint8).tobytes(), 6)
+            data = z if len(z) < len(raw) else raw
+        chunks.append(struct.pack("<ii", y0 + c0, len(data)) + data)
+    start = 8 + len(header) + 8 * len(chunks)
+    offs, p = [], start
+    for c in chunks:
+        offs.append(p); p += len(c)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 20000630, 2) + header + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(chunks))

@@ -378,7 +378,9 @@ def test_infinite_light_environment_map(pt, tmp_path):
     l = d.lights[0]
     assert abs(l.l2w[0]) < 1e-6 and abs(abs(l.l2w[1]) - 1) < 1e-6           # the Rotate reached the light's frame
     s = pt.Scene(text=head + 'LightSource "infinite" "string mapname" "sky.exr"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
-    assert any("PFM" in m for m in s.errors) and s.desc.envmaps[0].width == 1
+    assert any("sky.exr" in m for m in s.errors) and s.desc.envmaps[0].width == 1     # unreadable map: constant light, reported
+    s = pt.Scene(text=head + 'LightSource "infinite" "string mapname" "sky.jpg"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("PFM, TGA, PNG and scan-line EXR" in m for m in s.errors)
 
 
 def test_scale_and_mix_textures_of_constants_fold(pt):
@@ -625,3 +627,64 @@ def test_parallel_bvh_build_is_the_serial_tree(pt, tmp_path, monkeypatch):
         return d.n_nodes, hashlib.md5(nodes).hexdigest(), hashlib.md5(prims).hexdigest(), s.stats["interior_nodes"], s.stats["leaf_nodes"]
     one = digest(1)
     assert one[0] > 100000 and one == digest(4) == digest(13)
+
+
+def test_exr_images_are_read_like_rgba_input_file(pt, tmp_path):
+    """ReadImageEXR (imageio.cpp:121-160) goes through Imf::RgbaInputFile: HALF frame buffer, so FLOAT channels are rounded to
+    half; scan-line files with no / ZIPS / ZIP compression, a data window that does not start at 0; PIZ is reported."""
+    rng = np.random.default_rng(4)
+    img = (rng.random((20, 16, 3)) ** 3 * 50).astype(np.float32)
+    img[3, 5] = [1e-6, 65000.0, 7e4]     # a subnormal half, near the top of the range, beyond it (-> inf)
+    img[4, 4] = [0.0, 1.0, 0.33333334]
+    want = img.astype(np.float16).astype(np.float32)
+    head = 'Camera "perspective"\nWorldBegin\n'
+    body = ""
+    cases = [("none", "half"), ("zips", "half"), ("zip", "half"), ("zip", "float"), ("none", "float")]
+    for i, (comp, dt) in enumerate(cases):
+        st.write_exr(str(tmp_path / ("t%d.exr" % i)), img, compression=comp, dtype=dt, data_window_origin=(3, -2) if i == 2 else (0, 0))
+        body += 'Texture "t%d" "spectrum" "imagemap" "string filename" "t%d.exr" "string wrap" "clamp"\n' % (i, i)
+        body += 'Material "matte" "texture Kd" "t%d"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n' % i
+    s = pt.Scene(text=head + body + "WorldEnd\n", base_dir=str(tmp_path))
+    assert s.errors == [] and s.desc.n_mipmaps == len(cases)
+    for i in range(len(cases)):
+        m = s.desc.mipmaps[i]
+        assert (m.width, m.height) == (16, 32)        # 20 rows resampled to 32; 16 columns kept
+    # level 0 of a power-of-two image is the file's pixels (flipped): use a 16 x 8 crop written again
+    st.write_exr(str(tmp_path / "p2.exr"), img[:8], compression="zip", dtype="float")
+    s = pt.Scene(text=head + 'Texture "p" "spectrum" "imagemap" "string filename" "p2.exr"\nMaterial "matte" "texture Kd" "p"\n'
+                 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', base_dir=str(tmp_path))
+    assert s.errors == []
+    l0 = _mip_level(s.desc.mipmaps[0], 0)
+    assert np.array_equal(l0, want[:8][::-1])
+    assert np.isinf(l0[8 - 1 - 3, 5, 2]) and l0[8 - 1 - 3, 5, 0] > 0
+    # an environment map in EXR
+    st.write_exr(str(tmp_path / "env.exr"), img, compression="zip", dtype="half")
+    s = pt.Scene(text=head + 'LightSource "infinite" "string mapname" "env.exr"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert s.errors == [] and (s.desc.envmaps[0].width, s.desc.envmaps[0].height) == (16, 32)
+    # unsupported compression is an error, not garbage
+    raw = bytearray(open(tmp_path / "t0.exr", "rb").read())
+    raw[raw.index(b"compression\0compression\0") + 28] = 4   # PIZ
+    open(tmp_path / "piz.exr", "wb").write(bytes(raw))
+    s = pt.Scene(text=head + 'Texture "z" "spectrum" "imagemap" "string filename" "piz.exr"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("compression method 4" in e for e in s.errors)
+
+
+def test_exr_float_channels_round_to_half_like_numpy(pt, tmp_path):
+    """FLOAT channels reach the texture as half(float) (round to nearest even): magnitudes from subnormal halves to overflow,
+    and exact ties between neighbouring halves."""
+    rng = np.random.default_rng(9)
+    v = (10.0 ** rng.uniform(-9, 5.2, 64 * 64 * 3)).astype(np.float32)
+    h = rng.integers(1, 0x7bff, 2048).astype(np.uint16).view(np.float16).astype(np.float32)
+    nxt = (rng.integers(1, 0x7bff, 2048).astype(np.uint16) + 1).view(np.float16).astype(np.float32)
+    v[:2048] = h                                                     # exact halves
+    hh = rng.integers(1, 0x7bfe, 2048).astype(np.uint16)
+    v[2048:4096] = (hh.view(np.float16).astype(np.float64) + (hh + 1).view(np.float16).astype(np.float64)).astype(np.float32) / 2   # ties
+    img = v.reshape(64, 64, 3)
+    st.write_exr(str(tmp_path / "f.exr"), img, compression="zip", dtype="float")
+    s = pt.Scene(text='Camera "perspective"\nWorldBegin\nTexture "f" "spectrum" "imagemap" "string filename" "f.exr"\n'
+                 'Material "matte" "texture Kd" "f"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n',
+                 base_dir=str(tmp_path))
+    assert s.errors == []
+    with np.errstate(over="ignore"):
+        want = img.astype(np.float16).astype(np.float32)[::-1]
+    assert np.array_equal(_mip_level(s.desc.mipmaps[0], 0), want)
