@@ -44,9 +44,9 @@ const char *mi_scene_last_error(void);
  * float64 (plane-major), values multiplied by `scale`. film_sum is [h*w*31]. */
 int mi_film_write_dat(const char *filename, int w, int h, const float *film_sum, float scale);
 /* Film::WriteImage, RGB branch ("bool spectralFlag" false; src/core/film.cpp:182-225 + imageio.cpp:81-119):
- * XYZ -> RGB of the summed spectrum, division by the filter-weight sum, clamp, scale. Writes PFM (.pfm) or
- * TGA (.tga); any other extension (EXR/PNG need libraries this build does not link) is written as a .pfm
- * beside it. weight_sum is [h*w]. */
+ * XYZ -> RGB of the summed spectrum, division by the filter-weight sum, clamp, scale. Writes PFM (.pfm),
+ * TGA (.tga) or scan-line OpenEXR (.exr: HALF B, G, R, ZIP -- WriteImageEXR, imageio.cpp:163-189); any other extension
+ * (PNG) is written as a .pfm beside it. weight_sum is [h*w]. */
 int mi_film_write_rgb(const char *filename, int w, int h, const float *film_sum, const float *weight_sum, float scale);
 /* Read one back: returns 0 and fills w,h; data (if non-NULL) receives
  * [h*w*31] floats pixel-major. */

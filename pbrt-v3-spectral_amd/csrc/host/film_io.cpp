@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include "scene.h"
+#include "image.h"
 
 namespace mipt {
 
@@ -67,6 +68,10 @@ bool WriteRGBImage(const std::string &filename, int w, int h, const float *filmS
     };
     std::string out = filename;
     const bool tga = hasExt(".tga");
+    if (hasExt(".exr")) {   // WriteImageEXR, imageio.cpp:163-189
+        if (written) *written = out;
+        return WriteEXR(out, w, h, rgb.data(), err);
+    }
     if (!tga && !hasExt(".pfm")) out = filename.substr(0, filename.find_last_of('.')) + ".pfm";
     FILE *f = fopen(out.c_str(), "wb");
     if (!f) { *err = "Unable to open output file \"" + out + "\""; return false; }

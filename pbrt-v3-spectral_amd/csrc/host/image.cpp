@@ -374,6 +374,71 @@ bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB>
 
 }  // namespace
 
+bool WriteEXR(const std::string &filename, int w, int h, const float *rgb, std::string *err) {
+    std::vector<unsigned char> head;
+    auto put = [&](const void *p, size_t n) { head.insert(head.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
+    auto putStr = [&](const char *s) { put(s, strlen(s) + 1); };
+    auto attr = [&](const char *name, const char *type, const void *data, int32_t size) { putStr(name); putStr(type); put(&size, 4); put(data, size); };
+    const uint32_t magic = 20000630u, version = 2;
+    put(&magic, 4); put(&version, 4);
+    {
+        std::vector<unsigned char> ch;
+        for (const char *n : {"B", "G", "R"}) {
+            ch.insert(ch.end(), n, n + 2);
+            const int32_t v[4] = {1 /* HALF */, 0, 1, 1};
+            ch.insert(ch.end(), (const unsigned char *)v, (const unsigned char *)v + 16);
+        }
+        ch.push_back(0);
+        attr("channels", "chlist", ch.data(), (int32_t)ch.size());
+    }
+    const unsigned char zip = 3, incY = 0;
+    attr("compression", "compression", &zip, 1);
+    const int32_t box[4] = {0, 0, w - 1, h - 1};
+    attr("dataWindow", "box2i", box, 16);
+    attr("displayWindow", "box2i", box, 16);
+    attr("lineOrder", "lineOrder", &incY, 1);
+    const float one = 1.f, centre[2] = {0.f, 0.f};
+    attr("pixelAspectRatio", "float", &one, 4);
+    attr("screenWindowCenter", "v2f", centre, 8);
+    attr("screenWindowWidth", "float", &one, 4);
+    head.push_back(0);
+    const int linesPerBlock = 16, nChunks = (h + linesPerBlock - 1) / linesPerBlock;
+    std::vector<std::vector<unsigned char>> chunks(nChunks);
+    const size_t lineBytes = (size_t)w * 3 * 2;
+    std::vector<unsigned char> raw, tmp;
+    for (int c = 0; c < nChunks; ++c) {
+        const int y0 = c * linesPerBlock, nLines = std::min(linesPerBlock, h - y0);
+        raw.resize(lineBytes * nLines);
+        for (int l = 0; l < nLines; ++l)
+            for (int k = 0; k < 3; ++k)   // channel order B, G, R
+                for (int x = 0; x < w; ++x) {
+                    const uint16_t hv = FloatToHalf(rgb[3 * ((size_t)(y0 + l) * w + x) + (2 - k)]);
+                    memcpy(&raw[lineBytes * l + ((size_t)k * w + x) * 2], &hv, 2);
+                }
+        const size_t n = raw.size(), halfN = (n + 1) / 2;
+        tmp.resize(n);
+        for (size_t i = 0; i < n; ++i) tmp[(i & 1) ? halfN + i / 2 : i / 2] = raw[i];            // reordering
+        for (size_t i = n - 1; i >= 1; --i) tmp[i] = (unsigned char)(tmp[i] - tmp[i - 1] + 128);   // predictor
+        uLongf zn = compressBound((uLong)n);
+        std::vector<unsigned char> z(zn);
+        const bool packed = compress2(z.data(), &zn, tmp.data(), (uLong)n, 6) == Z_OK && zn < n;
+        const int32_t y = y0, size = (int32_t)(packed ? zn : n);
+        chunks[c].insert(chunks[c].end(), (const unsigned char *)&y, (const unsigned char *)&y + 4);
+        chunks[c].insert(chunks[c].end(), (const unsigned char *)&size, (const unsigned char *)&size + 4);
+        if (packed) chunks[c].insert(chunks[c].end(), z.begin(), z.begin() + zn);
+        else chunks[c].insert(chunks[c].end(), raw.begin(), raw.end());
+    }
+    FILE *f = fopen(filename.c_str(), "wb");
+    if (!f) { *err = "Error writing \"" + filename + "\""; return false; }
+    bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+    uint64_t off = head.size() + (uint64_t)nChunks * 8;
+    for (int c = 0; c < nChunks && ok; ++c) { ok = fwrite(&off, 8, 1, f) == 1; off += chunks[c].size(); }
+    for (int c = 0; c < nChunks && ok; ++c) ok = fwrite(chunks[c].data(), 1, chunks[c].size(), f) == chunks[c].size();
+    fclose(f);
+    if (!ok) *err = "Error writing \"" + filename + "\"";
+    return ok;
+}
+
 bool ReadImage(const std::string &filename, int *xres, int *yres, std::vector<RGB> *texels, std::string *err) {
     const size_t dot = filename.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : filename.substr(dot);

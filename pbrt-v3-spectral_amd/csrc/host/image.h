@@ -24,6 +24,10 @@ enum class ImageWrap { Repeat = 0, Black = 1, Clamp = 2 };  // mipmap.h:50
 // top row first. EXR is not read by this build. On failure returns false with *err set.
 bool ReadImage(const std::string &filename, int *xres, int *yres, std::vector<RGB> *texels, std::string *err);
 
+// WriteImageEXR (imageio.cpp:163-189): RGB as HALF channels B, G, R of a scan-line OpenEXR file (ZIP compression; the
+// reference's RgbaOutputFile defaults to PIZ, any reader takes either).
+bool WriteEXR(const std::string &filename, int w, int h, const float *rgb, std::string *err);
+
 // MIPMap<RGBSpectrum>: power-of-two Lanczos resampling + box-filtered pyramid (mipmap.h:118-211).
 struct MIPMap {
     struct Level { int w, h; std::vector<RGB> t; };

@@ -349,8 +349,21 @@ def test_rgb_film_output_pfm_and_tga(pt, tmp_path):
     pt.write_rgb(str(tmp_path / "a.tga"), film, weight)
     tga = open(tmp_path / "a.tga", "rb").read()
     assert tga[2] == 2 and tga[12] == 7 and tga[14] == 5 and tga[16] == 24 and len(tga) == 18 + 3 * 35
-    pt.write_rgb(str(tmp_path / "b.exr"), film, weight)       # EXR is not linked: a .pfm beside it
-    assert (tmp_path / "b.pfm").exists()
+    # .exr (the film's default name is pbrt.exr): HALF B, G, R, ZIP; read back through the image reader it is the PFM
+    # image rounded to half
+    rng2 = np.random.default_rng(5)
+    film2 = (rng2.random((32, 16, 31)) * 3).astype(np.float32)
+    w2 = np.ones((32, 16), np.float32)
+    pt.write_rgb(str(tmp_path / "b.exr"), film2, w2)
+    pt.write_rgb(str(tmp_path / "b.pfm"), film2, w2)
+    ref = np.frombuffer(open(tmp_path / "b.pfm", "rb").read().split(b"\n", 3)[3], "<f4").reshape(32, 16, 3)   # bottom-up
+    sc = pt.Scene(text='Camera "perspective"\nWorldBegin\nTexture "b" "spectrum" "imagemap" "string filename" "b.exr"\n'
+                  'Material "matte" "texture Kd" "b"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n',
+                  base_dir=str(tmp_path))
+    assert sc.errors == []
+    assert np.array_equal(_mip_level(sc.desc.mipmaps[0], 0), ref.astype(np.float16).astype(np.float32))
+    pt.write_rgb(str(tmp_path / "c.png"), film, weight)       # PNG output is not written: a .pfm beside it
+    assert (tmp_path / "c.pfm").exists()
 
 
 def test_infinite_light_environment_map(pt, tmp_path):
