@@ -275,33 +275,42 @@ bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB>
     struct Channel { std::string name; int type; };
     std::vector<Channel> channels;
     int compression = -1, lineOrder = 0, dw[4] = {0, 0, -1, -1};
+    // a NUL-terminated string inside [p, end)
+    auto str = [&](size_t &p, size_t end, std::string *out) {
+        size_t e = p;
+        while (e < end && f[e] != 0) ++e;
+        if (e >= end) return false;
+        out->assign((const char *)&f[p], e - p);
+        p = e + 1;
+        return true;
+    };
     while (pos < f.size() && f[pos] != 0) {
-        std::string name((const char *)&f[pos]); pos += name.size() + 1;
-        if (pos >= f.size()) return fail("truncated header");
-        std::string type((const char *)&f[pos]); pos += type.size() + 1;
-        if (pos + 4 > f.size()) return fail("truncated header");
+        std::string name, type;
+        if (!str(pos, f.size(), &name) || !str(pos, f.size(), &type) || pos + 4 > f.size()) return fail("truncated header");
         const int size = i32(pos); pos += 4;
         if (size < 0 || pos + (size_t)size > f.size()) return fail("truncated header");
+        const size_t end = pos + (size_t)size;
         if (name == "channels") {
             size_t p = pos;
-            while (p < pos + size && f[p] != 0) {
+            while (p < end && f[p] != 0) {
                 Channel c;
-                c.name = (const char *)&f[p]; p += c.name.size() + 1;
+                if (!str(p, end, &c.name) || p + 16 > end) return fail("bad channel list");
                 c.type = i32(p);
                 const int xs = i32(p + 8), ys = i32(p + 12);
                 p += 16;
                 if (xs != 1 || ys != 1) return fail("subsampled channels are not read by this build");
                 channels.push_back(c);
             }
-        } else if (name == "compression") compression = f[pos];
-        else if (name == "dataWindow") for (int k = 0; k < 4; ++k) dw[k] = i32(pos + 4 * k);
-        else if (name == "lineOrder") lineOrder = f[pos];
-        pos += size;
+        } else if (name == "compression" && size >= 1) compression = f[pos];
+        else if (name == "dataWindow" && size >= 16) for (int k = 0; k < 4; ++k) dw[k] = i32(pos + 4 * k);
+        else if (name == "lineOrder" && size >= 1) lineOrder = f[pos];
+        pos = end;
     }
     ++pos;   // end of header
     (void)lineOrder;   // every chunk carries its y
-    const int w = dw[2] - dw[0] + 1, h = dw[3] - dw[1] + 1;
-    if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || channels.empty()) return fail("bad header");
+    const long long wl = (long long)dw[2] - dw[0] + 1, hl = (long long)dw[3] - dw[1] + 1;
+    if (wl <= 0 || hl <= 0 || wl > 65536 || hl > 65536 || channels.empty() || channels.size() > 64) return fail("bad header");
+    const int w = (int)wl, h = (int)hl;
     int linesPerBlock;
     switch (compression) { case 0: case 1: case 2: linesPerBlock = 1; break; case 3: linesPerBlock = 16; break;
                            default: return fail("compression method " + std::to_string(compression) + " (PIZ, PXR24, B44, DWA) is not read by this build"); }
@@ -325,15 +334,17 @@ bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB>
     for (int chunk = 0; chunk < nChunks; ++chunk) {
         uint64_t off;
         memcpy(&off, &f[pos + (size_t)chunk * 8], 8);
-        if (off + 8 > f.size()) return fail("truncated chunk");
+        if (off > f.size() || off + 8 > f.size()) return fail("truncated chunk");
         const int y = i32(off), dataSize = i32(off + 4);
         if (dataSize < 0 || off + 8 + (size_t)dataSize > f.size()) return fail("truncated chunk");
-        const int y0 = y - dw[1], nLines = std::min(linesPerBlock, h - y0);
-        if (y0 < 0 || y0 >= h) return fail("chunk outside the data window");
+        const long long y0l = (long long)y - dw[1];
+        if (y0l < 0 || y0l >= h) return fail("chunk outside the data window");
+        const int y0 = (int)y0l, nLines = std::min(linesPerBlock, h - y0);
         const size_t rawSize = lineBytes * nLines;
         raw.resize(rawSize);
         const unsigned char *data = &f[off + 8];
-        if (compression == 0 || (size_t)dataSize == rawSize) memcpy(raw.data(), data, std::min(rawSize, (size_t)dataSize));
+        if (compression == 0 && (size_t)dataSize != rawSize) return fail("truncated chunk");
+        if (compression == 0 || (size_t)dataSize == rawSize) memcpy(raw.data(), data, rawSize);
         else {
             tmp.resize(rawSize);
             if (compression == 1) {   // run-length
