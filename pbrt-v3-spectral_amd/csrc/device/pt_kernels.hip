@@ -1630,8 +1630,16 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     }
     for (uint32_t i = 0; i < d->n_tris * 3; ++i)
         if (d->tri_indices[i] < 0 || (uint32_t)d->tri_indices[i] >= d->n_verts) { g_err = "triangle vertex index out of range"; return MI_ERR_INVALID; }
-    for (uint32_t i = 0; i < d->n_materials; ++i)
+    for (uint32_t i = 0; i < d->n_tris; ++i)
+        if (d->tri_mesh[i] >= d->n_meshes) { g_err = "triangle mesh index out of range"; return MI_ERR_INVALID; }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
         if (d->materials[i].n_bxdfs < 0 || d->materials[i].n_bxdfs > MI_MAX_BXDFS) { g_err = "material lobe count out of range"; return MI_ERR_INVALID; }
+        if (d->materials[i].bump_tex >= (int)d->n_textures) { g_err = "mi_material.bump_tex out of range"; return MI_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        const mi_light &l = d->lights[i];
+        if (l.type == MI_LIGHT_DIFFUSE_AREA && (l.shape >= 0 ? (uint32_t)l.shape >= d->n_tris : (uint32_t)(~l.shape) >= d->n_spheres)) { g_err = "area light shape index out of range"; return MI_ERR_INVALID; }
+    }
     if (d->integrator.n_ca_bands < 1 || d->integrator.n_ca_bands > MI_NSPEC) { g_err = "n_ca_bands must be in [1, 31]"; return MI_ERR_INVALID; }
     if (d->sampler.n_dims < 6 + 8 * d->integrator.max_depth * d->integrator.n_ca_bands) {
         g_err = "Halton tables cover too few dimensions for max_depth x n_ca_bands (the reference's prime table ends at 1000)";
