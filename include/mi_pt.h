@@ -178,7 +178,13 @@ typedef struct mi_texture {   /* spectrum textures: RGB pyramid; float textures:
     float su, sv, du, dv;   /* UVMapping2D */
     float post_scale;       /* float textures: the looked-up value is multiplied by this (1 for a plain image texture; the
                              * constant operand of a Texture "scale" over an image texture, scale.h:56-58) */
+    int32_t type;           /* mi_tex_type */
+    int32_t aa_none;        /* checkerboard: "aamode" "none" (point sampled) instead of the closed-form box filter */
+    float spec1[MI_NSPEC], spec2[MI_NSPEC]; /* checkerboard: "tex1" / "tex2" (constant spectra) */
 } mi_texture;
+/* MI_TEX_CHECKERBOARD: Checkerboard2DTexture<Spectrum> over UVMapping2D (src/textures/checkerboard.h:47-86): the value is
+ * (1 - a) * spec1 + a * spec2 with a = 0 / 1 inside a check and the box-filtered area fraction across an edge. */
+typedef enum mi_tex_type { MI_TEX_IMAGEMAP = 0, MI_TEX_CHECKERBOARD = 1 } mi_tex_type;
 
 /* ---- lights */
 typedef enum mi_light_type {

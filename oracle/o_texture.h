@@ -241,10 +241,33 @@ inline void Bump(const mi_scene_desc &d, int tex, SurfaceInteraction *si, const 
 }
 
 // Texture<Spectrum>::Evaluate(si).Clamp() for image texture `tex`
+// Checkerboard2DTexture<Spectrum>::Evaluate over constant tex1 / tex2, checkerboard.h:47-86: the weight of tex2
+inline Float CheckerboardArea2(const Float st[2], const Float dstdx[2], const Float dstdy[2], bool aaNone) {
+    const Float point = (((int)std::floor(st[0]) + (int)std::floor(st[1])) % 2 == 0) ? 0.f : 1.f;
+    if (aaNone) return point;
+    Float ds = std::max(std::abs(dstdx[0]), std::abs(dstdy[0]));
+    Float dt = std::max(std::abs(dstdx[1]), std::abs(dstdy[1]));
+    Float s0 = st[0] - ds, s1 = st[0] + ds;
+    Float t0 = st[1] - dt, t1 = st[1] + dt;
+    if (std::floor(s0) == std::floor(s1) && std::floor(t0) == std::floor(t1)) return point;
+    auto bumpInt = [](Float x) { return (int)std::floor(x / 2) + 2 * std::max(x / 2 - (int)std::floor(x / 2) - (Float)0.5, (Float)0); };
+    Float sint = (bumpInt(s1) - bumpInt(s0)) / (2 * ds);
+    Float tint = (bumpInt(t1) - bumpInt(t0)) / (2 * dt);
+    Float area2 = sint + tint - 2 * sint * tint;
+    if (ds > 1 || dt > 1) area2 = .5f;
+    return area2;
+}
+
 inline Spec EvalImageTexture(const mi_scene_desc &d, int tex, const SurfaceInteraction &si, const TexDifferentials &td) {
     const mi_texture &t = d.textures[tex];
     const Float dstdx[2] = {t.su * td.dudx, t.sv * td.dvdx}, dstdy[2] = {t.su * td.dudy, t.sv * td.dvdy};
     const Float st[2] = {t.su * si.uv[0] + t.du, t.sv * si.uv[1] + t.dv};
+    if (t.type == MI_TEX_CHECKERBOARD) {
+        const Float area2 = CheckerboardArea2(st, dstdx, dstdy, t.aa_none != 0);
+        Spec s = (1 - area2) * Spec::From(t.spec1) + area2 * Spec::From(t.spec2);
+        for (int i = 0; i < NS; ++i) s.c[i] = Clamp(s.c[i], 0, Infinity);
+        return s;
+    }
     MipView mip{d.mipmaps[t.mipmap]};
     const RGB3 mem = mip.Lookup(st, dstdx, dstdy, t.filter, t.max_aniso);
     Spec s = SpecFromRGBIllum(d, mem.c);

@@ -1049,6 +1049,8 @@ void oracle_distribution1d(const float *func, int n, float u, int mode, float *o
 // ImageTexture::Evaluate makes of it (imagemap.h:82-93): out[0..2] = RGB, out[3..33] = Spectrum::FromRGB(rgb).
 void oracle_texture_lookup(const mi_scene_desc *desc, int tex, const float *st2, const float *d4, float *out34) {
     const mi_texture &t = desc->textures[tex];
+    for (int i = 0; i < 34; ++i) out34[i] = 0;
+    if (t.type != MI_TEX_IMAGEMAP) return;
     MipView mip{desc->mipmaps[t.mipmap]};
     const Float st[2] = {st2[0], st2[1]}, dx[2] = {d4[0], d4[1]}, dy[2] = {d4[2], d4[3]};
     const RGB3 v = mip.Lookup(st, dx, dy, t.filter, t.max_aniso);

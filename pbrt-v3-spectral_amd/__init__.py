@@ -68,7 +68,8 @@ class MipMap(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("mipmap", C.c_int32), ("filter", C.c_int32), ("max_aniso", C.c_float),
-                ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float), ("post_scale", C.c_float)]
+                ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float), ("post_scale", C.c_float),
+                ("type", C.c_int32), ("aa_none", C.c_int32), ("spec1", C.c_float * NSPEC), ("spec2", C.c_float * NSPEC)]
 
 
 class Light(C.Structure):

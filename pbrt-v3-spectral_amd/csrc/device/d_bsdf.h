@@ -228,9 +228,14 @@ struct LobeTexT {
     unsigned hasR, hasS, mulR, mulS;
     IllumRGB r[NL], s[NL];
     const float *basis;     // rgbIllum2Spect{White..Blue}, [7][31]: FromRGB's default type is Illuminant (spectrum.h:428-429)
+    const mi_texture *textures;   // for checkerboard values (i1 < 0: i2 = texture, w0 = weight of its spec2)
 };
 // Bin of Spectrum::FromRGB(rgb).Clamp(): Clamp((((0 + white*w0) + basis[i1]*w1) + basis[i2]*w2) * .86445f, 0, inf)
-DEV float TexBin(const float *basis, const IllumRGB &q, int bin) {
+DEV float TexBin(const float *basis, const mi_texture *textures, const IllumRGB &q, int bin) {
+    if (q.i1 < 0) {   // Checkerboard2DTexture: (1 - area2) * tex1 + area2 * tex2, then the material's Clamp()
+        const mi_texture &t = textures[q.i2];
+        return clampf((1 - q.w0) * t.spec1[bin] + q.w0 * t.spec2[bin], 0.f, kInfinity);
+    }
     float r = 0.f;
     r += basis[bin] * q.w0;
     r += basis[q.i1 * MI_NSPEC + bin] * q.w1;
@@ -243,7 +248,7 @@ template <int NL>
 DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int bin) {
     const float c = which ? b.S[bin] : b.R[bin];
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return c;
-    const float T = TexBin(lt.basis, which ? lt.s[li] : lt.r[li], bin);
+    const float T = TexBin(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], bin);
     return (((which ? lt.mulS : lt.mulR) >> li) & 1u) ? c * T : T;
 }
 

@@ -280,8 +280,28 @@ DEV void Bump(const DScene &s, int tex, float u, float v, const TexDifferentials
 }
 
 // Texture<Spectrum>::Evaluate(si) of image texture `tex` in FromRGB's compact form (see IllumRGB)
+// Checkerboard2DTexture::Evaluate over constant tex1 / tex2 (checkerboard.h:47-86): the weight of tex2
+DEV float CheckerboardArea2(float st0, float st1, float dx0, float dx1, float dy0, float dy1, bool aaNone) {
+    const float point = (((int)floorf(st0) + (int)floorf(st1)) % 2 == 0) ? 0.f : 1.f;
+    if (aaNone) return point;
+    const float ds = maxf(absf(dx0), absf(dy0)), dt = maxf(absf(dx1), absf(dy1));
+    const float s0 = st0 - ds, s1 = st0 + ds, t0 = st1 - dt, t1 = st1 + dt;
+    if (floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1)) return point;
+    auto bumpInt = [](float x) { return (int)floorf(x / 2) + 2 * maxf(x / 2 - (int)floorf(x / 2) - 0.5f, 0.f); };
+    const float sint = (bumpInt(s1) - bumpInt(s0)) / (2 * ds);
+    const float tint = (bumpInt(t1) - bumpInt(t0)) / (2 * dt);
+    float area2 = sint + tint - 2 * sint * tint;
+    if (ds > 1 || dt > 1) area2 = .5f;
+    return area2;
+}
 DEV IllumRGB EvalImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
     const mi_texture &t = s.textures[tex];
+    if (t.type == MI_TEX_CHECKERBOARD) {
+        IllumRGB q;
+        q.i1 = -1; q.i2 = tex; q.w1 = q.w2 = 0.f;
+        q.w0 = CheckerboardArea2(t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy, t.aa_none != 0);
+        return q;
+    }
     const mi_mipmap &m = s.mipmaps[t.mipmap];
     const RGB3 mem = MipLookup(s, m, t.su * u + t.du, t.sv * v + t.dv, t.su * td.dudx, t.sv * td.dvdx, t.su * td.dudy, t.sv * td.dvdy,
                                t.filter, t.max_aniso);

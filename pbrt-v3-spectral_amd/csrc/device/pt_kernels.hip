@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 // Material::ComputeScatteringFunctions with image textures: evaluate them at the hit, keep the lobes
                 // whose tested spectrum is not black (matte.cpp:55-63, plastic.cpp:52-68, uber.cpp:60-100, ...)
                 lt.hasR = lt.hasS = lt.mulR = lt.mulS = 0u;
-                lt.basis = s.rgbIllum;
+                lt.basis = s.rgbIllum; lt.textures = s.textures;
                 ltp = &lt;
                 if (mat->textured && s.prims[prim].shape >= 0) {
                     const float4 hr = pool.R(R_HIT, slot);
@@ -1219,8 +1219,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         for (int b = 0; b < MI_NSPEC; ++b) {
                             rNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 0, b) != 0.f;
                             sNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 1, b) != 0.f;
-                            if (ltx.tex_R >= 0) texNonBlack |= TexBin(lt.basis, lt.r[i], b) != 0.f;
-                            if (ltx.tex_S >= 0) texNonBlack |= TexBin(lt.basis, lt.s[i], b) != 0.f;
+                            if (ltx.tex_R >= 0) texNonBlack |= TexBin(lt.basis, lt.textures, lt.r[i], b) != 0.f;
+                            if (ltx.tex_S >= 0) texNonBlack |= TexBin(lt.basis, lt.textures, lt.s[i], b) != 0.f;
                         }
                         const bool present = ltx.rule == MI_LOBE_IF_R_OR_S ? (rNonBlack || sNonBlack) : (ltx.rule == MI_LOBE_IF_TEX ? texNonBlack : rNonBlack);
                         if (present) mask |= 1u << i;
@@ -1557,6 +1557,7 @@ struct mi_pt {
     double lastSeconds[8] = {0};
     unsigned smallClasses = 1u << MISS_CLASS, largeClasses = 0;  // shading classes with <= 2 lobes / with more
     uint32_t nTextures = 0;
+    std::vector<int> textureTypes;
     bool hasAlphaMasks = false;      // picks the traversal kernels compiled with the alpha-mask test
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
@@ -1883,9 +1884,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             s.mipmaps = nullptr; s.textures = nullptr;
             if (!mips.empty()) UP(mips.data(), mips.size(), s.mipmaps);
             for (uint32_t i = 0; i < d->n_textures; ++i)
-                if ((uint32_t)d->textures[i].mipmap >= d->n_mipmaps) { g_err = "mi_texture.mipmap out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
+                if (d->textures[i].type == MI_TEX_IMAGEMAP && (uint32_t)d->textures[i].mipmap >= d->n_mipmaps) { g_err = "mi_texture.mipmap out of range"; mi_pt_destroy(pt); return MI_ERR_INVALID; }
             if (d->n_textures) UP(d->textures, (size_t)d->n_textures, s.textures);
             pt->nTextures = d->n_textures;
+            for (uint32_t i = 0; i < d->n_textures; ++i) pt->textureTypes.push_back(d->textures[i].type);
             float lut[128];   // MIPMap::weightLut, mipmap.h:199-206
             for (int i = 0; i < 128; ++i) {
                 float alpha = 2;
@@ -2152,6 +2154,7 @@ int mi_pt_last_timings(mi_pt *pt, double *seconds, int n) {
 int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *queries, float *rgb) {
     if (!pt || !queries || !rgb) { g_err = "null argument"; return MI_ERR_INVALID; }
     if (tex < 0 || (uint32_t)tex >= pt->nTextures) { g_err = "texture index out of range"; return MI_ERR_INVALID; }
+    if (pt->textureTypes[tex] != MI_TEX_IMAGEMAP) { g_err = "mi_pt_texture_lookup: not an image texture"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;
     HIPCHK(hipSetDevice(pt->device));
     float *dq = nullptr, *dout = nullptr;

@@ -555,14 +555,36 @@ struct Api {
     void Texture(const std::string &name, const std::string &type, const std::string &texname, const ParamSet &ps) {
         // Every texture on this path evaluates to a constant, so "scale" and "mix" of such textures fold into
         // constants with the reference's arithmetic (src/textures/scale.h:56-58, mix.h:57-61, scale.cpp, mix.cpp).
-        if (texname != "constant" && texname != "scale" && texname != "mix" && texname != "imagemap") {
-            Err("Texture class \"" + texname + "\" is outside the hot-path scope (\"constant\", \"scale\" / \"mix\" of constants, spectrum \"imagemap\")");
+        if (texname != "constant" && texname != "scale" && texname != "mix" && texname != "imagemap" && texname != "checkerboard") {
+            Err("Texture class \"" + texname + "\" is outside the hot-path scope (\"constant\", \"scale\", \"mix\", \"imagemap\", \"checkerboard\")");
             return;
         }
         ParamSet empty;
         TextureParams tp(ps, empty, gs.textures, &scene->errors);
         const bool isFloat = type == "float", isSpec = type == "color" || type == "spectrum";
         if (!isFloat && !isSpec) { Err("Texture type \"" + type + "\" unknown."); return; }
+        if (texname == "checkerboard") {  // CreateCheckerboardSpectrumTexture, checkerboard.cpp:99-150
+            if (isFloat) { Err("Texture \"" + name + "\": float \"checkerboard\" textures are outside the hot-path scope"); return; }
+            if (ps.FindOneInt("dimension", 2) != 2) { Err("Texture \"" + name + "\": 3D \"checkerboard\" textures are outside the hot-path scope"); return; }
+            const std::string mapping = ps.FindOneString("mapping", "uv");
+            if (mapping != "uv") { Err("Texture \"" + name + "\": 2D texture mapping \"" + mapping + "\" is outside the hot-path scope (\"uv\" only)"); return; }
+            const SpectrumParam t1 = tp.GetSpectrumParam("tex1", Spectrum(1.f)), t2 = tp.GetSpectrumParam("tex2", Spectrum(0.f));
+            if (t1.tex >= 0 || t2.tex >= 0) { Err("Texture \"" + name + "\": a \"checkerboard\" of image textures is outside the hot-path scope (constant tex1 / tex2)"); return; }
+            mi_texture t{};
+            t.type = MI_TEX_CHECKERBOARD;
+            t.mipmap = -1;
+            t.su = ps.FindOneFloat("uscale", 1.f); t.sv = ps.FindOneFloat("vscale", 1.f);
+            t.du = ps.FindOneFloat("udelta", 0.f); t.dv = ps.FindOneFloat("vdelta", 0.f);
+            t.post_scale = 1.f; t.max_aniso = 8.f;
+            const std::string aa = ps.FindOneString("aamode", "closedform");
+            if (aa == "none") t.aa_none = 1;
+            else if (aa != "closedform") Warn("Antialiasing mode \"" + aa + "\" not understood by Checkerboard2DTexture; using \"closedform\"");
+            for (int i = 0; i < MI_NSPEC; ++i) { t.spec1[i] = t1.s.c[i]; t.spec2[i] = t2.s.c[i]; }
+            gs.textures.spectrumTex.erase(name);
+            gs.textures.imageTex[name] = (int)scene->textures.size();
+            scene->textures.push_back(t);
+            return;
+        }
         if (texname == "imagemap") {  // CreateImageSpectrumTexture, imagemap.cpp:152-197
             const std::string mapping = ps.FindOneString("mapping", "uv");
             if (mapping != "uv") { Err("Texture \"" + name + "\": 2D texture mapping \"" + mapping + "\" is outside the hot-path scope (\"uv\" only)"); return; }

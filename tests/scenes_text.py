@@ -283,6 +283,8 @@ Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string 
 Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2] "float maxanisotropy" [4]
 Texture "tga_nofilt" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool noFiltering" ["true"] "bool gamma" ["false"]
 Texture "tinted" "spectrum" "scale" "texture tex1" "tri_tga" "rgb tex2" [.9 .6 .4]
+Texture "checks" "spectrum" "checkerboard" "float uscale" [7] "float vscale" [5] "rgb tex1" [.8 .75 .1] "rgb tex2" [0 0 0]
+Texture "checks_pt" "spectrum" "checkerboard" "float uscale" [3] "float vscale" [3] "string aamode" "none" "rgb tex1" [.1 .2 .8] "rgb tex2" [.9 .9 .9]
 # ground: matte, EWA-filtered at a grazing angle
 AttributeBegin
   Material "matte" "texture Kd" "ewa_png"
@@ -308,13 +310,13 @@ AttributeBegin
 AttributeEnd
 # mirror and translucent panels
 AttributeBegin
-  Material "mirror" "texture Kr" "png_black"
+  Material "uber" "texture Kd" "checks_pt" "texture Kr" "png_black" "rgb Ks" [0 0 0]
   Translate 2.2 .8 0
   Rotate -35 0 1 0
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0] "float uv" [0 0 1 0 1 1 0 1]
 AttributeEnd
 AttributeBegin
-  Material "translucent" "texture Kd" "ewa_png" "rgb Ks" [.2 .2 .2] "rgb reflect" [.4 .5 .4] "rgb transmit" [.5 .4 .5]
+  Material "translucent" "texture Kd" "checks" "rgb Ks" [.2 .2 .2] "rgb reflect" [.4 .5 .4] "rgb transmit" [.5 .4 .5]
   Translate 0 2.6 2
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 -.5 0  1.5 -.5 0  1.5 .5 0  -1.5 .5 0] "float uv" [0 0 1 0 1 1 0 1]
 AttributeEnd
@@ -510,9 +512,11 @@ def random_scene(seed, res=32, spp=8):
     out.append('Texture "bump_raw" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [2] "float vscale" [2]')
     out.append('Texture "bump" "float" "scale" "texture tex1" "bump_raw" "float tex2" [%.3f]' % r(.01, .1))
     out.append('Texture "mask" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [%.1f]' % r(1, 3))
+    out.append('Texture "chk" "spectrum" "checkerboard" "float uscale" [%.1f] "float vscale" [%.1f] "rgb tex1" %s "rgb tex2" %s %s'
+               % (r(1, 9), r(1, 9), rgb(), rgb(0, .3), '"string aamode" "none"' if rng.random() < .3 else ""))
 
     def material():
-        k = int(rng.integers(0, 14))
+        k = int(rng.integers(0, 15))
         bump = ' "texture bumpmap" "bump"' if rng.random() < .25 else ""
         if k == 0: return 'Material "matte" "rgb Kd" %s "float sigma" [%.1f]%s' % (rgb(), r(0, 40) if rng.random() < .5 else 0, bump)
         if k == 1: return 'Material "plastic" "rgb Kd" %s "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(), rgb(.05, .5), r(.01, .4), bump)
@@ -528,7 +532,8 @@ def random_scene(seed, res=32, spp=8):
         if k == 10: return 'Material "plastic" "texture Kd" "img_s" "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(.05, .4), r(.02, .3), bump)
         if k == 11: return 'Material "uber" "texture Kd" "img_b" "texture Ks" "img_a" "rgb Kr" %s "float roughness" [%.3f]' % (rgb(0, .2), r(.05, .3))
         if k == 12: return 'Material "substrate" "texture Kd" "img_a" "rgb Ks" %s' % rgb(.05, .4)
-        return 'Material "glass" "texture Kt" "img_b" "rgb Kr" %s' % rgb(.5, 1)
+        if k == 13: return 'Material "glass" "texture Kt" "img_b" "rgb Kr" %s' % rgb(.5, 1)
+        return 'Material "matte" "texture Kd" "chk"%s' % bump
 
     out.append('AttributeBegin\n  %s\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 -8  8 0 -8  8 0 8  -8 0 8] "float uv" [0 0 4 0 4 4 0 4]\nAttributeEnd' % material())
     out.append('AttributeBegin\n  %s\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 5  8 0 5  8 8 5  -8 8 5] "float uv" [0 0 2 0 2 1 0 1]\nAttributeEnd' % material())

@@ -419,8 +419,8 @@ def test_scale_and_mix_textures_of_constants_fold(pt):
     assert np.array_equal(got, want)
     # roughness texture r = (1 - .5) * .5 + .5 * .1 = .3, remapped by RoughnessToAlpha
     assert abs(plastic.bxdf[1].p[0] - plastic.bxdf[1].p[1]) == 0 and abs(plastic.bxdf[1].p[0] - 0.857) < 0.002
-    s2 = pt.Scene(text=txt.replace('"scale"', '"checkerboard"'))
-    assert any("checkerboard" in e for e in s2.errors)
+    s2 = pt.Scene(text=txt.replace('"scale"', '"marble"'))
+    assert any("marble" in e for e in s2.errors)
 
 
 def test_spot_light_is_parsed(pt):
@@ -701,3 +701,23 @@ def test_exr_float_channels_round_to_half_like_numpy(pt, tmp_path):
     with np.errstate(over="ignore"):
         want = img.astype(np.float16).astype(np.float32)[::-1]
     assert np.array_equal(_mip_level(s.desc.mipmaps[0], 0), want)
+
+
+def test_checkerboard_texture_binding(pt):
+    """Texture "checkerboard" (checkerboard.cpp:99-150): 2D, uv mapping, constant tex1 / tex2, "aamode"; binds to a lobe like
+    an image texture; 3D / float / nested-image checkerboards are reported."""
+    head = 'Camera "perspective"\nWorldBegin\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    s = pt.Scene(text=head + 'Texture "c" "spectrum" "checkerboard" "float uscale" [4] "float vdelta" [.5] "rgb tex1" [.2 .4 .6] "string aamode" "none"\n'
+                 'Material "matte" "texture Kd" "c"\n' + tri + "WorldEnd\n")
+    assert s.errors == [] and s.desc.n_textures == 1 and s.desc.n_mipmaps == 0
+    t = s.desc.textures[0]
+    assert (t.type, t.aa_none, t.su, t.sv, t.dv, t.mipmap) == (1, 1, 4.0, 1.0, 0.5, -1)
+    assert list(t.spec2) == [0.0] * 31 and 0.15 < t.spec1[0] < 0.7        # tex2 defaults to 0, tex1 from the rgb
+    m = s.desc.materials[s.desc.n_materials - 1]
+    assert m.textured == 1 and m.tex[0].tex_R == 0
+    for body, needle in [('Texture "c" "float" "checkerboard"\n', "float \"checkerboard\""),
+                         ('Texture "c" "spectrum" "checkerboard" "integer dimension" [3]\n', "3D"),
+                         ('Texture "c" "spectrum" "checkerboard" "string mapping" "planar"\n', "mapping")]:
+        s = pt.Scene(text=head + body + "WorldEnd\n")
+        assert any(needle in e for e in s.errors), (needle, s.errors)

@@ -426,6 +426,8 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
     rng = np.random.default_rng(11)
     n = 3000
     for tex in range(s.desc.n_textures):
+        if s.desc.textures[tex].type != 0:   # checkerboards have no pyramid
+            continue
         q = np.zeros((n, 6), np.float32)
         q[:, 0:2] = rng.uniform(-0.7, 1.8, (n, 2))
         scale = 10.0 ** rng.uniform(-4, -0.3, (n, 1))
