@@ -1050,6 +1050,14 @@ void oracle_distribution1d(const float *func, int n, float u, int mode, float *o
 void oracle_texture_lookup(const mi_scene_desc *desc, int tex, const float *st2, const float *d4, float *out34) {
     const mi_texture &t = desc->textures[tex];
     for (int i = 0; i < 34; ++i) out34[i] = 0;
+    if (t.type == MI_TEX_CHECKERBOARD) {   // out[0] = weight of tex2, out[3..33] = the spectrum
+        const Float st[2] = {st2[0], st2[1]}, dx[2] = {d4[0], d4[1]}, dy[2] = {d4[2], d4[3]};
+        const Float area2 = CheckerboardArea2(st, dx, dy, t.aa_none != 0);
+        out34[0] = area2;
+        const Spec sp = (1 - area2) * Spec::From(t.spec1) + area2 * Spec::From(t.spec2);
+        for (int i = 0; i < NS; ++i) out34[3 + i] = sp.c[i];
+        return;
+    }
     if (t.type != MI_TEX_IMAGEMAP) return;
     MipView mip{desc->mipmaps[t.mipmap]};
     const Float st[2] = {st2[0], st2[1]}, dx[2] = {d4[0], d4[1]}, dy[2] = {d4[2], d4[3]};

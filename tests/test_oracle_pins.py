@@ -373,3 +373,31 @@ def test_textured_render_equals_the_constant_it_encodes(pt, ob, tmp_path):
     fb, wb, cb, _ = ob.render(b, n_threads=4)
     assert np.array_equal(wa, wb) and ca.as_dict() == cb.as_dict()
     assert np.allclose(fa, fb, rtol=2e-6, atol=0)
+
+
+def test_checkerboard_known_answers(pt, ob):
+    """Checkerboard2DTexture::Evaluate (checkerboard.h:47-86) against values that follow from its definition: inside a check
+    the value is exactly tex1 or tex2 (parity of floor(s) + floor(t)); a footprint wider than a check gives the half-half
+    mix; a footprint centred on an edge in s covers both colours equally; the closed form is the area of the box filter
+    over the odd checks; "aamode" "none" never mixes."""
+    head = 'Camera "perspective"\nWorldBegin\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    s = pt.Scene(text=head + 'Texture "c" "spectrum" "checkerboard" "spectrum tex1" [400 2 700 2] "spectrum tex2" [400 6 700 6]\nMaterial "matte" "texture Kd" "c"\n' + tri +
+                 'Texture "n" "spectrum" "checkerboard" "string aamode" "none" "spectrum tex1" [400 2 700 2] "spectrum tex2" [400 6 700 6]\nMaterial "matte" "texture Kd" "n"\n' + tri +
+                 "WorldEnd\n")
+    assert s.errors == []
+    look = lambda tex, st, dx=(0, 0), dy=(0, 0): ob.texture_lookup(s, tex, st, dx, dy)
+    for (st, want) in [((0.5, 0.5), 2.0), ((1.5, 0.5), 6.0), ((1.5, 1.5), 2.0), ((-0.5, 0.5), 6.0), ((2.25, 3.75), 6.0)]:
+        a, spec = look(0, st)
+        assert np.all(spec == np.float32(want)) and a[0] in (0.0, 1.0)
+        a, spec = look(0, st, (0.1, 0.05), (0.02, 0.1))          # a small footprint inside the check changes nothing
+        assert np.all(spec == np.float32(want))
+    a, spec = look(0, (0.3, 0.3), (1.5, 0), (0, 0.2))            # ds > 1: half and half
+    assert a[0] == 0.5 and np.allclose(spec, 4.0)
+    a, spec = look(0, (1.0, 0.5), (0.25, 0), (0, 0.25))          # centred on the edge s = 1, inside t in (0.25, 0.75)
+    assert abs(a[0] - 0.5) < 1e-6 and np.allclose(spec, 4.0, rtol=1e-6)
+    # box filter [0.9, 1.3] x [0.4, 0.6]: a quarter of it lies in the check s < 1 (tex1), three quarters in s > 1 (tex2)
+    a, spec = look(0, (1.1, 0.5), (0.2, 0), (0, 0.1))
+    assert abs(a[0] - 0.75) < 1e-5 and np.allclose(spec, 2 * 0.25 + 6 * 0.75, rtol=1e-5)
+    a, spec = look(1, (1.0001, 0.5), (0.25, 0), (0, 0.25))       # "none": point sampled whatever the footprint
+    assert a[0] == 1.0 and np.all(spec == np.float32(6.0))
