@@ -482,6 +482,7 @@ inline bool SphereIntersect(const mi_sphere &s, const Ray &r, Float *tHit, Surfa
     isect->shading.dpdu = XfVector(m, o.shading.dpdu); isect->shading.dpdv = XfVector(m, o.shading.dpdv);
     isect->shading.dndu = XfNormal(mi, o.shading.dndu); isect->shading.dndv = XfNormal(mi, o.shading.dndv);
     isect->shading.n = Faceforward(isect->shading.n, isect->n);
+    isect->flip = flip;
     *tHit = t;
     return true;
 }

@@ -627,7 +627,7 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
         const mi_material &mat = d.materials[matIdx];
         TexDifferentials td;
         if (mat.textured) td = ComputeDifferentials(isect, diff);   // isect.ComputeScatteringFunctions(ray, ...), interaction.cpp:91-97
-        if (mat.bump_tex >= 0 && d.prims[isect.prim].shape >= 0) Bump(d, mat.bump_tex, &isect, td);
+        if (mat.bump_tex >= 0) Bump(d, mat.bump_tex, &isect, td);
         BSDF bsdf(isect, mat, &d, &td);
         const Distribution1D *distrib = lightDistrib.Lookup(isect.p);
         if (bsdf.NumComponents(MI_BSDF_ALL & ~MI_BSDF_SPECULAR) > 0) {

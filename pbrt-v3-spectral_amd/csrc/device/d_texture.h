@@ -255,6 +255,37 @@ DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool 
     return true;
 }
 
+// The same for a sphere hit (sphere.cpp:113-160): (u, v) = (phi / phiMax, (theta - thetaMin) / (thetaMax - thetaMin)), dpdv
+// and the Weingarten dndu / dndv, taken to world space as Transform::operator()(SurfaceInteraction) does.
+DEV bool SphereTexCoords(const mi_sphere &sp, const V3 &ro, const V3 &rd, float *u, float *v, TriShading *ts) {
+    V3 dObj, pHit; float phi, t;
+    if (!SphereRoots(sp, ro, rd, kInfinity, &dObj, &pHit, &phi, &t)) return false;
+    const float radius = sp.radius, phiMax = sp.phi_max, thetaMin = sp.theta_min, thetaMax = sp.theta_max;
+    *u = phi / phiMax;
+    float theta = acosF(clampf(pHit.z / radius, -1, 1));
+    *v = (theta - thetaMin) / (thetaMax - thetaMin);
+    float zRadius = __builtin_sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    float invZRadius = 1 / zRadius;
+    float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+    V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinF(theta));
+    V3 d2Pduu = -phiMax * phiMax * V3(pHit.x, pHit.y, 0);
+    V3 d2Pduv = (thetaMax - thetaMin) * pHit.z * phiMax * V3(-sinPhi, cosPhi, 0.);
+    V3 d2Pdvv = -(thetaMax - thetaMin) * (thetaMax - thetaMin) * V3(pHit.x, pHit.y, pHit.z);
+    float E = Dot(dpdu, dpdu), F = Dot(dpdu, dpdv), G = Dot(dpdv, dpdv);
+    V3 N = Normalize(Cross(dpdu, dpdv));
+    float e = Dot(N, d2Pduu), f = Dot(N, d2Pduv), g = Dot(N, d2Pdvv);
+    float invEGF2 = 1 / (E * G - F * F);
+    V3 dndu = (f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv;
+    V3 dndv = (g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv;
+    ts->dpdv = XfVector(sp.o2w, dpdv);
+    ts->shDpdv = ts->dpdv;
+    ts->dndu = XfNormal(sp.w2o, dndu);
+    ts->dndv = XfNormal(sp.w2o, dndv);
+    ts->flip = (sp.reverse_orientation != 0) ^ (sp.swaps_handedness != 0);
+    return true;
+}
+
 // Texture<Float>::Evaluate(si) of float image texture `tex`
 DEV float EvalFloatImageTexture(const DScene &s, int tex, float u, float v, const TexDifferentials &td) {
     const mi_texture &t = s.textures[tex];

@@ -1185,11 +1185,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 lt.hasR = lt.hasS = lt.mulR = lt.mulS = 0u;
                 lt.basis = s.rgbIllum; lt.textures = s.textures;
                 ltp = &lt;
-                if (mat->textured && s.prims[prim].shape >= 0) {
-                    const float4 hr = pool.R(R_HIT, slot);
-                    float u, v;
-                    TriShading tsh;
-                    TriTexCoords(s, s.prims[prim].shape, hr.y, hr.z, hr.w, isect, &u, &v, &tsh);
+                float u = 0.f, v = 0.f;
+                TriShading tsh;
+                bool haveUV = false;
+                if (mat->textured) {
+                    const int shape = s.prims[prim].shape;
+                    if (shape >= 0) {
+                        const float4 hr = pool.R(R_HIT, slot);
+                        TriTexCoords(s, shape, hr.y, hr.z, hr.w, isect, &u, &v, &tsh);
+                        haveUV = true;
+                    } else
+                        haveUV = SphereTexCoords(s.spheres[~shape], ro, rd, &u, &v, &tsh);
+                }
+                if (haveUV) {
                     TexDifferentials td;
                     td.dudx = td.dvdx = td.dudy = td.dvdy = 0;
                     if (flags & F_DIFF) {   // SurfaceInteraction::ComputeDifferentials, interaction.cpp:99-143

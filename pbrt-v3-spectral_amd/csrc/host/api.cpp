@@ -429,8 +429,6 @@ struct Api {
             material = gs.currentMaterial->material;
         if (sphereIdx >= 0) {
             const mi_sphere &s = scene->spheres[sphereIdx];
-            if (material >= 0 && scene->materials[material].textured)
-                Err("image-textured material on a \"sphere\": this path evaluates image textures on triangle meshes only; the texture is ignored there");
             PendingPrim pp;
             pp.shape = ~sphereIdx;
             pp.material = material;

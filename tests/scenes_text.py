@@ -283,6 +283,8 @@ Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string 
 Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2] "float maxanisotropy" [4]
 Texture "tga_nofilt" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool noFiltering" ["true"] "bool gamma" ["false"]
 Texture "tinted" "spectrum" "scale" "texture tex1" "tri_tga" "rgb tex2" [.9 .6 .4]
+Texture "sphere_bump_raw" "float" "imagemap" "string filename" "tex_b.tga" "float uscale" [3] "float vscale" [2]
+Texture "sphere_bump" "float" "scale" "texture tex1" "sphere_bump_raw" "float tex2" [.05]
 Texture "checks" "spectrum" "checkerboard" "float uscale" [7] "float vscale" [5] "rgb tex1" [.8 .75 .1] "rgb tex2" [0 0 0]
 Texture "checks_pt" "spectrum" "checkerboard" "float uscale" [3] "float vscale" [3] "string aamode" "none" "rgb tex1" [.1 .2 .8] "rgb tex2" [.9 .9 .9]
 # ground: matte, EWA-filtered at a grazing angle
@@ -319,6 +321,19 @@ AttributeBegin
   Material "translucent" "texture Kd" "checks" "rgb Ks" [.2 .2 .2] "rgb reflect" [.4 .5 .4] "rgb transmit" [.5 .4 .5]
   Translate 0 2.6 2
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 -.5 0  1.5 -.5 0  1.5 .5 0  -1.5 .5 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# textured, bump-mapped spheres (uv from the sphere's parametrisation; one partial, one mirrored)
+AttributeBegin
+  Material "plastic" "texture Kd" "ewa_png" "rgb Ks" [.2 .2 .2] "texture bumpmap" "sphere_bump"
+  Translate -3.2 .7 -1.5
+  Rotate 40 0 1 0
+  Shape "sphere" "float radius" [.7] "float zmin" [-.5] "float phimax" [300]
+AttributeEnd
+AttributeBegin
+  Material "matte" "texture Kd" "checks_pt"
+  Translate 3.3 .6 -1.8
+  Scale -1 1 1
+  Shape "sphere" "float radius" [.6]
 AttributeEnd
 # specular glass pane with a textured transmittance
 AttributeBegin
@@ -548,12 +563,7 @@ def random_scene(seed, res=32, spp=8):
             out.append("  ReverseOrientation")
         kind = rng.random()
         if kind < .3:
-            textured = "texture" in out[-3] or "texture" in out[-4] if len(out) > 4 else False
-            mat_line = next(l for l in reversed(out) if l.strip().startswith("Material"))
-            if "texture" in mat_line:
-                out.append("  " + _curved_patch(4, 3))
-            else:
-                out.append('  Shape "sphere" "float radius" [%.2f]' % r(.3, .9))
+            out.append('  Shape "sphere" "float radius" [%.2f]%s' % (r(.3, .9), ' "float phimax" [%.0f]' % r(120, 340) if rng.random() < .3 else ""))
         elif kind < .6:
             out.append("  " + _curved_patch(int(rng.integers(2, 6)), int(rng.integers(2, 5))))
         else:

@@ -507,7 +507,6 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
         'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "plastic" "texture roughness" "f"\n' + tri: "Float image texture",
         'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
         'Material "disney" "texture color" "t"\n' + tri: "Image texture",
-        'Material "matte" "texture Kd" "t"\nShape "sphere"\n': "sphere",
         'Material "glass" "texture Kr" "t" "float uroughness" [.1] "float vroughness" [.1]\n' + tri: "rough",
         'Texture "m" "spectrum" "imagemap" "string filename" "missing.png"\nMaterial "matte" "texture Kd" "m"\n' + tri: "missing.png",
         'Texture "e" "spectrum" "imagemap" "string filename" "a.exr"\nMaterial "matte" "texture Kd" "e"\n' + tri: "exr",
