@@ -743,12 +743,21 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
     if (qi < ctr->misCount.v) {
         const uint32_t slot = pool.misQ[qi];
         int flags = pool.I(I_FLAGS, slot);
-        const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
-        V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+        // the ray and the hit record are fetched only by the few rays that need them: postponed quadrics, or a hit on the
+        // sampled light whose facing has to be tested (most MIS rays hit something else: 48 B of scattered reads saved)
+        V3 ro, rd;
         Hit h;
-        h.prim = pool.I(I_HITPRIM, slot); h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
+        h.prim = pool.I(I_HITPRIM, slot); h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
+        bool haveRay = false;
+        auto loadRay = [&]() {
+            if (haveRay) return;
+            const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
+            ro = V3(r0.x, r0.y, r0.z); rd = V3(r0.w, r1.x, r1.y);
+            if (h.prim >= 0) { h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w; }
+            haveRay = true;
+        };
         bool found = h.prim >= 0;
-        if (pool.I(I_NPEND, slot) != 0) found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris);
+        if (pool.I(I_NPEND, slot) != 0) { loadRay(); found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
         bool added = false;
         if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
             const bool lZero = (flags & F_L_ZERO) != 0;
@@ -768,6 +777,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
                 const mi_light &l = s.lights[lightNum];
                 bool emit = l.two_sided != 0;
                 if (!emit) {
+                    loadRay();
                     SurfaceInteraction li;
                     HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
                     emit = Dot(li.n, -rd) > 0;
