@@ -1127,11 +1127,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         const int prim = pool.I(I_HITPRIM, slot);
         const bool found = prim >= 0;
         auto loadBeta = [&](int c) -> float4 { return LoadBeta(pool, c, slot, betaOne); };
-        const float4 ray0 = pool.R(R_RAY0, slot), ray1 = pool.R(R_RAY1, slot);
+        // the ray and the interaction are needed by vertices that will be shaded or may show emitted light; an escaped
+        // ray without environment lights and a path at its last vertex need neither (a third of the queue entries)
+        const bool emitCheck = bounces == 0 || (flags & F_SPECULAR);
+        const bool needIsect = found && (bounces < s.maxDepth || emitCheck);
+        const bool needRay = needIsect || (!found && emitCheck && TM_LIGHT(TM, MI_LIGHT_INFINITE) && s.nInfiniteLights > 0);
+        float4 ray0 = make_float4(0.f, 0.f, 0.f, 0.f), ray1 = make_float4(0.f, 0.f, 1.f, 1.f);
+        if (needRay) { ray0 = pool.R(R_RAY0, slot); ray1 = pool.R(R_RAY1, slot); }
         V3 ro(ray0.x, ray0.y, ray0.z), rd(ray1.x, ray1.y, ray1.z);
         SurfaceInteraction isect;
         bool finished = false, passThrough = false;
-        if (found) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, ro, rd, hr.y, hr.z, hr.w, &isect); }
+        if (needIsect) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, ro, rd, hr.y, hr.z, hr.w, &isect); }
         // emitted light at the vertex, path.cpp:91-101
         if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
             const int li = s.prims[prim].area_light;
