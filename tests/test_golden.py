@@ -74,3 +74,30 @@ def test_gpu_film_matches_the_golden_films(pt, name, scene, tol):
     mean = gold.mean() / spp
     assert per_pixel.mean() < tol * mean
     assert (per_pixel > 1e-3 * mean).mean() < 50 * tol                      # pixels over the per-pixel target
+
+
+def _textured_scene(pt, tmp_path, z):
+    import scenes_text as st
+    st.write_texture_files(str(tmp_path))
+    st.write_alpha_png(str(tmp_path))
+    s = pt.Scene(text=st.textured_zoo(res=int(z["res"]), spp=int(z["spp"])), base_dir=str(tmp_path))
+    assert s.errors == []
+    return s
+
+
+def test_oracle_reproduces_the_textured_golden(pt, ob, tmp_path):
+    z, counters = _load("textured_zoo_64spp.npz")
+    film, weight, c, _ = ob.render(_textured_scene(pt, tmp_path, z))
+    assert np.array_equal(film, z["film"]) and np.array_equal(weight, z["weight"]) and c.as_dict() == counters
+
+
+@pytest.mark.gpu
+def test_gpu_film_matches_the_textured_golden(pt, tmp_path):
+    z, counters = _load("textured_zoo_64spp.npz")
+    integ = pt.CreatePathIntegrator(_textured_scene(pt, tmp_path, z))
+    film, weight = integ.Render()
+    c = integ.counters.as_dict()
+    assert c["camera_rays"] == counters["camera_rays"] and np.array_equal(weight, z["weight"])
+    for k in ("regular_rays", "shadow_rays", "total_paths", "zero_radiance_paths", "path_length_sum"):
+        assert abs(c[k] - counters[k]) <= 1e-4 * counters[k] + 3, k
+    assert _rel_l2(film, z["film"]) < 1e-4

@@ -10,6 +10,8 @@ they pin the oracle itself against regressions.
   cornell_256spp_crop.npz     same for scenes/cornell-glass.pbrt (maxdepth 8) at 256 spp on a 32x32 crop over
                               the glass sphere's caustic
   killeroo_rays.npz           4096 camera + 4096 random rays with closest-hit (prim, t, b0, b1) and any-hit results
+  textured_zoo_64spp.npz      the image-textured material zoo of tests/scenes_text.py (64x64, 64 spp): image textures of
+                              three file formats, checkerboards, bump maps, textured spheres
 
 Usage: python tools/make_golden.py   (a few minutes on 8 cores)
 """
@@ -58,8 +60,28 @@ def ray_fixture(path):
                                                         (closest.view(np.int32)[:, 0] >= 0).sum(), (anyhit.view(np.int32)[:, 0] >= 0).sum()))
 
 
+def text_scene_fixture(path, which, res, spp):
+    """A fixture of one of the authored test scenes that need generated image files (tests/scenes_text.py)."""
+    import tempfile
+    import scenes_text as st
+    d = tempfile.mkdtemp()
+    st.write_texture_files(d)
+    st.write_alpha_png(d)
+    text = {"textured_zoo": st.textured_zoo, "bump_scene": st.bump_scene, "alpha_scene": st.alpha_scene}[which](res=res, spp=spp)
+    s = pt.Scene(text=text, base_dir=d)
+    assert s.errors == [], s.errors
+    film, weight, c, secs = ob.render(s)
+    dd = c.as_dict()
+    np.savez_compressed(path, film=film, weight=weight, spp=spp, res=res, scene=which,
+                        counters=np.array([dd[k] for k in sorted(dd)], np.int64), counter_names=np.array(sorted(dd)))
+    print("%s: film %s mean/spp %.6f, %.1f s" % (os.path.basename(path), film.shape, film.mean() / spp, secs))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    text_scene_fixture(os.path.join(OUT, "textured_zoo_64spp.npz"), "textured_zoo", 64, 64)
+    if "--textured-only" in sys.argv:
+        sys.exit(0)
     ray_fixture(os.path.join(OUT, "killeroo_rays.npz"))
     film_fixture(os.path.join(OUT, "cornell_256spp_crop.npz"), CORNELL, 256, CORNELL_CROP)
     film_fixture(os.path.join(OUT, "killeroo_1024spp_crop.npz"), KILLEROO, 1024, KILLEROO_CROP)
