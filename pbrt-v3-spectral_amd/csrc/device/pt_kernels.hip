@@ -1586,6 +1586,7 @@ struct mi_pt {
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
+    unsigned mediumClasses = 0, texturedMedium = 0;              // 3- and 4-lobe classes (uber with Kr / Kt, translucent): 4-lobe instances
     unsigned texturedSmall = 0, texturedLarge = 0;               // classes of image-textured materials (taken out of small / largeClasses)              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
 };
@@ -1729,6 +1730,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     std::vector<int> matClass(d->n_materials, 0);
     {
         std::vector<std::vector<int>> signatures;
+        int classLobes[MAX_CLASSES] = {0};       // per class: the longest lobe list
         unsigned classTypes[MAX_CLASSES] = {0};  // per class: lobe types (bits 0..15) and fresnel kinds (bits 16..) present
         for (uint32_t i = 0; i < d->n_materials; ++i) {
             const mi_material &m = d->materials[i];
@@ -1740,6 +1742,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             if (c == signatures.size()) signatures.push_back(sig);
             matClass[i] = (int)std::min<size_t>(c, MISS_CLASS - 1);
             ((m.n_bxdfs > 2 || c >= (size_t)MISS_CLASS - 1) ? pt->largeClasses : pt->smallClasses) |= 1u << matClass[i];
+            classLobes[matClass[i]] = std::max(classLobes[matClass[i]], (c >= (size_t)MISS_CLASS - 1) ? MI_MAX_BXDFS : (int)m.n_bxdfs);
             for (int j = 0; j < m.n_bxdfs; ++j) {
                 classTypes[matClass[i]] |= (1u << m.bxdf[j].type) | (1u << (16 + m.bxdf[j].fresnel));
                 if (m.bxdf[j].scaled) classTypes[matClass[i]] |= TM_SCALED;
@@ -1768,6 +1771,12 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 if ((pt->smallClasses >> c) & 1u) { pt->texturedSmall |= 1u << c; pt->smallClasses &= ~(1u << c); }
                 if ((pt->largeClasses >> c) & 1u) { pt->texturedLarge |= 1u << c; pt->largeClasses &= ~(1u << c); }
             }
+        if (!getenv("MIPT_NO_SPECIALISE"))
+            for (int c = 0; c < MISS_CLASS; ++c)
+                if (classLobes[c] <= 4) {
+                    if ((pt->largeClasses >> c) & 1u) { pt->mediumClasses |= 1u << c; pt->largeClasses &= ~(1u << c); }
+                    if ((pt->texturedLarge >> c) & 1u) { pt->texturedMedium |= 1u << c; pt->texturedLarge &= ~(1u << c); }
+                }
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
     {
@@ -2073,6 +2082,8 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
             if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
         }
         if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+        if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
+        if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
         if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
         if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
         if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
