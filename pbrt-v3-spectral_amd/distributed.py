@@ -48,13 +48,22 @@ def reduce_film(film, weight=None, dst=0):
     dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     if weight is not None:
         dist.reduce(weight, dst=dst, op=dist.ReduceOp.SUM)
+    if film.is_cuda:
+        # RCCL runs on torch's communication stream and the renderer on its own HIP streams: wait on the
+        # host until the reduce has read the film, so the next frame cannot overwrite it underneath.
+        import torch
+        torch.cuda.current_stream(film.device).synchronize()
     return film, weight
 
 
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            import torch
+            dist.barrier(device_ids=[torch.cuda.current_device()])  # the rank's own GPU, not a guess from the rank number
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value):
