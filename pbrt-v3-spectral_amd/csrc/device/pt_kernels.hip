@@ -122,7 +122,8 @@ struct Pool {
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
-    // a slot's 8 quads of one spectrum are one 128-B line: [spectrum][slot][quad]
+    // a slot's 8 quads of one spectrum are one 128-B line: [spectrum][slot][quad] ([slot][spectrum][quad], the
+    // spectra of a slot in one page, measured the same)
     DEV float4 &Q(int plane, uint32_t slot) const { return q[(((size_t)(plane >> 3) * n + slot) << 3) + (plane & 7)]; }
     DEV float4 &R(int plane, uint32_t slot) const { return r[(size_t)plane * n + slot]; }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
@@ -2025,13 +2026,18 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
-    // Default pool: a quarter of the samples to render, between 4M and 32M slots in total (22 GB of path
-    // state at 32M): bigger pools mean fewer, better-filled launches, but the last iterations of a render
-    // drain the pool at low occupancy, which a small job (one shard of a multi-GPU frame) feels.
+    // Default pool: a quarter of the samples to render, at most 32M slots in total (22 GB of path state)
+    // and at least 4M (8M per sub-renderer when several share the GPU): bigger pools mean fewer, better-filled
+    // launches, but the last iterations of a render drain the pool at low occupancy, which a small job (one
+    // shard of a multi-GPU frame) feels. Measured on the 1024-spp killeroo frame and its shards
+    // (tools/shard_tune.py): a 1/8 shard on four sub-renderers takes 0.149 s with 16M slots and 0.143 s with
+    // 32M; 64M slots (47 GB) make the traversal launches 3 % faster and k_shade / k_generate 4-6 % slower
+    // (the path state outgrows the TLB reach), no gain for the full frame.
     uint32_t poolN = rp->path_pool;
     if (poolN == 0) {
         const unsigned long long quarter = wd.totalWork * (unsigned long long)subCount / 4;
-        poolN = (uint32_t)std::min<unsigned long long>(1ull << 25, std::max<unsigned long long>(1ull << 22, quarter));
+        const unsigned long long floorN = subCount > 1 ? (8ull << 20) * (unsigned long long)subCount : (1ull << 22);
+        poolN = (uint32_t)std::min<unsigned long long>(1ull << 25, std::max<unsigned long long>(floorN, quarter));
     }
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);

@@ -19,7 +19,12 @@ def run(si, sc):
     t0 = time.perf_counter()
     integ.Render(shard_index=si, shard_count=sc, film_out=film.data_ptr(), weight_out=weight.data_ptr())
     torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if os.environ.get("SHARD_VERBOSE"):
+        tk = integ.timings()
+        print("   shard %d/%d: wall %.4f  render loop %.4f  kernels %.4f (gen %.4f ext %.4f shade %.4f shadow %.4f mis %.4f)  iterations %d"
+              % (si, sc, dt, tk[0], sum(tk[1:6]), tk[1], tk[2], tk[3], tk[4], tk[5], integ.counters.as_dict()["iterations"]))
+    return dt
 
 run(0, 1)
 full = min(run(0, 1) for _ in range(2))
