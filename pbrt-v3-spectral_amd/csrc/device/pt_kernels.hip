@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                         size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
                         float *dst = film + pix * 32 + bin;
                         if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
-                        else if (!zero) atomicAdd(dst, (val * 1.f) * fw);      // contribSum += L * sampleWeight * fw
+                        else if (!zero && val != 0.f) atomicAdd(dst, (val * 1.f) * fw);   // contribSum += L * sampleWeight * fw (x + 0 == x: a black bin is not sent)
                     }
                 }
             }
