@@ -1560,12 +1560,14 @@ __global__ void k_film_split(const float *film32, float *filmSum, float *weightS
 // =============================================================================
 // C ABI
 // =============================================================================
+constexpr int N_EV = 8;   // events per iteration: kernel-class boundaries + the start of the closest-hit traversal launch
 struct SubRenderer {
     Pool pool{};
     DevCounters *ctr = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t evIter[2][7] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
+    hipEvent_t evIter[2][N_EV] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
     double t[7] = {0};
+    int poolQuadPlanes = 0;   // spectral planes the pool was allocated with (spectralpath needs one set more)
     unsigned long long iterations = 0;
     DevCounters result{};
 };
@@ -1575,6 +1577,7 @@ struct mi_pt {
     DScene scene{};
     std::vector<void *> allocs;
     float *film = nullptr;  // [nPix][32]
+    float *stageSum = nullptr, *stageW = nullptr;   // [nPix][31] / [nPix] staging of the host hand-over
     size_t nPix = 0;
     int filmW = 0, filmH = 0;
     long long spp = 0;
@@ -1612,24 +1615,46 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
     return MI_OK;
 }
 
+void FreePool(Pool &p) {
+    hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ);
+    p = Pool{};   // n = 0, every pointer null: a later render cannot mistake a half-built pool for a usable one
+}
+
+// Failure-safe: the new pool is built aside and swapped in only when every allocation succeeded; after a failure the
+// sub-renderer holds no pool at all (n == 0), so the next render allocates afresh instead of launching on stale sizes.
 int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     Pool &p = sub.pool;
-    if (p.n == n && p.f) return MI_OK;
-    if (p.f) {
-        hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ);
-        p.f = nullptr; p.q = nullptr; p.r = nullptr; p.i = nullptr; p.shadowQ = p.misQ = p.extQ = nullptr; p.shadeQ = nullptr;
+    if (p.n == n && p.f && sub.poolQuadPlanes == nQuadPlanes) return MI_OK;
+    FreePool(p);
+    sub.poolQuadPlanes = 0;
+    Pool t{};
+    const bool ok = hipMalloc((void **)&t.f, (size_t)P_COUNT * n * sizeof(float)) == hipSuccess &&
+                    hipMalloc((void **)&t.q, (size_t)nQuadPlanes * n * sizeof(float4)) == hipSuccess &&
+                    hipMalloc((void **)&t.r, (size_t)R_COUNT * n * sizeof(float4)) == hipSuccess &&
+                    hipMalloc((void **)&t.i, (size_t)I_COUNT * n * sizeof(int)) == hipSuccess &&
+                    hipMalloc((void **)&t.shadowQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.extQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.misQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();   // the failed hipMalloc must not poison the next call's hipGetLastError
+        FreePool(t);
+        g_err = "hipMalloc(path pool of " + std::to_string(n) + " slots) failed";
+        return MI_ERR_NOMEM;
     }
-    HIPCHK(hipMalloc((void **)&p.f, (size_t)P_COUNT * n * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&p.q, (size_t)nQuadPlanes * n * sizeof(float4)));
-    HIPCHK(hipMalloc((void **)&p.r, (size_t)R_COUNT * n * sizeof(float4)));
-    HIPCHK(hipMalloc((void **)&p.i, (size_t)I_COUNT * n * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&p.shadowQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&p.extQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&p.misQ, (size_t)n * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&p.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)));
-    p.n = n;
+    t.n = n;
+    p = t;
+    sub.poolQuadPlanes = nQuadPlanes;
     return MI_OK;
 }
+
+// Device temporaries of the entry points: freed on every return path.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <typename T> T *as() const { return (T *)p; }
+};
 
 }  // namespace
 
@@ -1996,7 +2021,9 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         for (SubRenderer &sub : pt->subs) {
             if (hipMalloc((void **)&sub.ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "hipMalloc(counters) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
             if (hipStreamCreateWithFlags(&sub.stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
-            for (int a = 0; a < 2; ++a) for (int b = 0; b < 7; ++b) hipEventCreate(&sub.evIter[a][b]);
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < N_EV; ++b)
+                    if (hipEventCreate(&sub.evIter[a][b]) != hipSuccess) { g_err = "hipEventCreate failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
         }
     }
     *out = pt;
@@ -2059,7 +2086,9 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipEventElapsedTime(&ms, sub.evIter[set][2], sub.evIter[set][3]); sub.t[3] += ms * 1e-3;
         hipEventElapsedTime(&ms, sub.evIter[set][3], sub.evIter[set][4]); sub.t[4] += ms * 1e-3;
         hipEventElapsedTime(&ms, sub.evIter[set][4], sub.evIter[set][5]); sub.t[5] += ms * 1e-3;
-        hipEventElapsedTime(&ms, sub.evIter[set][1], sub.evIter[set][6]); sub.t[6] += ms * 1e-3;
+        // the closest-hit traversal launch alone: from an event recorded right before it (after the host's
+        // per-iteration read of `alive`), so the host round trip is in [2] but not in [6]
+        hipEventElapsedTime(&ms, sub.evIter[set][7], sub.evIter[set][6]); sub.t[6] += ms * 1e-3;
     };
     int set = 0;
     bool prevFull = false, havePrev = false;
@@ -2073,6 +2102,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipStreamSynchronize(st));
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
+        HIPCHK(hipEventRecord(ev[7], st));
         if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<0, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_trav<0, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[6], st));
@@ -2104,6 +2134,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         else hipLaunchKernelGGL((k_trav<2, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
         hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[5], st));
+        HIPCHK(hipGetLastError());   // a launch of this iteration that was refused (bad configuration) stops the render here
         havePrev = true; prevFull = true;
         set ^= 1;
         if (++sub.iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; }
@@ -2133,7 +2164,13 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         errs[0] = g_err;
         for (auto &t : threads) t.join();
     }
-    for (int k = 0; k < nSub; ++k) if (rcs[k] != MI_OK) { g_err = errs[k]; return rcs[k]; }
+    for (int k = 0; k < nSub; ++k)
+        if (rcs[k] != MI_OK) {
+            // a failed sub-renderer may have left kernels queued: nothing of the caller's may be touched after we return
+            (void)hipDeviceSynchronize();
+            g_err = errs[k];
+            return rcs[k];
+        }
     HIPCHK(hipDeviceSynchronize());
     pt->lastSeconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long iterations = 0;
@@ -2164,16 +2201,19 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         const bool onDev = (rp->flags & MI_RENDER_FILM_ON_DEVICE) != 0;
         float *dSum = nullptr, *dW = nullptr;
         if (onDev) { dSum = film_sum; dW = weight_sum; }
-        else {
-            if (film_sum) HIPCHK(hipMalloc((void **)&dSum, pt->nPix * 31 * sizeof(float)));
-            if (weight_sum) HIPCHK(hipMalloc((void **)&dW, pt->nPix * sizeof(float)));
+        else {   // staging for the host hand-over: allocated once per renderer, freed by mi_pt_destroy
+            if (film_sum && !pt->stageSum) HIPCHK(hipMalloc((void **)&pt->stageSum, pt->nPix * 31 * sizeof(float)));
+            if (weight_sum && !pt->stageW) HIPCHK(hipMalloc((void **)&pt->stageW, pt->nPix * sizeof(float)));
+            if (film_sum) dSum = pt->stageSum;
+            if (weight_sum) dW = pt->stageW;
         }
         size_t total = pt->nPix * 32;
         hipLaunchKernelGGL(k_film_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pt->film, dSum, dW, pt->nPix);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         if (!onDev) {
-            if (film_sum) { HIPCHK(hipMemcpy(film_sum, dSum, pt->nPix * 31 * sizeof(float), hipMemcpyDeviceToHost)); hipFree(dSum); }
-            if (weight_sum) { HIPCHK(hipMemcpy(weight_sum, dW, pt->nPix * sizeof(float), hipMemcpyDeviceToHost)); hipFree(dW); }
+            if (film_sum) HIPCHK(hipMemcpy(film_sum, dSum, pt->nPix * 31 * sizeof(float), hipMemcpyDeviceToHost));
+            if (weight_sum) HIPCHK(hipMemcpy(weight_sum, dW, pt->nPix * sizeof(float), hipMemcpyDeviceToHost));
         }
     }
     return MI_OK;
@@ -2198,15 +2238,14 @@ int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *querie
     if (pt->textureTypes[tex] != MI_TEX_IMAGEMAP) { g_err = "mi_pt_texture_lookup: not an image texture"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;
     HIPCHK(hipSetDevice(pt->device));
-    float *dq = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void **)&dq, (size_t)n * 6 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 3 * sizeof(float)));
-    HIPCHK(hipMemcpy(dq, queries, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_texture_lookup, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, tex, dq, n, dout);
+    DevBuf dq, dout;
+    HIPCHK(dq.alloc((size_t)n * 6 * sizeof(float)));
+    HIPCHK(dout.alloc((size_t)n * 3 * sizeof(float)));
+    HIPCHK(hipMemcpy(dq.p, queries, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_texture_lookup, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, tex, dq.as<float>(), n, dout.as<float>());
+    HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(rgb, dout, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    hipFree(dq);
-    hipFree(dout);
+    HIPCHK(hipMemcpy(rgb, dout.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 
@@ -2214,15 +2253,14 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
     if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;
     HIPCHK(hipSetDevice(pt->device));
-    float *dr = nullptr, *dh = nullptr;
-    HIPCHK(hipMalloc((void **)&dr, (size_t)n * 7 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&dh, (size_t)n * 4 * sizeof(float)));
-    HIPCHK(hipMemcpy(dr, rays, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, dr, n, any_hit, dh);
+    DevBuf dr, dh;
+    HIPCHK(dr.alloc((size_t)n * 7 * sizeof(float)));
+    HIPCHK(dh.alloc((size_t)n * 4 * sizeof(float)));
+    HIPCHK(hipMemcpy(dr.p, rays, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, pt->scene, dr.as<float>(), n, any_hit, dh.as<float>());
+    HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(hits, dh, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    hipFree(dr);
-    hipFree(dh);
+    HIPCHK(hipMemcpy(hits, dh.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 
@@ -2232,18 +2270,12 @@ void mi_pt_destroy(mi_pt *pt) {
     hipDeviceSynchronize();
     for (void *p : pt->allocs) hipFree(p);
     if (pt->film) hipFree(pt->film);
+    if (pt->stageSum) hipFree(pt->stageSum);
+    if (pt->stageW) hipFree(pt->stageW);
     for (SubRenderer &sub : pt->subs) {
-        Pool &p = sub.pool;
-        if (p.f) hipFree(p.f);
-        if (p.q) hipFree(p.q);
-        if (p.r) hipFree(p.r);
-        if (p.i) hipFree(p.i);
-        if (p.shadowQ) hipFree(p.shadowQ);
-        if (p.extQ) hipFree(p.extQ);
-        if (p.misQ) hipFree(p.misQ);
-        if (p.shadeQ) hipFree(p.shadeQ);
+        FreePool(sub.pool);
         if (sub.ctr) hipFree(sub.ctr);
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 7; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < N_EV; ++b) if (sub.evIter[a][b]) hipEventDestroy(sub.evIter[a][b]);
         if (sub.stream) hipStreamDestroy(sub.stream);
     }
     delete pt;

@@ -2,6 +2,8 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include "../../../include/mi_scene.h"
 #include "integrator.h"
 #include "scene.h"
@@ -10,6 +12,27 @@ using namespace mipt;
 
 struct mi_scene { HostScene *hs; };
 static thread_local std::string g_err;
+
+// Nothing may throw across the C ABI (include/mi_scene.h): a corrupt input that gets as far as an allocation
+// (a header that promises 2^40 pixels, ...) comes back as an error code like every other malformed scene.
+template <typename F>
+static int Guarded(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        g_err = "out of memory while loading the scene (corrupt size in an input file?)";
+        return MI_ERR_NOMEM;
+    } catch (const std::length_error &e) {
+        g_err = std::string("size out of range while loading the scene: ") + e.what();
+        return MI_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        g_err = std::string("scene front end: ") + e.what();
+        return MI_ERR_INVALID;
+    } catch (...) {
+        g_err = "scene front end: unknown exception";
+        return MI_ERR_INVALID;
+    }
+}
 
 static LoadOverrides ToOv(const mi_scene_overrides *ov) {
     LoadOverrides o;
@@ -25,20 +48,24 @@ extern "C" {
 
 int mi_scene_load_file(const char *path, const mi_scene_overrides *ov, mi_scene **out) {
     if (!path || !out) { g_err = "null argument"; return MI_ERR_INVALID; }
-    std::string err;
-    HostScene *hs = LoadSceneFile(path, ToOv(ov), &err);
-    if (!hs) { g_err = err; return MI_ERR_INVALID; }
-    *out = new mi_scene{hs};
-    return MI_OK;
+    return Guarded([&]() -> int {
+        std::string err;
+        HostScene *hs = LoadSceneFile(path, ToOv(ov), &err);
+        if (!hs) { g_err = err; return MI_ERR_INVALID; }
+        *out = new mi_scene{hs};
+        return MI_OK;
+    });
 }
 
 int mi_scene_load_string(const char *text, const char *base_dir, const mi_scene_overrides *ov, mi_scene **out) {
     if (!text || !out) { g_err = "null argument"; return MI_ERR_INVALID; }
-    std::string err;
-    HostScene *hs = LoadSceneString(text, base_dir ? base_dir : ".", ToOv(ov), &err);
-    if (!hs) { g_err = err; return MI_ERR_INVALID; }
-    *out = new mi_scene{hs};
-    return MI_OK;
+    return Guarded([&]() -> int {
+        std::string err;
+        HostScene *hs = LoadSceneString(text, base_dir ? base_dir : ".", ToOv(ov), &err);
+        if (!hs) { g_err = err; return MI_ERR_INVALID; }
+        *out = new mi_scene{hs};
+        return MI_OK;
+    });
 }
 
 const mi_scene_desc *mi_scene_get_desc(const mi_scene *s) { return s ? &s->hs->desc : nullptr; }
@@ -105,12 +132,14 @@ int mi_film_read_dat(const char *filename, int *w, int *h, float *data, uint64_t
 
 int mi_integrator_render(const mi_scene *s, int device_ordinal, const char *outfile, mi_counters *counters) {
     if (!s) { g_err = "null scene"; return MI_ERR_INVALID; }
-    std::unique_ptr<PathIntegrator> integ(CreatePathIntegrator(*s->hs, device_ordinal, outfile ? outfile : ""));
-    std::string err;
-    int rc = integ->Render(*s->hs, &err);
-    if (counters) *counters = integ->counters;
-    g_err = err;
-    return rc;
+    return Guarded([&]() -> int {
+        std::unique_ptr<PathIntegrator> integ(CreatePathIntegrator(*s->hs, device_ordinal, outfile ? outfile : ""));
+        std::string err;
+        int rc = integ->Render(*s->hs, &err);
+        if (counters) *counters = integ->counters;
+        g_err = err;
+        return rc;
+    });
 }
 
 }  // extern "C"

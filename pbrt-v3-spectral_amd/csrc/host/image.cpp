@@ -60,6 +60,13 @@ bool ReadPFM(const std::string &filename, int *xres, int *yres, std::vector<RGB>
     if (ok && readWord(buf, 80) != -1) height = atoi(buf); else ok = false;
     if (ok && readWord(buf, 80) != -1) sscanf(buf, "%f", &scale); else ok = false;
     if (!ok || width <= 0 || height <= 0) { fclose(fp); return false; }
+    {   // the header's size against the bytes that follow it: a corrupt width / height is an error, not an allocation
+        const long here = ftell(fp);
+        fseek(fp, 0, SEEK_END);
+        const long long left = (long long)ftell(fp) - here;
+        fseek(fp, here, SEEK_SET);
+        if ((long long)nChannels * width * height * 4 > left) { fclose(fp); return false; }
+    }
     std::vector<float> data((size_t)nChannels * width * height);
     for (int y = height - 1; y >= 0 && ok; --y)   // P*M has its origin at the lower left
         ok = fread(&data[(size_t)y * nChannels * width], sizeof(float), (size_t)nChannels * width, fp) == (size_t)nChannels * width;

@@ -99,7 +99,13 @@ bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std:
             format = (f == "ascii") ? 0 : (f == "binary_little_endian") ? 1 : (f == "binary_big_endian") ? 2 : -1;
         } else if (kw == "element") {
             PlyElement e;
-            ls >> e.name >> e.count;
+            if (!(ls >> e.name >> e.count) || e.count < 0) { *err = "Unable to read the header of PLY file \"" + filename + "\""; return false; }
+            // the arrays below are sized by the one vertex / face element: a second one would write past them
+            for (const PlyElement &prev : elements)
+                if (prev.name == e.name && (e.name == "vertex" || e.name == "face")) {
+                    *err = filename + ": PLY file is invalid! More than one \"" + e.name + "\" element";
+                    return false;
+                }
             elements.push_back(e);
         } else if (kw == "property") {
             if (elements.empty()) { *err = "Unable to read the header of PLY file \"" + filename + "\""; return false; }
@@ -128,6 +134,19 @@ bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std:
         else if (e.name == "face") faceCount = e.count;
     }
     if (vertexCount == 0 || faceCount == 0) { *err = filename + ": PLY file is invalid! No face/vertex elements found!"; return false; }
+    {   // an element cannot hold more items than the file has bytes left (every item takes at least one: a binary
+        // scalar, an ascii digit, or a list's count), so a count beyond that is a corrupt header, not an allocation size
+        const std::streampos here = in.tellg();
+        in.seekg(0, std::ios::end);
+        const long long left = (long long)(in.tellg() - here);
+        in.seekg(here);
+        for (const PlyElement &e : elements)
+            if (!e.props.empty() && (long long)e.count > left) {
+                *err = filename + ": PLY file is invalid! Element \"" + e.name + "\" declares " + std::to_string(e.count) +
+                       " items, the file holds " + std::to_string(left) + " bytes of data";
+                return false;
+            }
+    }
 
     // which vertex properties feed which buffer (plymesh.cpp:189-243)
     const PlyElement *ve = nullptr;
@@ -152,7 +171,7 @@ bool ReadPLYMesh(const std::string &filename, PLYMeshData *out, std::vector<std:
             for (const PlyProperty &p : e.props) {
                 if (!p.isList) {
                     const double v = rd.Next(p.type);
-                    if (isVertex) {
+                    if (isVertex && (size_t)i < out->P.size()) {
                         const float f = (float)v;
                         if (p.name == "x") out->P[i].x = f; else if (p.name == "y") out->P[i].y = f; else if (p.name == "z") out->P[i].z = f;
                         else if (haveN && p.name == "nx") out->N[i].x = f; else if (haveN && p.name == "ny") out->N[i].y = f;

@@ -318,6 +318,29 @@ def test_plymesh_errors(pt, tmp_path):
     _write_ply(tmp_path / "bad.ply", "ascii", np.zeros((3, 3), np.float32), [(0, 1, 7)])
     s = pt.Scene(text=head + 'Shape "plymesh" "string filename" "bad.ply"\nWorldEnd\n', base_dir=str(tmp_path))
     assert any("out of bounds" in e for e in s.errors) and s.stats["n_triangles"] == 0
+    # headers that lie about their elements: a second `element vertex` (the arrays are sized by one of them), negative and
+    # absurd counts. Each is reported as an error -- nothing is written out of bounds, nothing throws across the C ABI.
+    body = "0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n"
+    props = "property float x\nproperty float y\nproperty float z\n"
+    face = "element face 1\nproperty list uchar int vertex_indices\n"
+    for name, header in [
+        ("dup", "element vertex 3\n" + props + face + "element vertex 1\n" + props),
+        ("neg", "element vertex -5\n" + props + face),
+        ("huge", "element vertex 4000000000000\n" + props + face),
+        ("hugeface", "element vertex 3\n" + props + "element face 9000000000000\nproperty list uchar int vertex_indices\n"),
+        ("nocount", "element vertex\n" + props + face),
+    ]:
+        (tmp_path / (name + ".ply")).write_text("ply\nformat ascii 1.0\n" + header + "end_header\n" + body)
+        s = pt.Scene(text=head + 'Shape "plymesh" "string filename" "%s.ply"\nWorldEnd\n' % name, base_dir=str(tmp_path))
+        assert s.errors and s.stats["n_triangles"] == 0, name
+
+
+def test_corrupt_image_sizes_are_errors_not_allocations(pt, tmp_path):
+    """A PFM header that promises more pixels than the file holds (the allocation used to throw through ctypes)."""
+    (tmp_path / "big.pfm").write_bytes(b"PF\n2000000 2000000\n-1.0\n" + b"\0" * 64)
+    s = pt.Scene(text='Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "big.pfm"\n'
+                      'Material "matte" "texture Kd" "t"\nShape "sphere"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("big.pfm" in e for e in s.errors)
 
 
 def test_rgb_film_output_pfm_and_tga(pt, tmp_path):

@@ -18,6 +18,13 @@ for fmt in ("ascii","binary_little_endian","binary_big_endian"):
                 b[rnd.randrange(0,len(b))]=rnd.randrange(256)
         open(os.path.join(d,'f.ply'),'wb').write(bytes(b))
         s=pt.Scene(text='Camera "perspective"\nWorldBegin\nShape "plymesh" "string filename" "f.ply"\nWorldEnd\n', base_dir=d); n+=1
+# PLY headers that lie about their elements: duplicated / negative / absurd element counts
+props="property float x\nproperty float y\nproperty float z\n"; face="element face 1\nproperty list uchar int vertex_indices\n"
+for header in ("element vertex 3\n"+props+face+"element vertex 1\n"+props, "element vertex -5\n"+props+face,
+               "element vertex 4000000000000\n"+props+face, "element vertex 3\n"+props+"element face 9000000000000\nproperty list uchar int vertex_indices\n"):
+    open(os.path.join(d,'f.ply'),'w').write("ply\nformat ascii 1.0\n"+header+"end_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    s=pt.Scene(text='Camera "perspective"\nWorldBegin\nShape "plymesh" "string filename" "f.ply"\nWorldEnd\n', base_dir=d); n+=1
+    assert s.errors
 # .pbrt text mutations
 import scenes_text as st
 txt=st.material_zoo(res=8, spp=1)
