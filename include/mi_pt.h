@@ -372,6 +372,14 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  * the UVMapping2D; rgb: 3 floats per query. */
 int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *queries, float *rgb);
 
+/* Parity tool for the spatial light-selection strategy: the per-voxel Distribution1D tables mi_pt_create estimated on
+ * the device (SpatialLightDistribution::ComputeDistribution, src/core/lightdistrib.cpp:232-300; the reference fills its
+ * hash table lazily, this build tabulates every voxel). Voxel (x, y, z) has index (z * n_voxels[1] + y) * n_voxels[0] + x.
+ * func: [n_voxels * n_lights] floats (Distribution1D::func of voxel v at v * n_lights), func_int: [n_voxels]
+ * (Distribution1D::funcInt); either may be NULL. capacity_voxels must be >= the voxel count. MI_ERR_INVALID when the
+ * scene does not use "lightsamplestrategy" "spatial" (or has no lights). Host pointers. */
+int mi_pt_light_distribution(mi_pt *pt, float *func, float *func_int, uint64_t capacity_voxels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1025,6 +1025,94 @@ void oracle_light_pmf(const mi_scene_desc *desc, const float *p3, float *pmf) {
         pmf[i] = (dist->funcInt > 0) ? dist->func[i] / (dist->funcInt * dist->Count()) : 0;
 }
 
+// Shape::Sample(ref, u, &pdf) (shape.cpp:56-70, sphere.cpp:232-292, triangle.cpp:583-608) of shape `shape`
+// (>= 0 triangle, < 0 ~sphere) for a reference point as the reference's tests build it
+// (tests/shapes.cpp:240: Interaction ref(pc, Normal3f(), Vector3f(), Vector3f(0, 0, 1), ...): no normal, no error bound).
+// n samples u2[n][2] -> out7[n] = {p.xyz, n.xyz, pdf}.
+void oracle_shape_sample(const mi_scene_desc *desc, int shape, const float *ref3, int n, const float *u2, float *out7) {
+    Interaction ref;
+    ref.p = V3(ref3[0], ref3[1], ref3[2]);
+    ref.pError = V3(0, 0, 0); ref.n = V3(0, 0, 0); ref.wo = V3(0, 0, 1);
+    for (int i = 0; i < n; ++i) {
+        const Float u[2] = {u2[2 * i], u2[2 * i + 1]};
+        Float pdf = 0;
+        Interaction it = ShapeSample(*desc, shape, ref, u, &pdf);
+        float *o = out7 + (size_t)i * 7;
+        o[0] = it.p.x; o[1] = it.p.y; o[2] = it.p.z;
+        o[3] = it.n.x; o[4] = it.n.y; o[5] = it.n.z;
+        o[6] = pdf;
+    }
+}
+// Shape::Pdf(ref, wi) (shape.cpp:72-87, sphere.cpp:294-306) for the same kind of reference point.
+float oracle_shape_pdf(const mi_scene_desc *desc, int shape, float area, const float *ref3, const float *wi3) {
+    Interaction ref;
+    ref.p = V3(ref3[0], ref3[1], ref3[2]);
+    ref.pError = V3(0, 0, 0); ref.n = V3(0, 0, 0); ref.wo = V3(0, 0, 1);
+    return ShapePdf(*desc, shape, area, ref, V3(wi3[0], wi3[1], wi3[2]));
+}
+// The rays a SurfaceInteraction spawns (tests/shapes.cpp:154-205, 375-425): intersect `ray7` with the scene; at the hit,
+// for each of the n `targets` (mode 0: a direction w -> isect.SpawnRay(w); mode 1: a point p2 -> isect.SpawnRayTo(p2)),
+// optionally flipped into the hemisphere of the surface normal first (Faceforward, the convex-shape variant), write the
+// spawned ray {o, d, tMax} to out_rays. Returns 1 if the first ray hit, else 0 (then nothing is written).
+int oracle_spawn_rays(const mi_scene_desc *desc, const float *ray7, int n, const float *targets, int mode, int faceforward,
+                      float *out_rays) {
+    Scene scene(*desc);
+    Counters c;
+    Ray ray(V3(ray7[0], ray7[1], ray7[2]), V3(ray7[3], ray7[4], ray7[5]), ray7[6]);
+    SurfaceInteraction isect;
+    if (!scene.Intersect(ray, &isect, c)) return 0;
+    for (int i = 0; i < n; ++i) {
+        V3 t(targets[3 * i], targets[3 * i + 1], targets[3 * i + 2]);
+        Ray r;
+        if (mode == 0) {
+            if (faceforward) t = Faceforward(t, isect.n);
+            r = SpawnRay(isect, t);
+        } else {
+            if (faceforward) {
+                V3 w = t - isect.p;
+                w = Faceforward(w, isect.n);
+                t = isect.p + w;
+            }
+            r = Ray(OffsetRayOrigin(isect.p, isect.pError, isect.n, t - isect.p), t - isect.p, 1 - ShadowEpsilon);
+        }
+        float *o = out_rays + (size_t)i * 7;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.tMax;
+    }
+    return 1;
+}
+
+// The raw table of voxel (x, y, z): Distribution1D::func [n_lights] and funcInt (lightdistrib.cpp:232-300).
+void oracle_light_voxel(const mi_scene_desc *desc, const int *pi3, float *func, float *func_int) {
+    LightDistribution ld(*desc);
+    if (desc->n_lights == 0 || desc->light_distrib.type != MI_LD_SPATIAL) return;
+    std::unique_ptr<Distribution1D> dist(ld.ComputeDistribution(pi3));
+    for (uint32_t i = 0; i < desc->n_lights; ++i) func[i] = dist->func[i];
+    *func_int = dist->funcInt;
+}
+
+// ... and of every voxel at once (index (z * ny + y) * nx + x), on n_threads threads: func [n_voxels * n_lights], func_int [n_voxels].
+void oracle_light_table(const mi_scene_desc *desc, int n_threads, float *func, float *func_int) {
+    if (desc->n_lights == 0 || desc->light_distrib.type != MI_LD_SPATIAL) return;
+    LightDistribution ld(*desc);
+    const int *nv = desc->light_distrib.n_voxels;
+    const size_t nVox = (size_t)nv[0] * nv[1] * nv[2];
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t v = next.fetch_add(1);
+            if (v >= nVox) return;
+            const int pi[3] = {(int)(v % nv[0]), (int)((v / nv[0]) % nv[1]), (int)(v / ((size_t)nv[0] * nv[1]))};
+            std::unique_ptr<Distribution1D> dist(ld.ComputeDistribution(pi));
+            for (uint32_t i = 0; i < desc->n_lights; ++i) func[v * desc->n_lights + i] = dist->func[i];
+            func_int[v] = dist->funcInt;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::max(1, n_threads); ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
 // Distribution1D over func[n] (sampling.h:55-109): mode 0 = SampleDiscrete(u) -> out{offset, pdf};
 // mode 1 = SampleContinuous(u) -> out{x, pdf, offset}; mode 2 = DiscretePDF(index = (int)u) -> out{pdf}.
 void oracle_distribution1d(const float *func, int n, float u, int mode, float *out) {

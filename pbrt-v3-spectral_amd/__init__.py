@@ -211,6 +211,7 @@ def hip_lib():
         lib.mi_pt_last_error.restype = C.c_char_p
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
         lib.mi_pt_texture_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.mi_pt_light_distribution.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
         _hip = lib
     return _hip
 
@@ -352,6 +353,17 @@ class PathIntegrator:
             raise RuntimeError("mi_pt_trace failed: %s" % hip_lib().mi_pt_last_error().decode())
         return hits
 
+
+    def light_distribution(self):
+        """The spatial light-selection tables built at create: (func [nz, ny, nx, n_lights], funcInt [nz, ny, nx])."""
+        d = self.scene.desc
+        nx, ny, nz = [int(v) for v in d.light_distrib.n_voxels]
+        func = np.zeros((nz, ny, nx, d.n_lights), np.float32)
+        fint = np.zeros((nz, ny, nx), np.float32)
+        rc = hip_lib().mi_pt_light_distribution(self._h, _fptr(func), _fptr(fint), nx * ny * nz)
+        if rc != 0:
+            raise RuntimeError("mi_pt_light_distribution failed: %s" % hip_lib().mi_pt_last_error().decode())
+        return func, fint
 
     def texture_lookup(self, tex, queries):
         """MIPMap::Lookup on the device: queries [n, 6] = (s, t, dsdx, dtdx, dsdy, dtdy) -> rgb [n, 3]."""

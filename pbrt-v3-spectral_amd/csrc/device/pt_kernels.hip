@@ -2249,6 +2249,18 @@ int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *querie
     return MI_OK;
 }
 
+int mi_pt_light_distribution(mi_pt *pt, float *func, float *func_int, uint64_t capacity_voxels) {
+    if (!pt) { g_err = "null argument"; return MI_ERR_INVALID; }
+    const DScene &s = pt->scene;
+    if (s.ldType != MI_LD_SPATIAL || s.nLights == 0) { g_err = "mi_pt_light_distribution: the scene has no spatial light distribution"; return MI_ERR_INVALID; }
+    const size_t nVox = (size_t)s.nVoxels[0] * s.nVoxels[1] * s.nVoxels[2];
+    if (capacity_voxels < nVox) { g_err = "mi_pt_light_distribution: buffer too small"; return MI_ERR_INVALID; }
+    HIPCHK(hipSetDevice(pt->device));
+    if (func) HIPCHK(hipMemcpy(func, s.ldFunc, nVox * s.nLights * sizeof(float), hipMemcpyDeviceToHost));
+    if (func_int) HIPCHK(hipMemcpy(func_int, s.ldFuncInt, nVox * sizeof(float), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
 int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hits) {
     if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;

@@ -35,6 +35,8 @@ def lib():
         l.oracle_tri_test.argtypes = [F, F, F]
         l.oracle_bsdf.argtypes = [D, C.c_int, C.c_int, F, F, F, C.c_int, F]
         l.oracle_light_pmf.argtypes = [D, F, F]
+        l.oracle_light_voxel.argtypes = [D, C.POINTER(C.c_int32), F, F]
+        l.oracle_light_table.argtypes = [D, C.c_int, F, F]
         _lib = l
     return _lib
 
@@ -83,3 +85,22 @@ def texture_lookup(scene, tex, st, dstdx=(0, 0), dstdy=(0, 0)):
     out = np.zeros(34, np.float32)
     lib().oracle_texture_lookup(scene.desc_ptr, int(tex), _f(st2), _f(d4), _f(out))
     return out[:3], out[3:]
+
+
+def light_voxel(scene, pi):
+    """(func[n_lights], funcInt) of the spatial light distribution's voxel pi = (x, y, z)."""
+    idx = (C.c_int32 * 3)(*[int(v) for v in pi])
+    func = np.zeros(scene.desc.n_lights, np.float32)
+    fint = np.zeros(1, np.float32)
+    lib().oracle_light_voxel(scene.desc_ptr, idx, _f(func), _f(fint))
+    return func, float(fint[0])
+
+
+def light_table(scene, n_threads=None):
+    """Every voxel of the spatial light distribution: (func [nz, ny, nx, n_lights], funcInt [nz, ny, nx])."""
+    d = scene.desc
+    nx, ny, nz = [int(v) for v in d.light_distrib.n_voxels]
+    func = np.zeros((nz, ny, nx, d.n_lights), np.float32)
+    fint = np.zeros((nz, ny, nx), np.float32)
+    lib().oracle_light_table(scene.desc_ptr, n_threads or os.cpu_count() or 1, _f(func), _f(fint))
+    return func, fint
