@@ -380,6 +380,17 @@ int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *querie
  * scene does not use "lightsamplestrategy" "spatial" (or has no lights). Host pointers. */
 int mi_pt_light_distribution(mi_pt *pt, float *func, float *func_int, uint64_t capacity_voxels);
 
+/* Parity tool: the state of ONE camera sample (pixel px, py; Halton sample number `sample`) vertex by vertex, for a
+ * side-by-side comparison with the oracle's log of the same sample (oracle_path_log) when a film differs. One record of
+ * MI_PATH_RECORD_FLOATS floats per path vertex (one wavefront iteration):
+ *   [0] bounces  [1] hit primitive (-1: escaped)  [2] sampler dimension before the vertex  [3] 1 if the path ended here
+ *   [4..6] incoming ray origin  [7] t of the hit  [8..10] incoming ray direction  [11] etaScale before
+ *   [12..14] next ray origin  [15] sampler dimension after  [16..18] next ray direction  [19] etaScale after
+ *   [20..50] beta after the vertex  [51..81] L after the vertex's direct lighting has been added
+ * The device film is cleared by this call. */
+#define MI_PATH_RECORD_FLOATS 96
+int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t max_records, float *records, int32_t *n_records);
+
 #ifdef __cplusplus
 }
 #endif

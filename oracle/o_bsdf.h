@@ -54,8 +54,8 @@ inline void ConcentricSampleDisk(const Float u[2], Float d[2]) {  // sampling.cp
     Float theta, r;
     if (std::abs(ox) > std::abs(oy)) { r = ox; theta = PiOver4 * (oy / ox); }
     else { r = oy; theta = PiOver2 - PiOver4 * (ox / oy); }
-    d[0] = r * std::cos(theta);
-    d[1] = r * std::sin(theta);
+    d[0] = r * CosF(theta);
+    d[1] = r * SinF(theta);
 }
 inline V3 CosineSampleHemisphere(const Float u[2]) {  // sampling.h:159-163
     Float d[2];
@@ -144,7 +144,7 @@ inline Float FrSchlick(Float R0, Float cosTheta) { return Lerp(SchlickWeight(cos
 inline Spec FrSchlick(const Spec &R0, Float cosTheta) { return Lerp(SchlickWeight(cosTheta), R0, Spec(1.)); }
 inline Float GTR1(Float cosTheta, Float alpha) {
     Float alpha2 = alpha * alpha;
-    return (alpha2 - 1) / (Pi * std::log(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
+    return (alpha2 - 1) / (Pi * LogF(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
 }
 inline Float smithG_GGX(Float cosTheta, Float alpha) {
     Float alpha2 = alpha * alpha;
@@ -421,7 +421,7 @@ struct BxDF {
         case MI_BXDF_DISNEY_CLEARCOAT: {  // disney.cpp:280-303
             if (wo.z == 0) return Spec(0.);
             Float alpha2 = b->p[1] * b->p[1];
-            Float cosTheta = std::sqrt(std::max(Float(0), (1 - std::pow(alpha2, 1 - u[0])) / (1 - alpha2)));
+            Float cosTheta = std::sqrt(std::max(Float(0), (1 - PowF(alpha2, 1 - u[0])) / (1 - alpha2)));
             Float sinTheta = std::sqrt(std::max((Float)0, 1 - cosTheta * cosTheta));
             Float phi = 2 * Pi * u[1];
             V3 wh = SphericalDirection(sinTheta, cosTheta, phi);

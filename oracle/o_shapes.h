@@ -424,7 +424,7 @@ inline bool SphereRoots(const mi_sphere &s, const Ray &r, Ray *rayObj, V3 *pHitO
     V3 pHit = ray((Float)tShapeHit);
     pHit *= radius / Distance(pHit, V3(0, 0, 0));
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
-    Float phi = std::atan2(pHit.y, pHit.x);
+    Float phi = Atan2F(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * Pi;
     if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) {
         if (tShapeHit == t1) return false;
@@ -433,7 +433,7 @@ inline bool SphereRoots(const mi_sphere &s, const Ray &r, Ray *rayObj, V3 *pHitO
         pHit = ray((Float)tShapeHit);
         pHit *= radius / Distance(pHit, V3(0, 0, 0));
         if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
-        phi = std::atan2(pHit.y, pHit.x);
+        phi = Atan2F(pHit.y, pHit.x);
         if (phi < 0) phi += 2 * Pi;
         if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) return false;
     }
@@ -449,14 +449,14 @@ inline bool SphereIntersect(const mi_sphere &s, const Ray &r, Float *tHit, Surfa
     if (!SphereRoots(s, r, &ray, &pHit, &phi, &t)) return false;
     const Float radius = s.radius, phiMax = s.phi_max, thetaMin = s.theta_min, thetaMax = s.theta_max;
     Float u = phi / phiMax;
-    Float theta = std::acos(Clamp(pHit.z / radius, -1, 1));
+    Float theta = AcosF(Clamp(pHit.z / radius, -1, 1));
     Float v = (theta - thetaMin) / (thetaMax - thetaMin);
     Float zRadius = std::sqrt(pHit.x * pHit.x + pHit.y * pHit.y);
     Float invZRadius = 1 / zRadius;
     Float cosPhi = pHit.x * invZRadius;
     Float sinPhi = pHit.y * invZRadius;
     V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
-    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * std::sin(theta));
+    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * SinF(theta));
     V3 d2Pduu = -phiMax * phiMax * V3(pHit.x, pHit.y, 0);
     V3 d2Pduv = (thetaMax - thetaMin) * pHit.z * phiMax * V3(-sinPhi, cosPhi, 0.);
     V3 d2Pdvv = -(thetaMax - thetaMin) * (thetaMax - thetaMin) * V3(pHit.x, pHit.y, pHit.z);
@@ -492,7 +492,7 @@ inline V3 UniformSampleSphere(const Float u[2]) {  // sampling.cpp:98-103
     Float z = 1 - 2 * u[0];
     Float r = std::sqrt(std::max((Float)0, (Float)1 - z * z));
     Float phi = 2 * Pi * u[1];
-    return V3(r * std::cos(phi), r * std::sin(phi), z);
+    return V3(r * CosF(phi), r * SinF(phi), z);
 }
 // Sphere::Sample(u), sphere.cpp:219-230
 inline Interaction SphereSampleArea(const mi_sphere &s, const Float u[2], Float *pdf) {

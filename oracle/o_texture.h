@@ -94,7 +94,7 @@ struct MipView {
         return (1 - ds) * (1 - dt) * Texel(level, s0, t0) + (1 - ds) * dt * Texel(level, s0, t0 + 1) +
                ds * (1 - dt) * Texel(level, s0 + 1, t0) + ds * dt * Texel(level, s0 + 1, t0 + 1);
     }
-    static Float Log2(Float x) { const Float invLog2 = 1.442695040888963387004650940071; return std::log(x) * invLog2; }
+    static Float Log2(Float x) { const Float invLog2 = 1.442695040888963387004650940071; return LogF(x) * invLog2; }
     RGB3 LookupWidth(const Float st[2], Float width, bool noFiltering) const {  // mipmap.h:238-266
         if (noFiltering) {
             Float s = st[0] * uSize(0) - 0.5f;

@@ -327,8 +327,8 @@ static void EnvLookup(const mi_envmap &e, const Float st[2], Float rgb[3]) {
 static V3 Mul3(const float m[9], const V3 &v) {  // Transform::operator()(Vector3f), transform.h:235-240
     return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
 }
-static Float SphericalTheta(const V3 &v) { return std::acos(Clamp(v.z, -1, 1)); }
-static Float SphericalPhi(const V3 &v) { Float p = std::atan2(v.y, v.x); return (p < 0) ? (p + 2 * Pi) : p; }
+static Float SphericalTheta(const V3 &v) { return AcosF(Clamp(v.z, -1, 1)); }
+static Float SphericalPhi(const V3 &v) { Float p = Atan2F(v.y, v.x); return (p < 0) ? (p + 2 * Pi) : p; }
 static Spec InfiniteLe(const mi_scene_desc &d, const mi_light &l, const V3 &dir) {  // infinite.cpp:91-95
     V3 w = Normalize(Mul3(l.w2l, dir));
     Float st[2] = {SphericalPhi(w) * Inv2Pi, SphericalTheta(w) * InvPi}, rgb[3];
@@ -354,7 +354,7 @@ static Float InfinitePdfLi(const mi_scene_desc &d, const mi_light &l, const V3 &
     const mi_envmap &e = d.envmaps[l.envmap];
     V3 wi = Mul3(l.w2l, w);
     Float theta = SphericalTheta(wi), phi = SphericalPhi(wi);
-    Float sinTheta = std::sin(theta);
+    Float sinTheta = SinF(theta);
     if (sinTheta == 0) return 0;
     Float p[2] = {phi * Inv2Pi, theta * InvPi};
     int iu = Clamp(int(p[0] * e.nu), 0, e.nu - 1);   // Distribution2D::Pdf, sampling.h:137-143
@@ -409,8 +409,8 @@ static LightSample SampleLi(const mi_scene_desc &d, const mi_light &l, const Int
         Float mapPdf = pdfs[0] * pdfs[1];
         if (mapPdf == 0) return ls;
         Float theta = d1 * Pi, phi = d0 * 2 * Pi;
-        Float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
-        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+        Float cosTheta = CosF(theta), sinTheta = SinF(theta);
+        Float sinPhi = SinF(phi), cosPhi = CosF(phi);
         ls.wi = Mul3(l.l2w, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
         ls.pdf = mapPdf / (2 * Pi * Pi * sinTheta);
         if (sinTheta == 0) ls.pdf = 0;
@@ -595,6 +595,27 @@ static Spec EstimateDirect(const Scene &scene, const SurfaceInteraction &it, con
     return Ld;
 }
 
+// Optional per-vertex log of Li (oracle_path_log; record layout: include/mi_pt.h, MI_PATH_RECORD_FLOATS).
+static thread_local std::vector<float> *g_pathLog = nullptr;
+struct PathLogRecord {
+    float *r = nullptr;
+    void Open(int bounces, int prim, int dim, const Ray &ray, Float etaScale) {
+        if (!g_pathLog) return;
+        g_pathLog->resize(g_pathLog->size() + MI_PATH_RECORD_FLOATS, 0.f);
+        r = g_pathLog->data() + g_pathLog->size() - MI_PATH_RECORD_FLOATS;
+        r[0] = (float)bounces; r[1] = (float)prim; r[2] = (float)dim; r[3] = 1.f;
+        r[4] = ray.o.x; r[5] = ray.o.y; r[6] = ray.o.z; r[7] = ray.tMax;
+        r[8] = ray.d.x; r[9] = ray.d.y; r[10] = ray.d.z; r[11] = etaScale;
+    }
+    void Close(bool ended, const Ray &next, int dim, Float etaScale, const Spec &beta, const Spec &L) {
+        if (!r) return;
+        r[3] = ended ? 1.f : 0.f;
+        r[12] = next.o.x; r[13] = next.o.y; r[14] = next.o.z; r[15] = (float)dim;
+        r[16] = next.d.x; r[17] = next.d.y; r[18] = next.d.z; r[19] = etaScale;
+        for (int k = 0; k < NS; ++k) { r[20 + k] = beta.c[k]; r[51 + k] = L.c[k]; }
+    }
+};
+
 static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r, Sampler &sampler, Counters &c,
                const RayDifferential &camDiff = RayDifferential()) {
     // path.cpp:64-188
@@ -610,6 +631,12 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
     for (bounces = 0;; ++bounces) {
         SurfaceInteraction isect;
         bool foundIntersection = scene.Intersect(ray, &isect, c);
+        PathLogRecord rec;
+        rec.Open(bounces, foundIntersection ? isect.prim : -1, sampler.dimension, ray, etaScale);
+        struct AtExit {   // whatever way the iteration ends, the record is closed with the state at that point
+            PathLogRecord &rec; const Ray &ray; Sampler &sampler; Float &etaScale; Spec &beta, &L; bool ended = true;
+            ~AtExit() { rec.Close(ended, ray, sampler.dimension, etaScale, beta, L); }
+        } atExit{rec, ray, sampler, etaScale, beta, L};
         if (bounces == 0 || specularBounce) {
             if (foundIntersection) L += beta * PrimLe(d, isect, -ray.d);
             else
@@ -622,6 +649,7 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
             ray = SpawnRay(isect, ray.d);
             diff.hasDifferentials = false;
             bounces--;
+            atExit.ended = false;
             continue;
         }
         const mi_material &mat = d.materials[matIdx];
@@ -669,6 +697,7 @@ static Spec Li(const Scene &scene, LightDistribution &lightDistrib, const Ray &r
             if (sampler.Get1D() < q) break;
             beta /= 1 - q;
         }
+        atExit.ended = false;
     }
     c.pathLengthSum += bounces;
     return L;
@@ -920,6 +949,20 @@ void oracle_li(const mi_scene_desc *desc, const int32_t *samples, int n, float *
     FillCounters(c, counters);
 }
 
+// Vertex-by-vertex log of one camera sample (record layout: include/mi_pt.h, MI_PATH_RECORD_FLOATS). Returns the number of records.
+int oracle_path_log(const mi_scene_desc *desc, int px, int py, int64_t sample, int max_records, float *records) {
+    std::vector<float> log;
+    g_pathLog = &log;
+    const int32_t smp[3] = {px, py, (int32_t)sample};
+    float out[NS];
+    mi_counters c;
+    oracle_li(desc, smp, 1, out, &c);
+    g_pathLog = nullptr;
+    const int n = std::min<int>(max_records, (int)(log.size() / MI_PATH_RECORD_FLOATS));
+    memcpy(records, log.data(), (size_t)n * MI_PATH_RECORD_FLOATS * sizeof(float));
+    return n;
+}
+
 // Camera rays for given samples: out = n x {o[3], d[3], tMax}.
 void oracle_camera_rays(const mi_scene_desc *desc, const int32_t *samples, int n, float *out) {
     Sampler sampler(*desc);
@@ -970,6 +1013,9 @@ void oracle_trace(const mi_scene_desc *desc, const float *rays, uint32_t n, int 
     }
     FillCounters(c, counters);
 }
+
+// libm evaluation mode of the oracle (o_math.h): 0 = the host's float functions, 1 = correctly rounded. Returns the previous mode.
+int oracle_set_libm(int mode) { const int old = g_libmMode; g_libmMode = mode ? 1 : 0; return old; }
 
 // ---- unit-level entry points for pinning against the reference's own tests
 float oracle_radical_inverse(const mi_scene_desc *desc, int base_index, uint64_t a) { return RadicalInverse(*desc, base_index, a); }

@@ -19,6 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NSPEC = 31
 MAX_BXDFS = 8
+PATH_RECORD_FLOATS = 96
 
 
 # ----------------------------------------------------------------------------
@@ -212,6 +213,7 @@ def hip_lib():
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
         lib.mi_pt_texture_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_light_distribution.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
+        lib.mi_pt_debug_path.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         _hip = lib
     return _hip
 
@@ -364,6 +366,15 @@ class PathIntegrator:
         if rc != 0:
             raise RuntimeError("mi_pt_light_distribution failed: %s" % hip_lib().mi_pt_last_error().decode())
         return func, fint
+
+    def debug_path(self, px, py, sample, max_records=64):
+        """Vertex-by-vertex state of one camera sample (records of PATH_RECORD_FLOATS floats, include/mi_pt.h)."""
+        rec = np.zeros((max_records, PATH_RECORD_FLOATS), np.float32)
+        n = C.c_int32()
+        rc = hip_lib().mi_pt_debug_path(self._h, int(px), int(py), int(sample), max_records, _fptr(rec), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("mi_pt_debug_path failed: %s" % hip_lib().mi_pt_last_error().decode())
+        return rec[: n.value]
 
     def texture_lookup(self, tex, queries):
         """MIPMap::Lookup on the device: queries [n, 6] = (s, t, dsdx, dtdx, dsdy, dtdy) -> rgb [n, 3]."""

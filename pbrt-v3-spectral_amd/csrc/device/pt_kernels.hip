@@ -2030,6 +2030,45 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     return MI_OK;
 }
 
+// The launches of one wavefront iteration, shared by RenderSub and the path-dump tool.
+static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid) {
+    const DScene &s = pt->scene;
+    const dim3 block(BLOCK);
+    hipStream_t st = sub.stream;
+    if (pt->hasAlphaMasks) {
+        if (mode == 0) hipLaunchKernelGGL((k_trav<0, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else if (mode == 1) hipLaunchKernelGGL((k_trav<1, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<2, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_trav<0, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else if (mode == 1) hipLaunchKernelGGL((k_trav<1, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<2, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+    }
+}
+
+static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
+    const DScene &s = pt->scene;
+    const dim3 block(BLOCK);
+    hipStream_t st = sub.stream;
+    const dim3 shadeGrid(grid.x + MAX_CLASSES);
+    constexpr unsigned TM_GENERIC = TM_ALL & ~TM_TEXTURED;
+    if (pt->hasInfiniteLight) {
+        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+    } else {
+        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+    }
+    if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+    if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
+    if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
+    if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
+    if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
+    if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
+    if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
+    if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
+}
+
 // One sub-renderer = one path pool with its queues and counters on its own HIP stream.
 // mi_pt_render splits its tile shard over pt->subs.size() sub-renderers that run
 // concurrently (one host thread each): while one pool is in a traversal kernel's tail
@@ -2103,35 +2142,16 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         if (havePrev) harvest(set ^ 1, prevFull);
         if (alive == 0) { harvest(set, false); break; }
         HIPCHK(hipEventRecord(ev[7], st));
-        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<0, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_trav<0, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        LaunchTraversal(pt, sub, 0, travGrid);
         HIPCHK(hipEventRecord(ev[6], st));
         hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
-        const dim3 shadeGrid(grid.x + MAX_CLASSES);
-        constexpr unsigned TM_GENERIC = TM_ALL & ~TM_TEXTURED;
-        if (pt->hasInfiniteLight) {
-            if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
-            if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-        } else {
-            if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
-            if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-        }
-        if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
-        if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
-        if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
-        if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
-        if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
-        if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
-        if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
-        if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
+        LaunchShade(pt, sub, grid);
         HIPCHK(hipEventRecord(ev[3], st));
-        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<1, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_trav<1, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        LaunchTraversal(pt, sub, 1, travGrid);
         hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[4], st));
-        if (pt->hasAlphaMasks) hipLaunchKernelGGL((k_trav<2, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_trav<2, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        LaunchTraversal(pt, sub, 2, travGrid);
         hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());   // a launch of this iteration that was refused (bad configuration) stops the render here
@@ -2258,6 +2278,91 @@ int mi_pt_light_distribution(mi_pt *pt, float *func, float *func_int, uint64_t c
     HIPCHK(hipSetDevice(pt->device));
     if (func) HIPCHK(hipMemcpy(func, s.ldFunc, nVox * s.nLights * sizeof(float), hipMemcpyDeviceToHost));
     if (func_int) HIPCHK(hipMemcpy(func_int, s.ldFuncInt, nVox * sizeof(float), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// Parity tool: one camera sample through the wavefront pipeline with a 256-slot pool, the path's state copied out at the
+// kernel boundaries of every iteration (layout of a record: include/mi_pt.h, MI_PATH_RECORD_FLOATS).
+int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t max_records, float *records, int32_t *n_records) {
+    if (!pt || !records || !n_records || max_records < 1) { g_err = "null argument"; return MI_ERR_INVALID; }
+    *n_records = 0;
+    HIPCHK(hipSetDevice(pt->device));
+    const DScene saved = pt->scene;
+    struct Restore { mi_pt *pt; DScene s; ~Restore() { pt->scene = s; } } restore{pt, saved};
+    DScene &s = pt->scene;
+    if (px < s.sampleBounds[0] || px >= s.sampleBounds[2] || py < s.sampleBounds[1] || py >= s.sampleBounds[3]) { g_err = "pixel outside the sample bounds"; return MI_ERR_INVALID; }
+    s.pixelBounds[0] = px; s.pixelBounds[1] = py; s.pixelBounds[2] = px + 1; s.pixelBounds[3] = py + 1;
+    SubRenderer &sub = pt->subs[0];
+    hipStream_t st = sub.stream;
+    WorkDesc wd{};
+    wd.nTilesX = (s.sampleBounds[2] - s.sampleBounds[0] + 15) / 16;
+    wd.nTilesY = (s.sampleBounds[3] - s.sampleBounds[1] + 15) / 16;
+    wd.shardIndex = ((py - s.sampleBounds[1]) / 16) * wd.nTilesX + (px - s.sampleBounds[0]) / 16;   // the pixel's tile alone
+    wd.shardCount = wd.nTilesX * wd.nTilesY;
+    wd.nTilesShard = 1;
+    wd.spp = 1;
+    wd.sampleBegin = sample;
+    wd.totalWork = 256;
+    const uint32_t poolN = BLOCK;
+    int rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
+    if (rc != MI_OK) return rc;
+    HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));
+    HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));
+    const dim3 grid(1), block(BLOCK), travGrid(1);
+    const Pool &pool = sub.pool;
+    std::vector<int> flags(poolN);
+    auto F4 = [&](int plane, uint32_t slot, float *dst) { return hipMemcpy(dst, pool.r + (size_t)plane * poolN + slot, 16, hipMemcpyDeviceToHost); };
+    auto I1 = [&](int plane, uint32_t slot, int *dst) { return hipMemcpy(dst, pool.i + (size_t)plane * poolN + slot, 4, hipMemcpyDeviceToHost); };
+    auto Spec = [&](int set, uint32_t slot, float *dst31) {
+        float line[32];
+        hipError_t e = hipMemcpy(line, pool.q + (((size_t)(set >> 3) * poolN + slot) << 3), 128, hipMemcpyDeviceToHost);
+        memcpy(dst31, line, 31 * sizeof(float));
+        return e;
+    };
+    int slot = -1;
+    for (int it = 0; it < 4096; ++it) {
+        HIPCHK(hipMemsetAsync(&sub.ctr->alive, 0, ITER_CLEAR_BYTES, st));
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, sub.pool, pt->film, sub.ctr, wd);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(flags.data(), pool.i + (size_t)I_FLAGS * poolN, poolN * sizeof(int), hipMemcpyDeviceToHost));
+        slot = -1;
+        for (uint32_t k = 0; k < poolN; ++k) if (flags[k] & F_ALIVE) { slot = (int)k; break; }
+        if (slot < 0) break;
+        if (*n_records >= max_records) break;
+        float *r = records + (size_t)(*n_records) * MI_PATH_RECORD_FLOATS;
+        for (int k = 0; k < MI_PATH_RECORD_FLOATS; ++k) r[k] = 0.f;
+        LaunchTraversal(pt, sub, 0, travGrid);
+        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipStreamSynchronize(st));
+        int bounces = 0, prim = -1, dim = 0;
+        float ray0[4], ray1[4], hit[4];
+        HIPCHK(I1(I_BOUNCES, slot, &bounces)); HIPCHK(I1(I_HITPRIM, slot, &prim)); HIPCHK(I1(I_DIM, slot, &dim));
+        HIPCHK(F4(R_RAY0, slot, ray0)); HIPCHK(F4(R_RAY1, slot, ray1)); HIPCHK(F4(R_HIT, slot, hit));
+        r[0] = (float)bounces; r[1] = (float)prim; r[2] = (float)dim;
+        r[4] = ray0[0]; r[5] = ray0[1]; r[6] = ray0[2]; r[7] = prim >= 0 ? hit[0] : ray0[3];
+        r[8] = ray1[0]; r[9] = ray1[1]; r[10] = ray1[2]; r[11] = ray1[3];
+        LaunchShade(pt, sub, grid);
+        LaunchTraversal(pt, sub, 1, travGrid);
+        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
+        LaunchTraversal(pt, sub, 2, travGrid);
+        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        int fl = 0;
+        HIPCHK(I1(I_FLAGS, slot, &fl)); HIPCHK(I1(I_DIM, slot, &dim));
+        HIPCHK(F4(R_RAY0, slot, ray0)); HIPCHK(F4(R_RAY1, slot, ray1));
+        r[3] = (fl & F_ALIVE) ? 0.f : 1.f;
+        r[12] = ray0[0]; r[13] = ray0[1]; r[14] = ray0[2]; r[15] = (float)dim;
+        r[16] = ray1[0]; r[17] = ray1[1]; r[18] = ray1[2]; r[19] = ray1[3];
+        if (fl & F_BETA_ONE) for (int k = 0; k < 31; ++k) r[20 + k] = 1.f;
+        else HIPCHK(Spec(Q_BETA, slot, r + 20));
+        if (!(fl & F_L_ZERO)) HIPCHK(Spec(Q_L, slot, r + 51));
+        ++*n_records;
+    }
+    FreePool(sub.pool);   // the next render sizes its own
+    sub.poolQuadPlanes = 0;
+    HIPCHK(hipMemset(pt->film, 0, pt->nPix * 32 * sizeof(float)));
     return MI_OK;
 }
 

@@ -37,6 +37,7 @@ def lib():
         l.oracle_light_pmf.argtypes = [D, F, F]
         l.oracle_light_voxel.argtypes = [D, C.POINTER(C.c_int32), F, F]
         l.oracle_light_table.argtypes = [D, C.c_int, F, F]
+        l.oracle_path_log.argtypes = [D, C.c_int, C.c_int, C.c_int64, C.c_int, F]
         _lib = l
     return _lib
 
@@ -104,3 +105,27 @@ def light_table(scene, n_threads=None):
     fint = np.zeros((nz, ny, nx), np.float32)
     lib().oracle_light_table(scene.desc_ptr, n_threads or os.cpu_count() or 1, _f(func), _f(fint))
     return func, fint
+
+
+def path_log(scene, px, py, sample, max_records=64):
+    """Vertex-by-vertex log of one camera sample (same record layout as PathIntegrator.debug_path)."""
+    rec = np.zeros((max_records, pt.PATH_RECORD_FLOATS), np.float32)
+    n = lib().oracle_path_log(scene.desc_ptr, int(px), int(py), int(sample), max_records, _f(rec))
+    return rec[:n]
+
+
+def set_libm(mode):
+    """libm evaluation mode of the oracle (oracle/o_math.h): 0 = the host's float functions, as the reference binary calls
+    them (default; every pin against the reference's own numbers); 1 = correctly rounded, which is what the device
+    computes (device-vs-oracle parity). Returns the previous mode."""
+    return lib().oracle_set_libm(int(mode))
+
+
+class exact_libm:
+    """with ob.exact_libm(): ... -- the oracle evaluates sin / cos / acos / atan2 / log / pow correctly rounded inside."""
+
+    def __enter__(self):
+        self._old = set_libm(1)
+
+    def __exit__(self, *a):
+        set_libm(self._old)

@@ -1,21 +1,46 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle. Run on the GPU box
 with `pytest -m gpu`.
 
-Tolerances. The device evaluates the same arithmetic in the same order (no FMA
-contraction, IEEE divide/sqrt, libm calls rounded once from double), so almost every
-path takes identical decisions; the few that do not (a libm result differing in the last
-bit near a discrete decision) change a pixel by O(L/spp). Integer results (hit primitive,
-camera-ray count, filter weights) are compared exactly; ray counters within 1e-4
-relative; films with the metric of BASELINE.json / SURVEY 8d: image-wide relative L2
-and per-pixel L2 normalised by the mean radiance, thresholds written at each test.
+Two comparisons, because the reference's result depends on the C library: it calls std::sin(float), std::acos(float),
+... whose last bit glibc rounds faithfully but not always to nearest, and a path amplifies such a bit (a refraction
+direction one ulp off, a Russian-roulette test against a throughput of 1.0000001) into a different path in O(1e-4) of the
+samples (tools/diag/path_compare.py shows them vertex by vertex).
+
+ * EXACT: the oracle with correctly rounded libm calls (`ob.exact_libm()`, oracle/o_math.h mode 1) -- the arithmetic the
+   device implements (d_math.h). Here device and oracle take the same decisions in every path: counters are compared
+   (almost) exactly and films to float accumulation order. A difference in this mode is a defect.
+ * REFERENCE LIBM: the oracle as the reference binary runs on this host (glibc's float functions; the mode in which the
+   oracle reproduces the reference's own counters exactly, tests/test_oracle_pins.py). The device is held to
+   BASELINE.json's target against it: per-pixel L2 < 1e-3 of the mean radiance, image relative L2 < 1e-4, at the
+   BASELINE sample counts (tests/test_golden.py, and the killeroo tests below).
+
+Integer results (hit primitive, camera-ray count, filter weights) are compared exactly in both.
+The measured numbers of every comparison are written to gpurun_out/parity_metrics.json.
 """
+import atexit
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import KILLEROO, CORNELL
+from conftest import KILLEROO, CORNELL, ROOT
 import scenes_text as st
 
 pytestmark = pytest.mark.gpu
+
+METRICS = []
+
+
+@atexit.register
+def _dump_metrics():
+    if METRICS:
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "parity_metrics.json"), "w") as fh:
+                json.dump(METRICS, fh, indent=1)
+        except OSError:
+            pass
 
 
 def _rel_l2(a, b):
@@ -28,11 +53,51 @@ def _pixel_l2(a, b, spp):
     return np.sqrt((d ** 2).mean(axis=2)) / spp
 
 
-def _check_counters(c, o, tol=1e-4):
+COUNTER_KEYS = ("regular_rays", "shadow_rays", "total_paths", "zero_radiance_paths", "path_length_sum")
+
+
+def _check_counters(c, o, tol=1e-4, slack=3):
     assert c["camera_rays"] == o["camera_rays"]
-    for k in ("regular_rays", "shadow_rays", "total_paths", "zero_radiance_paths", "path_length_sum"):
-        assert abs(c[k] - o[k]) <= tol * o[k] + 3, (k, c[k], o[k])
+    for k in COUNTER_KEYS:
+        assert abs(c[k] - o[k]) <= tol * o[k] + slack, (k, c[k], o[k])
     assert c["bad_samples"] == o["bad_samples"] == 0
+
+
+def _parity(pt, ob, s, name, exact=True, rel_tol=None, counter_tol=None, weights_exact=True):
+    """Render `s` on the device and with the oracle, record the measured differences, assert the bar of the mode.
+    EXACT mode bar: counters equal (2 counts of slack: the only arithmetic not shared is DivBy's reciprocal form, one ulp in
+    2^-22 of the quotients, d_math.h; measured difference: 0 in every test), image relative L2 < 1e-6 (float atomics:
+    accumulation order; measured <= 2.5e-7), every pixel within 2e-4 x mean radiance (measured <= 4e-5; the target is 1e-3).
+    REFERENCE-LIBM bar: what the caller passes (the BASELINE target at BASELINE sample counts)."""
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    if exact:
+        with ob.exact_libm():
+            ofilm, oweight, oc, _ = ob.render(s)
+    else:
+        ofilm, oweight, oc, _ = ob.render(s)
+    c, o = integ.counters.as_dict(), oc.as_dict()
+    spp = max(1, s.spp)
+    l2 = _pixel_l2(film, ofilm, spp)
+    mean = max(float(ofilm.mean()) / spp, 1e-12)
+    m = {"test": name, "mode": "exact" if exact else "reference-libm", "rel_l2": _rel_l2(film, ofilm),
+         "pixels": int(l2.size), "pixels_over_1e-3_mean": int((l2 > 1e-3 * mean).sum()), "max_pixel_l2_over_mean": float(l2.max() / mean),
+         "counter_diff": {k: int(c[k] - o[k]) for k in COUNTER_KEYS}, "counters": {k: int(o[k]) for k in COUNTER_KEYS},
+         "camera_rays": int(o["camera_rays"])}
+    METRICS.append(m)
+    assert not np.isnan(film).any()
+    if weights_exact:
+        assert np.array_equal(weight, oweight)
+    else:
+        assert np.allclose(weight, oweight, rtol=1e-5, atol=1e-6)
+    if exact:
+        _check_counters(c, o, tol=counter_tol if counter_tol is not None else 0.0, slack=2)
+        assert m["rel_l2"] < (rel_tol if rel_tol is not None else 1e-6), m
+        assert m["max_pixel_l2_over_mean"] < 2e-4, m
+    else:
+        _check_counters(c, o, tol=counter_tol if counter_tol is not None else 1e-4)
+        assert m["rel_l2"] < (rel_tol if rel_tol is not None else 1e-4), m
+    return film, weight, integ, ofilm, oweight, oc
 
 
 def test_traversal_kernel_matches_oracle_bit_exactly(pt, ob):
@@ -59,17 +124,14 @@ def test_traversal_kernel_matches_oracle_bit_exactly(pt, ob):
 def test_killeroo_full_size_low_spp_against_oracle(pt, ob):
     """700x700, 4 spp (the size of BASELINE configs 1-2): counters, weights, film."""
     s = pt.Scene(KILLEROO, spp=4)
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict())
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "killeroo 700x700 4spp")
     assert integ.counters.camera_rays == 700 * 700 * 4
-    assert np.array_equal(weight, oweight)          # filter-weight sums are exact
-    assert _rel_l2(film, ofilm) < 1e-4              # image-wide relative L2
+    # and against the oracle as the reference binary runs here (glibc libm): at 4 spp one diverged path moves a pixel by
+    # ~L/4, so the per-pixel target is met by all but a handful of pixels (measured 2e-5 of them; 1024 spp: test_golden.py)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "killeroo 700x700 4spp", exact=False)
     l2 = _pixel_l2(film, ofilm, 4)
     mean = ofilm.mean() / 4
-    # at 4 spp one diverged path moves a pixel by ~L/4: allow 0.1 % of the pixels
-    assert (l2 > 1e-3 * mean).mean() < 1e-3
+    assert (l2 > 1e-3 * mean).mean() < 2e-4
     assert np.median(l2) < 1e-6 * mean
 
 
@@ -80,16 +142,15 @@ def test_killeroo_64spp_crop_meets_the_l2_target(pt, ob):
     crop = (0.375, 0.625, 0.5, 0.75)
     s = pt.Scene(KILLEROO, spp=64, crop=crop)
     assert s.film_size == (175, 175)
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict())
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 1e-4
+    _parity(pt, ob, s, "killeroo 64spp crop")
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "killeroo 64spp crop", exact=False)
     l2 = _pixel_l2(film, ofilm, 64)
     mean = ofilm.mean() / 64
-    assert (l2 > 1e-3 * mean).mean() < 2e-3   # pixels above the per-pixel target
-    assert l2.mean() < 1e-4 * mean
+    # pixels above the per-pixel target against the glibc-libm oracle: measured 1.2e-3 of this crop at 64 spp (its mean
+    # radiance is 1/16 of the frame's; 1.4e-5 of the full frame), none of them far: a diverged path is one sample of 64
+    assert (l2 > 1e-3 * mean).mean() < 3e-3
+    assert l2.max() < 0.05 * mean
+    assert l2.mean() < 1e-5 * mean
 
 
 def test_sample_ranges_accumulate_to_the_same_film(pt, ob):
@@ -129,28 +190,28 @@ def test_material_zoo_glass_uber_disney_all_light_types(pt, ob, strategy):
     distant + spot lights, smooth normals, and the three light-selection strategies."""
     s = pt.Scene(text=st.material_zoo(res=96, spp=32, depth=6, strategy=strategy))
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=2e-3)
-    assert np.array_equal(weight, oweight)
-    assert not np.isnan(film).any()
-    assert _rel_l2(film, ofilm) < 5e-3   # specular chains amplify single-path divergence
-    l2 = _pixel_l2(film, ofilm, 32)
-    assert np.median(l2) < 1e-5 * (ofilm.mean() / 32)
+    _parity(pt, ob, s, "material zoo " + strategy)
+    # the per-voxel light tables behind "spatial" are the oracle's bit for bit
+    if strategy == "spatial":
+        integ = pt.CreatePathIntegrator(s)
+        dfunc, dfint = integ.light_distribution()
+        ofunc, ofint = ob.light_table(s)
+        assert np.array_equal(dfunc, ofunc, equal_nan=True) and np.array_equal(dfint, ofint, equal_nan=True)
+    # against the glibc-libm oracle a 96x96x32 render holds ~30 diverged samples: image L2 stays below 2e-4
+    _parity(pt, ob, s, "material zoo " + strategy, exact=False, rel_tol=2e-4, counter_tol=1e-4)
 
 
 def test_cornell_glass_sphere(pt, ob):
     """BASELINE config 3 scene at test size: dielectric sphere, two-triangle area light
     (spatial light distribution over 2 lights), maxdepth 8."""
     s = pt.Scene(CORNELL, spp=16, xres=128, yres=128)
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 2e-3
-    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "cornell glass 128x128 16spp")
+    dfunc, dfint = integ.light_distribution()
+    ofunc, ofint = ob.light_table(s)
+    assert np.array_equal(dfunc, ofunc, equal_nan=True) and np.array_equal(dfint, ofint, equal_nan=True)
+    # glibc-libm oracle: the glass sphere turns a last-bit difference of acosf / sinf in Sphere::Intersect into another
+    # path inside the sphere (2.7e-4 of the samples, each one sample of 16 in its pixel)
+    _parity(pt, ob, s, "cornell glass 128x128 16spp", exact=False, rel_tol=2e-3, counter_tol=1e-3)
 
 
 @pytest.mark.parametrize("text", [st.furnace_point(), st.furnace_area(), st.furnace_uber()])
@@ -176,12 +237,8 @@ def test_edge_cases_empty_scene_no_lights_crop_filter(pt, ob):
     txt = st.furnace_area(res=40, spp=4).replace('Sampler', 'PixelFilter "gaussian" "float xwidth" [2] "float ywidth" [2]\nSampler')
     txt = txt.replace('[40] "integer yresolution" [40]', '[40] "integer yresolution" [40] "float cropwindow" [.2 .8 .1 .9]')
     s = pt.Scene(text=txt)
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "gaussian filter + crop window", weights_exact=False)
     assert integ.counters.camera_rays == oc.camera_rays
-    assert np.allclose(weight, oweight, rtol=1e-5, atol=1e-6)
-    assert _rel_l2(film, ofilm) < 1e-4
     assert abs(float((film.sum(axis=(0, 1)) / weight.sum()).mean()) - 1.0) < 0.02
 
 
@@ -244,14 +301,8 @@ def test_procedural_many_mesh_scene_against_oracle(pt, ob, tmp_path):
         mps.write_scene(fh, 200_000, 96, 16, 7, 5)
     s = pt.Scene(str(path))
     assert s.stats["n_triangles"] == 200_002 and s.stats["n_lights"] == 5
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=5e-4)
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 1e-3
-    l2 = _pixel_l2(film, ofilm, 16)
-    assert np.median(l2) < 1e-6 * ofilm.mean() / 16
+    _parity(pt, ob, s, "procedural 200k triangles 96x96 16spp")
+    _parity(pt, ob, s, "procedural 200k triangles 96x96 16spp", exact=False, rel_tol=1e-3, counter_tol=5e-4)
 
 
 def _killeroo_spectralpath(pt, n_bands, **kw):
@@ -267,14 +318,9 @@ def test_spectralpath_bands_against_oracle(pt, ob, n_bands):
     consecutive Halton dimensions, band s supplying bins [round(31/n)*s, min(round(31/n)*(s+1), 31))."""
     s = _killeroo_spectralpath(pt, n_bands, spp=8, xres=96, yres=96)
     assert s.desc.integrator.n_ca_bands == n_bands
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "spectralpath %d bands" % n_bands)
     c = integ.counters.as_dict()
-    assert c["camera_rays"] == 96 * 96 * 8 * n_bands      # one camera ray per band
-    _check_counters(c, oc.as_dict(), tol=5e-4)
-    assert np.array_equal(weight, oweight)                 # one film sample per camera sample
-    assert _rel_l2(film, ofilm) < 1e-4
+    assert c["camera_rays"] == 96 * 96 * 8 * n_bands      # one camera ray per band; one film sample per camera sample (weights exact)
     if n_bands == 3:                                       # round(31/3) = 10: bin 30 is never assigned
         assert not film[..., 30].any() and film[..., 29].any()
 
@@ -312,13 +358,7 @@ def test_camera_film_filter_and_integrator_parameters(pt, ob, variant):
         txt = txt.replace(a, b, 1)
     s = pt.Scene(text=txt)
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.allclose(weight, oweight, rtol=1e-5, atol=1e-6)
-    assert _rel_l2(film, ofilm) < 2e-3
-    assert np.median(_pixel_l2(film, ofilm, 8)) <= 1e-5 * max(float(ofilm.mean()) / 8, 1e-9)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "zoo variant " + variant, weights_exact=False)
     if variant == "pixelbounds":
         assert not weight[:5].any() and not weight[:, :10].any() and weight[5:30, 10:40].all()
     if variant == "maxdepth0":
@@ -333,15 +373,11 @@ def test_infinite_area_light_against_oracle(pt, ob, tmp_path, kind, strategy):
     st.write_env_pfm(str(tmp_path / "env.pfm"))
     s = pt.Scene(text=st.zoo_with_infinite_light(kind, strategy=strategy), base_dir=str(tmp_path))
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.array_equal(weight, oweight)
-    # several lights + "spatial": the per-voxel pmfs are estimated on both sides from 128 Sample_Li calls, a last-bit
-    # difference there flips a few light choices (as in the material-zoo test above)
-    assert _rel_l2(film, ofilm) < (1e-2 if (strategy == "spatial" and kind != "only_env") else 2e-4)
-    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "infinite light %s %s" % (kind, strategy))
+    if strategy == "spatial":   # (the tables include the environment light's estimates: Sample_Li through the Distribution2D)
+        dfunc, dfint = integ.light_distribution()
+        ofunc, ofint = ob.light_table(s)
+        assert np.array_equal(dfunc, ofunc, equal_nan=True) and np.array_equal(dfint, ofint, equal_nan=True)
     assert film[:8].mean() > 0           # the sky is visible above the back wall: escaped camera rays see Le
 
 
@@ -354,13 +390,7 @@ def test_image_textures_against_oracle(pt, ob, tmp_path, lens):
     st.write_texture_files(str(tmp_path))
     s = pt.Scene(text=st.textured_zoo(res=64, spp=16, lens=lens), base_dir=str(tmp_path))
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 2e-4
-    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "textured zoo lens=%s" % lens)
     # the textures show: the ground's chequer pattern makes neighbouring pixels differ far more than noise would
     ground = film[40:60, 8:56].sum(axis=2)
     assert ground.std() > 0.2 * ground.mean()
@@ -372,13 +402,7 @@ def test_alpha_masks_against_oracle(pt, ob, tmp_path):
     st.write_alpha_png(str(tmp_path))
     s = pt.Scene(text=st.alpha_scene(), base_dir=str(tmp_path))
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 2e-4
-    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "alpha masks")
     # recorded rays through the cut-out panel: same hits on both sides, closest-hit and any-hit
     rng = np.random.default_rng(3)
     n = 4000
@@ -402,13 +426,7 @@ def test_bump_mapping_against_oracle(pt, ob, tmp_path):
     st.write_texture_files(str(tmp_path))
     s = pt.Scene(text=st.bump_scene(), base_dir=str(tmp_path))
     assert s.errors == []
-    integ = pt.CreatePathIntegrator(s)
-    film, weight = integ.Render()
-    ofilm, oweight, oc, _ = ob.render(s)
-    _check_counters(integ.counters.as_dict(), oc.as_dict(), tol=1e-3)
-    assert np.array_equal(weight, oweight)
-    assert _rel_l2(film, ofilm) < 2e-4
-    assert np.median(_pixel_l2(film, ofilm, 16)) < 1e-5 * (ofilm.mean() / 16)
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "bump mapping")
     # and the bump map does something: without it the render differs visibly
     flat = pt.Scene(text=st.bump_scene().replace('"texture bumpmap" "bumps_tri"', "").replace('"texture bumpmap" "bumps"', ""), base_dir=str(tmp_path))
     ff, _, _, _ = ob.render(flat)
@@ -417,8 +435,8 @@ def test_bump_mapping_against_oracle(pt, ob, tmp_path):
 
 def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
     """MIPMap::Lookup on the device against the oracle, query by query (mi_pt_texture_lookup / oracle_texture_lookup): EWA with
-    random anisotropic footprints, trilinear, unfiltered, the three wrap modes, coordinates outside [0, 1]. Equal bits are
-    expected except where the level of detail rests on logf's last bit (glibc's logf is not correctly rounded everywhere)."""
+    random anisotropic footprints, trilinear, unfiltered, the three wrap modes, coordinates outside [0, 1]. Equal bits against
+    the oracle with a correctly rounded logf; against glibc's logf the level of detail differs in the last bit now and then."""
     st.write_texture_files(str(tmp_path))
     s = pt.Scene(text=st.textured_zoo(res=16, spp=1), base_dir=str(tmp_path))
     assert s.errors == []
@@ -435,33 +453,25 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
         q[: n // 10, 2:6] = 0          # zero footprints
         q[n // 10: n // 5, 4:6] = 0    # degenerate ellipses
         dev = integ.texture_lookup(tex, q)
+        with ob.exact_libm():   # (the level of detail rests on logf: correctly rounded on both sides)
+            ref = np.array([ob.texture_lookup(s, tex, q[i, 0:2], q[i, 2:4], q[i, 4:6])[0] for i in range(n)], np.float32)
+        assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32)), (tex, np.abs(dev - ref).max())
         ref = np.array([ob.texture_lookup(s, tex, q[i, 0:2], q[i, 2:4], q[i, 4:6])[0] for i in range(n)], np.float32)
         same = (dev.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
-        assert same.mean() > 0.995, (tex, same.mean())
+        assert same.mean() > 0.995, (tex, same.mean())   # glibc's logf: a different last bit in < 0.5 % of the lookups
         assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
 
 
 def test_random_scenes_against_oracle(pt, ob, tmp_path):
     """Fuzz: 24 seeded random scenes over the whole supported feature set (scenes_text.random_scene) through the HIP path and
-    the oracle. Per scene: identical filter weights, ray counters within 2e-3, image relative L2 below 2e-3 (a 32x32x8
-    render has few samples: a handful of paths whose libm rounding or spatial-pmf last bit differs moves more than at
-    full size), no NaNs."""
+    the oracle (exact mode: same decisions in every path). Per scene: identical filter weights, ray counters equal, image
+    relative L2 at the float-accumulation level, no NaNs."""
     st.write_texture_files(str(tmp_path))
     st.write_alpha_png(str(tmp_path))
     worst = []
     for seed in range(24):
         s = pt.Scene(text=st.random_scene(seed), base_dir=str(tmp_path))
         assert s.errors == [], (seed, s.errors)
-        integ = pt.CreatePathIntegrator(s)
-        film, weight = integ.Render()
-        ofilm, oweight, oc, _ = ob.render(s)
-        assert not np.isnan(film).any(), seed
-        assert np.allclose(weight, oweight, rtol=1e-5, atol=1e-6), seed
-        c, o = integ.counters.as_dict(), oc.as_dict()
-        assert c["camera_rays"] == o["camera_rays"], seed
-        for k in ("regular_rays", "shadow_rays", "total_paths", "zero_radiance_paths", "path_length_sum"):
-            assert abs(c[k] - o[k]) <= 2e-3 * o[k] + 4, (seed, k, c[k], o[k])
-        rel = _rel_l2(film, ofilm)
-        worst.append((rel, seed))
-        assert rel < 2e-3, (seed, rel)
-    assert np.median([r for r, _ in worst]) < 1e-4, sorted(worst)[-5:]
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "random scene %d" % seed, weights_exact=False)
+        worst.append((_rel_l2(film, ofilm), seed))
+    assert np.median([r for r, _ in worst]) < 1e-6, sorted(worst)[-5:]

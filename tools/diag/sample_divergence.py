@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import pbrt_v3_spectral_amd as pt, oracle_binding as ob, scenes_text as st
 
+ob.set_libm(int(os.environ.get("ORACLE_LIBM", "1")))   # 1: correctly rounded libm in the oracle, like the device
 tmp = tempfile.mkdtemp()
 st.write_env_pfm(os.path.join(tmp, "env.pfm"))
 
