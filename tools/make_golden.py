@@ -13,6 +13,8 @@ they pin the oracle itself against regressions.
   textured_zoo_64spp.npz      the image-textured material zoo of tests/scenes_text.py (64x64, 64 spp): image textures of
                               three file formats, checkerboards, bump maps, textured spheres
   cornell_4096spp_crop.npz    BASELINE configs[2] at its full sample count: 512x512, maxdepth 8, 4096 spp, the same crop
+  killeroo_1024spp_tiles.npz  BASELINE configs[1] as the FULL 700x700 frame at 1024 spp: the film of every 64th 16x16 tile
+  cornell_4096spp_tiles.npz   BASELINE configs[2] as the FULL 512x512 frame at 4096 spp, maxdepth 8: every 64th tile
   procedural_10M_256spp.npz   BASELINE configs[3] stand-in at full size (tools/make_procedural_scene.py, 10 000 002
                               triangles, 700x700, 256 spp): the films of every 64th 16x16 tile (shard 0 of 64) and 8192
                               recorded rays (camera rays + random rays through the scene) with their hits
@@ -88,24 +90,33 @@ def procedural_rays(scene, n=4096, seed=13):
     return np.concatenate([cam, np.concatenate([o, dr, tmax[:, None]], axis=1)]).astype(np.float32)
 
 
+def tile_fixture(path, s, shard_count, rays=None):
+    """Every shard_count-th 16x16 tile of the FULL frame (tile_id % shard_count == 0, the multi-GPU decomposition): the
+    same sampler, film and Halton indexing as the whole frame -- a crop window would change the sampler's resolution
+    (halton.cpp:75-85) and with it every sample. Stored sparsely: the pixels the shard's samples reach."""
+    spp = s.spp
+    film, weight, d, film_x, dx, secs = both_modes(s, shard_index=0, shard_count=shard_count)
+    ys, xs = np.nonzero(weight)
+    extra = {}
+    if rays is not None:
+        closest, _ = ob.trace(s, rays, any_hit=False)
+        anyhit, _ = ob.trace(s, rays, any_hit=True)
+        extra = dict(rays=rays, closest=closest.view(np.int32), anyhit=anyhit.view(np.int32)[:, 0])
+    np.savez_compressed(path, ys=ys.astype(np.int16), xs=xs.astype(np.int16), film=film[ys, xs], film_exact=film_x[ys, xs],
+                        weight=weight[ys, xs], spp=spp, shard_count=shard_count,
+                        counters=np.array([d[k] for k in sorted(d)], np.int64), counter_names=np.array(sorted(d)),
+                        counters_exact=np.array([dx[k] for k in sorted(d)], np.int64),
+                        n_triangles=s.stats["n_triangles"], interior_nodes=s.stats["interior_nodes"], **extra)
+    rel = float(np.sqrt(((film.astype(np.float64) - film_x) ** 2).sum() / (film_x.astype(np.float64) ** 2).sum()))
+    print("%s: %d pixels (%d camera rays), mean/spp %.6f, %.1f s; glibc vs exact libm: rel L2 %.2e, regular rays %+d" %
+          (os.path.basename(path), len(ys), d["camera_rays"], film[ys, xs].mean() / spp, secs, rel, d["regular_rays"] - dx["regular_rays"]))
+
+
 def procedural_fixture(path):
     import tempfile
     s = pt.Scene(procedural_scene(tempfile.mkdtemp()))
     assert s.stats["n_triangles"] == PROCEDURAL["tris"] + 2, s.stats
-    film, weight, d, film_x, dx, secs = both_modes(s, shard_index=0, shard_count=PROCEDURAL["shard_count"])
-    ys, xs = np.nonzero(weight)   # the pixels of the shard's tiles
-    rays = procedural_rays(s)
-    closest, _ = ob.trace(s, rays, any_hit=False)
-    anyhit, _ = ob.trace(s, rays, any_hit=True)
-    np.savez_compressed(path, ys=ys.astype(np.int16), xs=xs.astype(np.int16), film=film[ys, xs], film_exact=film_x[ys, xs],
-                        weight=weight[ys, xs], spp=PROCEDURAL["spp"], shard_count=PROCEDURAL["shard_count"],
-                        counters=np.array([d[k] for k in sorted(d)], np.int64), counter_names=np.array(sorted(d)),
-                        counters_exact=np.array([dx[k] for k in sorted(d)], np.int64),
-                        rays=rays, closest=closest.view(np.int32), anyhit=anyhit.view(np.int32)[:, 0],
-                        n_triangles=s.stats["n_triangles"], interior_nodes=s.stats["interior_nodes"])
-    print("%s: %d pixels of %d tiles, mean/spp %.6f, %d camera rays, %.1f s; %d of %d recorded rays hit" %
-          (os.path.basename(path), len(ys), len(ys) // 256, film[ys, xs].mean() / PROCEDURAL["spp"], d["camera_rays"], secs,
-           (closest.view(np.int32)[:, 0] >= 0).sum(), len(rays)))
+    tile_fixture(path, s, PROCEDURAL["shard_count"], rays=procedural_rays(s))
 
 
 def ray_fixture(path):
@@ -151,6 +162,8 @@ if __name__ == "__main__":
         "cornell_256spp_crop": lambda p: film_fixture(p, CORNELL, 256, CORNELL_CROP),
         "killeroo_1024spp_crop": lambda p: film_fixture(p, KILLEROO, 1024, KILLEROO_CROP),
         "cornell_4096spp_crop": lambda p: film_fixture(p, CORNELL, 4096, CORNELL_CROP),
+        "killeroo_1024spp_tiles": lambda p: tile_fixture(p, pt.Scene(KILLEROO, spp=1024), 64),
+        "cornell_4096spp_tiles": lambda p: tile_fixture(p, pt.Scene(CORNELL, spp=4096), 64),
         "procedural_10M_256spp": procedural_fixture,
     }
     for name, job in jobs.items():
