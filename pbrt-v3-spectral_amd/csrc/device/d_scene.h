@@ -27,7 +27,9 @@ namespace dpt {
 
 struct DScene {
     const float4 *nodes;
-    const float4 *wnodes;  // 64 B per interior node: both children's boxes + child links (see pt_kernels.hip)
+    const float4 *wnodes;  // wide nodes (see pt_kernels.hip): bvhWidth 2 -> 64 B per BVH2 interior node (both children's boxes);
+                           // bvhWidth 4 -> 128 B per two-level subtree (up to four grandchild boxes + the visit orders)
+    int bvhWidth;
     const float4 *primTri;
     const mi_prim *prims;
     const int32_t *triIndices;

@@ -239,6 +239,7 @@ struct TravSpill {
 struct RayCtx {  // per-lane ray constants
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     bool n0, n1, n2;
+    DEV int Octant() const { return (n0 ? 1 : 0) | (n1 ? 2 : 0) | (n2 ? 4 : 0); }
 };
 DEV void InitRayCtx(RayCtx &r, float ox, float oy, float oz, float dx, float dy, float dz) {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
@@ -274,6 +275,7 @@ struct TravState {
 };
 DEV void StackPush(TravSpill &sp, int lane, int &n, int node, int meta, float tmin) {
     TravLds &lds = TravStack();
+    if (n >= STACK_LDS + STACK_SPILL) return;   // (cannot happen: mi_pt_create bounds the depth of the tree it uploads)
     if (n < STACK_LDS) { lds.node[n][lane] = node; lds.meta[n][lane] = meta; lds.tmin[n][lane] = tmin; }
     else {
         // keep the LDS and the scratch path apart: merged into one store through a selected
@@ -294,37 +296,93 @@ DEV void StackPop(TravSpill &sp, int lane, int &n, int *node, int *meta, float *
         *node = nd; *meta = mt; *tmin = tm;
     }
 }
+// Open interior node `cur`: test its children's boxes, take the first one hit in the reference's visiting order, push the
+// others (with their entry distances) so that they pop in that order. Returns whether a child was taken.
+//
+// W = 2: a record per BVH2 interior node (both children's boxes). W = 4: a record per two-level subtree of the BVH2 -- the
+// boxes of up to four grandchildren (a child that is a leaf stands for itself) and, for each of the 8 sign combinations of
+// the ray direction, the order in which the reference's traversal would reach them (near child first at the subtree's
+// root by its split axis, then near grandchild first inside each child by the child's axis; bvh.cpp:686-692). The child's
+// own box is not tested: a ray that hits a grandchild's box hits the child's box (it contains it, and the slab arithmetic
+// is monotone), and the entry-distance re-validation at pop time is the only tMax-dependent part of the test. So the lane
+// enters the same leaves in the same order against the same tMax as the BVH2 traversal -- closest hits, equal-t ties and
+// the count of primitive tests are unchanged -- with half the dependent node fetches per ray.
+template <int W>
+DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, float tMax, TravSpill &spill, int lane, int &sp,
+                  int *tkChild, int *tkMeta, unsigned &nodeCount) {
+    if constexpr (W == 2) {
+        const float4 a = wnodes[4 * cur], b = wnodes[4 * cur + 1], c = wnodes[4 * cur + 2];
+        const float4 dd = wnodes[4 * cur + 3];
+        const int childL = __float_as_int(dd.x), childR = __float_as_int(dd.y);
+        const int metaL = __float_as_int(dd.z), metaR = __float_as_int(dd.w);
+        const bool haveR = (metaR & 0xffff) != 0xffff;
+        float tL, tR = 0;
+        const bool hitL = BoxTest(r, a.x, a.y, a.z, a.w, b.x, b.y, tMax, &tL);
+        const bool hitR = haveR && BoxTest(r, b.z, b.w, c.x, c.y, c.z, c.w, tMax, &tR);
+        nodeCount += haveR ? 2 : 0;
+        const int axis = (metaL >> 16) & 0xff;
+        const bool negAxis = (axis == 0) ? r.n0 : ((axis == 1) ? r.n1 : r.n2);
+        // near child first (bvh.cpp:686-692): left unless the ray runs against the split axis
+        const bool hitF = negAxis ? hitR : hitL, hitS = negAxis ? hitL : hitR;
+        const int chF = negAxis ? childR : childL, chS = negAxis ? childL : childR;
+        const int mtF = (negAxis ? metaR : metaL) & 0xffff, mtS = (negAxis ? metaL : metaR) & 0xffff;
+        const float tS = negAxis ? tL : tR;
+        if (hitF) {
+            *tkChild = chF; *tkMeta = mtF;
+            if (hitS) StackPush(spill, lane, sp, chS, mtS, tS);
+            return true;
+        }
+        if (hitS) { *tkChild = chS; *tkMeta = mtS; return true; }
+        return false;
+    } else {
+        const float4 *__restrict__ n = wnodes + 8 * (size_t)cur;
+        const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6], q7 = n[7];
+        const unsigned c01 = __float_as_uint(q7.x), c23 = __float_as_uint(q7.y);
+        const int cnt0 = (int)(c01 & 0xffffu), cnt1 = (int)(c01 >> 16), cnt2 = (int)(c23 & 0xffffu), cnt3 = (int)(c23 >> 16);
+        const bool have1 = cnt1 != 0xffff, have2 = cnt2 != 0xffff, have3 = cnt3 != 0xffff;
+        float t0, t1 = 0, t2 = 0, t3 = 0;
+        const bool h0 = BoxTest(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tMax, &t0);
+        const bool h1 = have1 && BoxTest(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tMax, &t1);
+        const bool h2 = have2 && BoxTest(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tMax, &t2);
+        const bool h3 = have3 && BoxTest(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tMax, &t3);
+        nodeCount += 1u + (have1 ? 1u : 0u) + (have2 ? 1u : 0u) + (have3 ? 1u : 0u);
+        const unsigned hm = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+        if (hm == 0u) return false;
+        const int oct = r.Octant();
+        const unsigned ordWord = (oct & 4) ? __float_as_uint(q7.w) : __float_as_uint(q7.z);
+        const unsigned perm = (ordWord >> (8 * (oct & 3))) & 0xffu;   // slot visited k-th at bits 2k..2k+1
+        const int l0 = __float_as_int(q6.x), l1 = __float_as_int(q6.y), l2 = __float_as_int(q6.z), l3 = __float_as_int(q6.w);
+        // from the last visited to the first: a slot that is hit displaces the candidate found so far onto the stack, so the
+        // stack receives the later ones first and the first one in order stays in hand
+        int cand = -1;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const int sl = (int)((perm >> (2 * k)) & 3u);
+            if ((hm >> sl) & 1u) {
+                if (cand >= 0) {
+                    const int lk = cand == 0 ? l0 : (cand == 1 ? l1 : (cand == 2 ? l2 : l3));
+                    const int ct = cand == 0 ? cnt0 : (cand == 1 ? cnt1 : (cand == 2 ? cnt2 : cnt3));
+                    const float tt = cand == 0 ? t0 : (cand == 1 ? t1 : (cand == 2 ? t2 : t3));
+                    StackPush(spill, lane, sp, lk, ct, tt);
+                }
+                cand = sl;
+            }
+        }
+        *tkChild = cand == 0 ? l0 : (cand == 1 ? l1 : (cand == 2 ? l2 : l3));
+        *tkMeta = cand == 0 ? cnt0 : (cand == 1 ? cnt1 : (cand == 2 ? cnt2 : cnt3));
+        return true;
+    }
+}
+
 // Advance until the lane holds a leaf (returns true with leafOffset/leafCount) or the
 // traversal is finished (returns false, st.cur == -1).
+template <int W>
 DEV bool NextLeaf(const float4 *__restrict__ wnodes, const RayCtx &r, float tMax, TravState &st, TravSpill &spill,
                   int lane, int *leafOffset, int *leafCount, unsigned &nodeCount) {
     while (st.cur != -1) {
         int tkChild = 0, tkMeta = 0;
         bool got = false;
-        if (st.cur >= 0) {
-            const float4 a = wnodes[4 * st.cur], b = wnodes[4 * st.cur + 1], c = wnodes[4 * st.cur + 2];
-            const float4 dd = wnodes[4 * st.cur + 3];
-            const int childL = __float_as_int(dd.x), childR = __float_as_int(dd.y);
-            const int metaL = __float_as_int(dd.z), metaR = __float_as_int(dd.w);
-            const bool haveR = (metaR & 0xffff) != 0xffff;
-            float tL, tR = 0;
-            const bool hitL = BoxTest(r, a.x, a.y, a.z, a.w, b.x, b.y, tMax, &tL);
-            const bool hitR = haveR && BoxTest(r, b.z, b.w, c.x, c.y, c.z, c.w, tMax, &tR);
-            nodeCount += haveR ? 2 : 0;
-            const int axis = (metaL >> 16) & 0xff;
-            const bool negAxis = (axis == 0) ? r.n0 : ((axis == 1) ? r.n1 : r.n2);
-            // near child first (bvh.cpp:686-692): left unless the ray runs against the split axis
-            const bool hitF = negAxis ? hitR : hitL, hitS = negAxis ? hitL : hitR;
-            const int chF = negAxis ? childR : childL, chS = negAxis ? childL : childR;
-            const int mtF = (negAxis ? metaR : metaL) & 0xffff, mtS = (negAxis ? metaL : metaR) & 0xffff;
-            const float tS = negAxis ? tL : tR;
-            if (hitF) {
-                tkChild = chF; tkMeta = mtF; got = true;
-                if (hitS) StackPush(spill, lane, st.sp, chS, mtS, tS);
-            } else if (hitS) {
-                tkChild = chS; tkMeta = mtS; got = true;
-            }
-        }
+        if (st.cur >= 0) got = OpenNode<W>(wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
         while (!got && st.sp > 0) {  // a popped node is entered only if still in front of tMax
             float t;
             StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
@@ -349,8 +407,8 @@ constexpr int MAX_PENDING_SPHERES = 3;
 
 // Plain per-ray traversal with inline quadric tests (mi_pt_trace and the overflow path
 // of ResolveQuadrics).
-template <bool ANY>
-DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
+template <bool ANY, int W>
+DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
     const int lane = threadIdx.x;
     RayCtx r;
     InitRayCtx(r, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
@@ -362,7 +420,7 @@ DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *
     int nPend = 0;
     const float4 *__restrict__ primTri = s.primTri;
     int leafOffset = 0, leafCount = 0;
-    while (NextLeaf(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount)) {
+    while (NextLeaf<W>(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount)) {
         for (int i = 0; i < leafCount; ++i) {
             const int prim = leafOffset + i;
             const float4 v0 = primTri[3 * prim];
@@ -410,6 +468,12 @@ DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *
     return found;
 }
 
+template <bool ANY>
+DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
+    if (s.bvhWidth == 4) return TraverseW<ANY, 4>(s, ro, rd, tMax, hit, nodeCount, triCount);
+    return TraverseW<ANY, 2>(s, ro, rd, tMax, hit, nodeCount, triCount);
+}
+
 DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si);
 
 // ------------------------------------------------------------------ persistent traversal
@@ -440,7 +504,7 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 #define MIPT_TRAV_WAVES_PER_EU 4
 #endif
 // ALPHA: the scene has meshes with alpha masks (the mask test is compiled into this instance only)
-template <int MODE, bool ALPHA>
+template <int MODE, bool ALPHA, int W>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
     const int lane = threadIdx.x;
@@ -525,27 +589,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             bool needPop = false, got = false, finished = false;
             int tkChild = 0, tkMeta = 0;
             if (walking) {
-                const float4 a = s.wnodes[4 * st.cur], b = s.wnodes[4 * st.cur + 1], c = s.wnodes[4 * st.cur + 2];
-                const float4 dd = s.wnodes[4 * st.cur + 3];
-                const int childL = __float_as_int(dd.x), childR = __float_as_int(dd.y);
-                const int metaL = __float_as_int(dd.z), metaR = __float_as_int(dd.w);
-                const bool haveR = (metaR & 0xffff) != 0xffff;
-                float tL, tR = 0;
-                const bool hitL = BoxTest(r, a.x, a.y, a.z, a.w, b.x, b.y, tMax, &tL);
-                const bool hitR = haveR && BoxTest(r, b.z, b.w, c.x, c.y, c.z, c.w, tMax, &tR);
-                nodeCount += haveR ? 2 : 0;
-                const int axis = (metaL >> 16) & 0xff;
-                const bool negAxis = (axis == 0) ? r.n0 : ((axis == 1) ? r.n1 : r.n2);
-                const bool hitF = negAxis ? hitR : hitL, hitS = negAxis ? hitL : hitR;
-                const int chF = negAxis ? childR : childL, chS = negAxis ? childL : childR;
-                const int mtF = (negAxis ? metaR : metaL) & 0xffff, mtS = (negAxis ? metaL : metaR) & 0xffff;
-                const float tS = negAxis ? tL : tR;
-                if (hitF) {
-                    tkChild = chF; tkMeta = mtF; got = true;
-                    if (hitS) StackPush(spill, lane, st.sp, chS, mtS, tS);
-                } else if (hitS) {
-                    tkChild = chS; tkMeta = mtS; got = true;
-                }
+                got = OpenNode<W>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
                 needPop = !got;
                 st.cur = -1;
             }
@@ -1713,7 +1757,109 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         UP((const float4 *)d->nodes, (size_t)d->n_nodes * 2, nodes);
         s.nodes = nodes;
     }
-    {   // wide nodes: one 64-B record per interior node with both children's boxes
+    s.bvhWidth = 4;   // MIPT_BVH_WIDTH=2: one record per BVH2 interior node, i.e. the reference's own node-visit counts
+    if (const char *e = getenv("MIPT_BVH_WIDTH")) s.bvhWidth = (atoi(e) == 2) ? 2 : 4;
+    if (s.bvhWidth == 4 && d->n_nodes > 0) {
+        // Wide-4 records (OpenNode<4>): one per two-level subtree of the host's BVH2, in depth-first order. Slots 0/1 are the
+        // left child's children (slot 0 alone = the left child itself when it is a leaf), slots 2/3 the right child's.
+        const uint32_t nN = d->n_nodes;
+        const mi_bvh_node *nodes = d->nodes;
+        std::vector<int32_t> widx(nN, -1);
+        std::vector<uint32_t> order;   // BVH2 roots of the records, in record order
+        {
+            std::vector<uint32_t> stack;
+            if (nodes[0].n_prims == 0) stack.push_back(0);
+            while (!stack.empty()) {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                widx[i] = (int32_t)order.size();
+                order.push_back(i);
+                uint32_t sub[4];
+                int nSub = 0;
+                const uint32_t ch[2] = {i + 1, (uint32_t)nodes[i].offset};
+                for (int c = 0; c < 2; ++c) {
+                    if (nodes[ch[c]].n_prims > 0) continue;
+                    const uint32_t g[2] = {ch[c] + 1, (uint32_t)nodes[ch[c]].offset};
+                    for (int k = 0; k < 2; ++k) if (nodes[g[k]].n_prims == 0) sub[nSub++] = g[k];
+                }
+                for (int k = nSub - 1; k >= 0; --k) stack.push_back(sub[k]);   // first slot's subtree next in memory
+            }
+        }
+        const size_t nWide = std::max<size_t>(order.size(), 1);
+        std::vector<float4> w(nWide * 8, float4{0, 0, 0, 0});
+        std::vector<int> need(nWide, 0);   // stack entries a ray can hold below this record (filled bottom-up)
+        auto setBox = [&](float4 *rec, int slot, const mi_bvh_node &c) {
+            float *f = (float *)rec + (slot < 2 ? 0 : 12) + (slot & 1) * 6;
+            f[0] = c.bmin[0]; f[1] = c.bmin[1]; f[2] = c.bmin[2]; f[3] = c.bmax[0]; f[4] = c.bmax[1]; f[5] = c.bmax[2];
+        };
+        auto finish = [&](float4 *rec, const int link[4], const unsigned cnt[4], int axisRoot, const int groupN[2], const int groupAxis[2]) {
+            memcpy(&rec[6], link, 16);
+            const unsigned c01 = cnt[0] | (cnt[1] << 16), c23 = cnt[2] | (cnt[3] << 16);
+            unsigned ord[2] = {0, 0};
+            for (int oct = 0; oct < 8; ++oct) {
+                auto neg = [&](int axis) { return ((oct >> axis) & 1) != 0; };
+                int seq[4], n = 0;
+                bool used[4] = {false, false, false, false};
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int g = (neg(axisRoot) ? 1 : 0) ^ pass;   // near child's group first (bvh.cpp:686-692)
+                    const int base = 2 * g;
+                    if (groupN[g] == 2) {
+                        const bool swap = neg(groupAxis[g]);
+                        seq[n++] = base + (swap ? 1 : 0);
+                        seq[n++] = base + (swap ? 0 : 1);
+                    } else if (groupN[g] == 1) seq[n++] = base;
+                }
+                for (int k = 0; k < n; ++k) used[seq[k]] = true;
+                for (int sl = 0; sl < 4 && n < 4; ++sl) if (!used[sl]) seq[n++] = sl;   // absent slots last (never hit)
+                unsigned perm = 0;
+                for (int k = 0; k < 4; ++k) perm |= (unsigned)seq[k] << (2 * k);
+                ord[oct >> 2] |= perm << (8 * (oct & 3));
+            }
+            memcpy(&rec[7].x, &c01, 4); memcpy(&rec[7].y, &c23, 4);
+            memcpy(&rec[7].z, &ord[0], 4); memcpy(&rec[7].w, &ord[1], 4);
+        };
+        if (nodes[0].n_prims > 0) {   // single-leaf tree: the root itself in slot 0
+            int link[4] = {nodes[0].offset, 0, 0, 0};
+            unsigned cnt[4] = {nodes[0].n_prims, 0xffffu, 0xffffu, 0xffffu};
+            setBox(&w[0], 0, nodes[0]);
+            const int gN[2] = {1, 0}, gA[2] = {0, 0};
+            finish(&w[0], link, cnt, 0, gN, gA);
+        } else {
+            for (size_t r = order.size(); r-- > 0;) {   // records in reverse: a child record's stack need is known before its parent's
+                const uint32_t i = order[r];
+                float4 *rec = &w[r * 8];
+                int link[4] = {0, 0, 0, 0};
+                unsigned cnt[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+                int gN[2] = {0, 0}, gA[2] = {0, 0}, below = 0, present = 0;
+                const uint32_t ch[2] = {i + 1, (uint32_t)nodes[i].offset};
+                for (int c = 0; c < 2; ++c) {
+                    const mi_bvh_node &cn = nodes[ch[c]];
+                    uint32_t sl[2];
+                    if (cn.n_prims > 0) { gN[c] = 1; sl[0] = ch[c]; }
+                    else { gN[c] = 2; gA[c] = cn.axis; sl[0] = ch[c] + 1; sl[1] = (uint32_t)cn.offset; }
+                    for (int k = 0; k < gN[c]; ++k) {
+                        const mi_bvh_node &gn = nodes[sl[k]];
+                        const int slot = 2 * c + k;
+                        setBox(rec, slot, gn);
+                        if (gn.n_prims > 0) { link[slot] = gn.offset; cnt[slot] = gn.n_prims; }
+                        else { link[slot] = widx[sl[k]]; cnt[slot] = 0; below = std::max(below, need[widx[sl[k]]]); }
+                        ++present;
+                    }
+                }
+                need[r] = present - 1 + below;
+                finish(rec, link, cnt, nodes[i].axis, gN, gA);
+            }
+        }
+        if (need[0] > STACK_LDS + STACK_SPILL) {
+            // (pbrt's own 64-entry stack bounds the BVH2 depth; a wide record can hold up to three entries per two levels)
+            s.bvhWidth = 2;
+        } else {
+            const float4 *dev;
+            UP(w.data(), w.size(), dev);
+            s.wnodes = dev;
+        }
+    }
+    if (s.bvhWidth == 2) {   // wide-2 nodes: one 64-B record per interior node with both children's boxes
         const uint32_t nN = d->n_nodes;
         std::vector<int32_t> widx(nN, -1);
         uint32_t nInterior = 0;
@@ -2035,15 +2181,19 @@ static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid
     const DScene &s = pt->scene;
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
+#define TRAV_LAUNCH(MODE_, ALPHA_, W_) hipLaunchKernelGGL((k_trav<MODE_, ALPHA_, W_>), travGrid, block, 0, st, s, sub.pool, sub.ctr)
+#define TRAV_LAUNCH_W(MODE_, ALPHA_) do { if (s.bvhWidth == 4) TRAV_LAUNCH(MODE_, ALPHA_, 4); else TRAV_LAUNCH(MODE_, ALPHA_, 2); } while (0)
     if (pt->hasAlphaMasks) {
-        if (mode == 0) hipLaunchKernelGGL((k_trav<0, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else if (mode == 1) hipLaunchKernelGGL((k_trav<1, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_trav<2, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (mode == 0) TRAV_LAUNCH_W(0, true);
+        else if (mode == 1) TRAV_LAUNCH_W(1, true);
+        else TRAV_LAUNCH_W(2, true);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((k_trav<0, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else if (mode == 1) hipLaunchKernelGGL((k_trav<1, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_trav<2, false>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (mode == 0) TRAV_LAUNCH_W(0, false);
+        else if (mode == 1) TRAV_LAUNCH_W(1, false);
+        else TRAV_LAUNCH_W(2, false);
     }
+#undef TRAV_LAUNCH_W
+#undef TRAV_LAUNCH
 }
 
 static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
