@@ -159,6 +159,7 @@ struct WorkDesc {
     unsigned long long totalWork;
     int nTilesX, nTilesY, nTilesShard, shardIndex, shardCount;
     long long spp, sampleBegin;
+    int run;   // consecutive samples of a pixel handed out together (a power of two dividing spp, at most MIPT_WORK_RUN = 64)
 };
 
 DEV unsigned long long WaveSum(unsigned long long v) {
@@ -685,47 +686,68 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
     return found;
 }
 
+// Slots per block of the kernels that walk the whole pool (k_generate, k_resolve_extend): SLOT_CHUNKS x 256. Every block
+// ends in a returning atomicAdd on a queue cursor, and one word takes ~88 of those per microsecond whoever issues them
+// (MI355X_MICROARCH.md, "dequeue"): with one 256-slot chunk per block a 32M-slot pool sent 131k adds to each cursor per
+// launch, a floor of 1.5 ms under kernels that have 1.4-2 ms of work. Eight chunks per block: 16k adds, 0.19 ms.
+#ifndef MIPT_SLOT_CHUNKS
+#define MIPT_SLOT_CHUNKS 8
+#endif
+constexpr int SLOT_CHUNKS = MIPT_SLOT_CHUNKS;
+
 __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    bool traced = false;
-    int cls = MISS_CLASS;
-    unsigned nodes = 0, tris = 0;
-    if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
-        traced = true;
-        int prim = pool.I(I_HITPRIM, slot);
-        if (pool.I(I_NPEND, slot) != 0) {
-            const float4 r0 = pool.R(R_RAY0, slot), r1 = pool.R(R_RAY1, slot), hr = pool.R(R_HIT, slot);
-            V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
-            Hit h;
-            h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
-            const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
-            prim = found ? h.prim : -1;
-            pool.I(I_HITPRIM, slot) = prim;
-            pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
-        }
-        cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
-    }
     // append to the class queues: one atomic per class and block
-    __shared__ unsigned sCnt[BLOCK / 64][MAX_CLASSES], sBase[MAX_CLASSES];
+    __shared__ unsigned sCnt[SLOT_CHUNKS][BLOCK / 64][MAX_CLASSES], sBase[MAX_CLASSES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned rank = 0;
-    for (int c = 0; c < MAX_CLASSES; ++c) {
-        if (!((s.classMask >> c) & 1)) continue;
-        const unsigned long long m = __ballot(traced && cls == c);
-        if (lane == 0) sCnt[wave][c] = (unsigned)__popcll(m);
-        if (cls == c) rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
+    unsigned clsOf = 0, rankLo = 0, rankHi = 0;   // per chunk: 4 bits of (traced, class), 8 bits of rank within the wave and class
+    unsigned nodes = 0, tris = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+        bool traced = false;
+        int cls = MISS_CLASS;
+        if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
+            traced = true;
+            int prim = pool.I(I_HITPRIM, slot);
+            if (pool.I(I_NPEND, slot) != 0) {
+                const float4 r0 = pool.R(R_RAY0, slot), r1 = pool.R(R_RAY1, slot), hr = pool.R(R_HIT, slot);
+                V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
+                Hit h;
+                h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
+                const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
+                prim = found ? h.prim : -1;
+                pool.I(I_HITPRIM, slot) = prim;
+                pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
+            }
+            cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
+        }
+        unsigned rank = 0;
+        for (int c = 0; c < MAX_CLASSES; ++c) {
+            if (!((s.classMask >> c) & 1)) continue;
+            const unsigned long long m = __ballot(traced && cls == c);
+            if (lane == 0) sCnt[ch][wave][c] = (unsigned)__popcll(m);
+            if (cls == c) rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
+        }
+        clsOf |= (unsigned)((traced ? 8 : 0) | cls) << (4 * ch);
+        if (ch < 4) rankLo |= rank << (8 * ch); else rankHi |= rank << (8 * (ch - 4));
     }
     __syncthreads();
     if (threadIdx.x < MAX_CLASSES && ((s.classMask >> threadIdx.x) & 1)) {
-        const int c = threadIdx.x;
-        const unsigned tot = sCnt[0][c] + sCnt[1][c] + sCnt[2][c] + sCnt[3][c];
+        const int c = threadIdx.x;   // exclusive prefix over (chunk, wave), then the block's range of queue c in one add
+        unsigned tot = 0;
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sCnt[ch][w][c]; sCnt[ch][w][c] = tot; tot += n; }
         sBase[c] = tot ? atomicAdd(&ctr->shadeCount[c].v, tot) : 0;
     }
     __syncthreads();
-    if (traced) {
-        unsigned pos = sBase[cls] + rank;
-        for (int w = 0; w < wave; ++w) pos += sCnt[w][cls];
-        pool.shadeQ[(size_t)cls * pool.n + pos] = slot;
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const unsigned cc = (clsOf >> (4 * ch)) & 15u;
+        if (!(cc & 8u)) continue;
+        const int cls = (int)(cc & 7u);
+        const unsigned rank = ((ch < 4 ? rankLo >> (8 * ch) : rankHi >> (8 * (ch - 4))) & 255u);
+        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+        pool.shadeQ[(size_t)cls * pool.n + sBase[cls] + sCnt[ch][wave][cls] + rank] = slot;
     }
 }
 
@@ -868,171 +890,252 @@ DEV void CameraRay(const DScene &s, float pFilmX, float pFilmY, float lensU, flo
 }
 
 // FilmTile::AddSample + MergeFilmTile (film.h:123-163, film.cpp:124-142) as float atomics
-// into the resident film [pixel][32] (31 bins + filter-weight sum = one 128-B row).
-// Wave-cooperative: each finished lane stages its guarded radiance in LDS (row stride 33
-// words: conflict-free both ways); then the wave walks the finished lanes two at a time,
-// half-wave h adding sample h's 32 values to its pixel row -- every atomic
-// wave-instruction touches two full 128-B rows (the full-rate shape for gfx950 float
-// atomics) instead of 64 rows.
+// into the resident film [pixel][32] (31 bins + filter-weight sum = one 128-B row), then the refill of the
+// freed slots with new camera samples, then the extend work list.
+//
+// A block owns SLOT_CHUNKS x 256 consecutive slots and makes three passes over them, so that everything it needs from a
+// shared cursor is asked for ONCE per block (a word takes ~88 returning atomics per microsecond; see SLOT_CHUNKS):
+//   pass 1  flush the finished paths of each chunk into the film -- each finished lane stages its guarded radiance in LDS
+//           (row stride 33 words: conflict-free both ways); the samples of a wave that go to the same pixel are summed
+//           there and leave as ONE 128-B row update, two pixels per wave instruction (the full-rate shape for gfx950
+//           float atomics) -- and count the slots that are free now;
+//   ------  one atomicAdd on the work counter for all of them;
+//   pass 2  camera sample and camera ray for each free slot that drew a work item inside the bounds (an item outside
+//           them -- a pixel of an edge tile beyond the film -- leaves its slot idle for this iteration: the host stops
+//           when no path is alive AND the work counter has passed the end); count new and continuing paths;
+//   ------  one atomicAdd each on the two cursors of the extend work list;
+//   pass 3  write the work list: new camera rays from the front (consecutive samples of a pixel: the most coherent rays),
+//           continuing paths from the back.
 __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *film, DevCounters *ctr, WorkDesc wd) {
     __shared__ float sL[BLOCK * 33];
     __shared__ float sFilter[256];  // the 16x16 filter table, one LDS copy per block
+    __shared__ unsigned sWant[SLOT_CHUNKS][BLOCK / 64], sPrim[SLOT_CHUNKS][BLOCK / 64], sCont[SLOT_CHUNKS][BLOCK / 64];
+    __shared__ unsigned long long sWorkBase;
+    __shared__ unsigned sPrimBase, sContBase;
     sFilter[threadIdx.x] = s.filterTable[threadIdx.x];
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = slot < pool.n;
-    int flags = valid ? pool.I(I_FLAGS, slot) : 0;
+    __syncthreads();
     unsigned bad = 0, cam = 0;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waveBase = threadIdx.x & ~63;
-    const bool fin = valid && (flags & F_FINISHED);
-    float myFx = 0, myFy = 0;
-    int myZero = 0;
-    // Integrator "spectralpath" (spectralpath.cpp:258-318): nBands paths per camera sample; a finished
-    // path hands its bins to the sample's stitched spectrum and the slot restarts on the same camera ray
-    // with the sampler dimension running on; the last band flushes the stitched spectrum.
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int nBands = s.nBands;
-    bool restart = false;
-    int band = 0;
-    if (fin) {
-        if (nBands > 1) band = pool.I(I_BAND, slot);
-        // guards of SamplerIntegrator::Render, integrator.cpp:295-316
-        float yy = 0.f;
-        bool hasNaN = false;
-        float *row = &sL[threadIdx.x * 33];
-        const bool lZero = (flags & F_L_ZERO) != 0;
-        for (int c = 0; c < NQ; ++c) {
-            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!lZero) v4 = pool.Q(Q_L + c, slot);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int b = 4 * c + k;
-                if (b < MI_NSPEC) {
-                    const float v = Get4(v4, k);
-                    hasNaN |= isnanf_(v);
-                    yy += s.cieY[b] * v;
-                    row[b] = v;
-                }
-            }
-        }
-        float y = YScale(yy);
-        bool zero = false;
-        if (hasNaN) zero = true;
-        else if ((double)y < -1e-5) zero = true;
-        else if (isinff(y)) zero = true;
-        if (zero) ++bad;
-        if (nBands > 1) {
-            const int lo = s.bandDelta * band, hi = min(s.bandDelta * (band + 1), MI_NSPEC);
-            for (int c = 0; c < NQ; ++c) {   // bins [lo, hi) of the stitched spectrum <- this band's path
-                if (4 * c + 3 < lo || 4 * c >= hi) continue;
-                float4 v4 = pool.Q(Q_LCA + c, slot);
+    unsigned wantBits = 0, restartBits = 0, contBits = 0, gotBits = 0;   // bit ch: state of this thread's slot in chunk ch
+    // ---------------------------------------------------------------- pass 1: film flush
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+        const bool valid = slot < pool.n;
+        int flags = valid ? pool.I(I_FLAGS, slot) : 0;
+        const bool fin = valid && (flags & F_FINISHED);
+        float myFx = 0, myFy = 0;
+        int myZero = 0;
+        // Integrator "spectralpath" (spectralpath.cpp:258-318): nBands paths per camera sample; a finished
+        // path hands its bins to the sample's stitched spectrum and the slot restarts on the same camera ray
+        // with the sampler dimension running on; the last band flushes the stitched spectrum.
+        bool restart = false;
+        if (fin) {
+            int band = 0;
+            if (nBands > 1) band = pool.I(I_BAND, slot);
+            // guards of SamplerIntegrator::Render, integrator.cpp:295-316
+            float yy = 0.f;
+            bool hasNaN = false;
+            float *row = &sL[threadIdx.x * 33];
+            const bool lZero = (flags & F_L_ZERO) != 0;
+            for (int c = 0; c < NQ; ++c) {
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!lZero) v4 = pool.Q(Q_L + c, slot);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int b = 4 * c + k;
-                    if (b >= lo && b < hi) Set4(v4, k, zero ? 0.f : row[b]);
+                    if (b < MI_NSPEC) {
+                        const float v = Get4(v4, k);
+                        hasNaN |= isnanf_(v);
+                        yy += s.cieY[b] * v;
+                        row[b] = v;
+                    }
                 }
-                pool.Q(Q_LCA + c, slot) = v4;
             }
-            zero = false;
-            if (band + 1 < nBands) restart = true;
-            else {
-                yy = 0.f;
-                for (int c = 0; c < NQ; ++c) {
-                    const float4 v4 = pool.Q(Q_LCA + c, slot);
+            float y = YScale(yy);
+            bool zero = false;
+            if (hasNaN) zero = true;
+            else if ((double)y < -1e-5) zero = true;
+            else if (isinff(y)) zero = true;
+            if (zero) ++bad;
+            if (nBands > 1) {
+                const int lo = s.bandDelta * band, hi = min(s.bandDelta * (band + 1), MI_NSPEC);
+                for (int c = 0; c < NQ; ++c) {   // bins [lo, hi) of the stitched spectrum <- this band's path
+                    if (4 * c + 3 < lo || 4 * c >= hi) continue;
+                    float4 v4 = pool.Q(Q_LCA + c, slot);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int b = 4 * c + k;
-                        if (b < MI_NSPEC) {
-                            const float v = Get4(v4, k);
-                            yy += s.cieY[b] * v;
-                            row[b] = v;
+                        if (b >= lo && b < hi) Set4(v4, k, zero ? 0.f : row[b]);
+                    }
+                    pool.Q(Q_LCA + c, slot) = v4;
+                }
+                zero = false;
+                if (band + 1 < nBands) restart = true;
+                else {
+                    yy = 0.f;
+                    for (int c = 0; c < NQ; ++c) {
+                        const float4 v4 = pool.Q(Q_LCA + c, slot);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int b = 4 * c + k;
+                            if (b < MI_NSPEC) {
+                                const float v = Get4(v4, k);
+                                yy += s.cieY[b] * v;
+                                row[b] = v;
+                            }
+                        }
+                    }
+                    y = YScale(yy);
+                }
+            }
+            if (!zero && !restart && y > s.maxSampleLuminance) {  // FilmTile::AddSample clamp, film.h:126-127
+                const float scaleL = s.maxSampleLuminance / y;
+                for (int b = 0; b < MI_NSPEC; ++b) row[b] *= scaleL;
+            }
+            myZero = zero ? 1 : 0;
+            myFx = pool.F(P_FILMX, slot);
+            myFy = pool.F(P_FILMY, slot);
+            flags = 0;
+        }
+        // (a wave reads only the rows its own lanes staged)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int half = lane >> 5, bin = lane & 31;
+            const int filterTableSize = 16;
+            const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
+            const int w = s.croppedBounds[2] - s.croppedBounds[0];
+            // The sample's footprint (FilmTile::AddSample, film.h:131-141). With a radius of at most half a pixel -- the box
+            // filter of the BASELINE scenes -- it is one pixel for every sample that does not sit exactly on a pixel border.
+            int p0x = 0, p0y = 0, p1x = 0, p1y = 0, myTarget = -1;
+            float myFw = 0.f;
+            if (fin && !restart) {
+                const float dx = myFx - 0.5f, dy = myFy - 0.5f;
+                p0x = (int)ceilf(dx - s.filterRadius[0]); p0y = (int)ceilf(dy - s.filterRadius[1]);
+                p1x = (int)floorf(dx + s.filterRadius[0]) + 1; p1y = (int)floorf(dy + s.filterRadius[1]) + 1;
+                p0x = max(p0x, s.croppedBounds[0]); p0y = max(p0y, s.croppedBounds[1]);
+                p1x = min(p1x, s.croppedBounds[2]); p1y = min(p1y, s.croppedBounds[3]);
+                if (p1x - p0x == 1 && p1y - p0y == 1) {
+                    const float fy = absf((p0y - dy) * invRy * filterTableSize), fx = absf((p0x - dx) * invRx * filterTableSize);
+                    const int iy = min((int)floorf(fy), filterTableSize - 1), ix = min((int)floorf(fx), filterTableSize - 1);
+                    myFw = sFilter[iy * filterTableSize + ix];
+                    myTarget = (p0x - s.croppedBounds[0]) + (p0y - s.croppedBounds[1]) * w;
+                }
+            }
+            // Single-pixel samples: summed per pixel in LDS, one row update per pixel. Two pixels per pass, half-wave h
+            // summing the rows of group h bin by bin.
+            unsigned long long todo = __ballot(myTarget >= 0);
+            while (todo) {
+                const int j0 = __ffsll((long long)todo) - 1;
+                const int t0 = __shfl(myTarget, j0, 64);
+                const unsigned long long g0 = __ballot(myTarget == t0) & todo;
+                todo &= ~g0;
+                unsigned long long g1 = 0ull;
+                int t1 = -1;
+                if (todo) {
+                    const int j1 = __ffsll((long long)todo) - 1;
+                    t1 = __shfl(myTarget, j1, 64);
+                    g1 = __ballot(myTarget == t1) & todo;
+                    todo &= ~g1;
+                }
+                unsigned long long g = half ? g1 : g0;
+                const int tgt = half ? t1 : t0;
+                float acc = 0.f;
+                const int nWalk = max(__popcll(g0), __popcll(g1));
+                for (int it = 0; it < nWalk; ++it) {   // both halves walk their own group, in step (the shuffles need every lane)
+                    const bool have = g != 0ull;
+                    const int p = have ? __ffsll((long long)g) - 1 : 0;
+                    g &= g - 1;
+                    const float fw = __shfl(myFw, p, 64);
+                    const int zero = __shfl(myZero, p, 64);
+                    if (have) {
+                        if (bin == 31) acc += fw;                                                // filterWeightSum += fw
+                        else if (!zero) acc += (sL[(waveBase + p) * 33 + bin] * 1.f) * fw;      // contribSum += L * sampleWeight * fw
+                    }
+                }
+                if (tgt >= 0 && acc != 0.f) atomicAdd(film + (size_t)tgt * 32 + bin, acc);   // (x + 0 == x: a black bin is not sent)
+            }
+            // Wider footprints (other filters, samples on a pixel border): one row update per sample and pixel reached.
+            unsigned long long mask = __ballot(fin && !restart && myTarget < 0);
+            while (mask) {
+                const int j0 = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int j1 = -1;
+                if (mask) { j1 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                const int j = half ? j1 : j0;
+                const int src = j >= 0 ? j : 0;
+                const float pfx = __shfl(myFx, src, 64), pfy = __shfl(myFy, src, 64);
+                const int zero = __shfl(myZero, src, 64);
+                const int q0x = __shfl(p0x, src, 64), q0y = __shfl(p0y, src, 64), q1x = __shfl(p1x, src, 64), q1y = __shfl(p1y, src, 64);
+                if (j >= 0) {
+                    const float val = (bin < MI_NSPEC) ? sL[(waveBase + j) * 33 + bin] : 0.f;
+                    const float dx = pfx - 0.5f, dy = pfy - 0.5f;
+                    for (int y2 = q0y; y2 < q1y; ++y2) {
+                        float fy = absf((y2 - dy) * invRy * filterTableSize);
+                        int iy = min((int)floorf(fy), filterTableSize - 1);
+                        for (int x2 = q0x; x2 < q1x; ++x2) {
+                            float fx = absf((x2 - dx) * invRx * filterTableSize);
+                            int ix = min((int)floorf(fx), filterTableSize - 1);
+                            float fw = sFilter[iy * filterTableSize + ix];
+                            size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
+                            float *dst = film + pix * 32 + bin;
+                            if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
+                            else if (!zero && val != 0.f) atomicAdd(dst, (val * 1.f) * fw);   // contribSum += L * sampleWeight * fw (x + 0 == x: a black bin is not sent)
                         }
                     }
                 }
-                y = YScale(yy);
             }
         }
-        if (!zero && !restart && y > s.maxSampleLuminance) {  // FilmTile::AddSample clamp, film.h:126-127
-            const float scaleL = s.maxSampleLuminance / y;
-            for (int b = 0; b < MI_NSPEC; ++b) row[b] *= scaleL;
-        }
-        myZero = zero ? 1 : 0;
-        myFx = pool.F(P_FILMX, slot);
-        myFy = pool.F(P_FILMY, slot);
-        flags = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the rows are read before the next chunk overwrites them
+        __builtin_amdgcn_wave_barrier();
+        const bool want = valid && flags == 0 && !restart;
+        if (want) wantBits |= 1u << ch;
+        if (restart) restartBits |= 1u << ch;
+        if (valid && (flags & F_ALIVE)) contBits |= 1u << ch;
+        const unsigned long long wm = __ballot(want);
+        if (lane == 0) sWant[ch][wave] = (unsigned)__popcll(wm);
     }
     __syncthreads();
-    {
-        unsigned long long mask = __ballot(fin && !restart);
-        const int half = lane >> 5, bin = lane & 31;
-        const int filterTableSize = 16;
-        const float invRx = 1 / s.filterRadius[0], invRy = 1 / s.filterRadius[1];
-        const int w = s.croppedBounds[2] - s.croppedBounds[0];
-        while (mask) {
-            const int j0 = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            int j1 = -1;
-            if (mask) { j1 = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-            const int j = half ? j1 : j0;
-            const int src = j >= 0 ? j : 0;
-            const float pfx = __shfl(myFx, src, 64), pfy = __shfl(myFy, src, 64);
-            const int zero = __shfl(myZero, src, 64);
-            if (j >= 0) {
-                const float val = (bin < MI_NSPEC) ? sL[(waveBase + j) * 33 + bin] : 0.f;
-                float dx = pfx - 0.5f, dy = pfy - 0.5f;
-                int p0x = (int)ceilf(dx - s.filterRadius[0]), p0y = (int)ceilf(dy - s.filterRadius[1]);
-                int p1x = (int)floorf(dx + s.filterRadius[0]) + 1, p1y = (int)floorf(dy + s.filterRadius[1]) + 1;
-                p0x = max(p0x, s.croppedBounds[0]); p0y = max(p0y, s.croppedBounds[1]);
-                p1x = min(p1x, s.croppedBounds[2]); p1y = min(p1y, s.croppedBounds[3]);
-                for (int y2 = p0y; y2 < p1y; ++y2) {
-                    float fy = absf((y2 - dy) * invRy * filterTableSize);
-                    int iy = min((int)floorf(fy), filterTableSize - 1);
-                    for (int x2 = p0x; x2 < p1x; ++x2) {
-                        float fx = absf((x2 - dx) * invRx * filterTableSize);
-                        int ix = min((int)floorf(fx), filterTableSize - 1);
-                        float fw = sFilter[iy * filterTableSize + ix];
-                        size_t pix = (size_t)(x2 - s.croppedBounds[0]) + (size_t)(y2 - s.croppedBounds[1]) * w;
-                        float *dst = film + pix * 32 + bin;
-                        if (bin == 31) atomicAdd(dst, fw);                     // filterWeightSum += fw
-                        else if (!zero && val != 0.f) atomicAdd(dst, (val * 1.f) * fw);   // contribSum += L * sampleWeight * fw (x + 0 == x: a black bin is not sent)
-                    }
-                }
-            }
-        }
+    if (threadIdx.x == 0) {   // exclusive prefix over (chunk, wave) and the block's range of the work list in one add
+        unsigned tot = 0;
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sWant[ch][w]; sWant[ch][w] = tot; tot += n; }
+        sWorkBase = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : ~0ull;
     }
-    // refill: up to 4 tries to draw a work item that maps inside the sample / pixel bounds
-    bool need = valid && flags == 0 && !restart;
-    bool got = false;
-    int px = 0, py = 0;
-    long long sampleNum = 0;
-    if (restart) {  // next band of the same camera sample
-        const int pix = pool.I(I_PIXEL, slot);
-        px = (int)(short)(pix & 0xffff); py = pix >> 16;
-        sampleNum = pool.I(I_SAMPLE, slot);
-        got = true;
-    }
-    __shared__ unsigned sWork[4][5];
-    __shared__ unsigned long long sWorkBase[4];
-    for (int attempt = 0; attempt < 4; ++attempt) {  // one work-counter atomic per block and attempt
-        const bool want = need && !got;
-        const unsigned long long mask = __ballot(want);
-        const int wave = threadIdx.x >> 6;
-        if (lane == 0) sWork[attempt][wave] = (unsigned)__popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned tot = sWork[attempt][0] + sWork[attempt][1] + sWork[attempt][2] + sWork[attempt][3];
-            sWork[attempt][4] = tot;
-            sWorkBase[attempt] = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    // ---------------------------------------------------------------- pass 2: refill
+    bool anyAlive = false;
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+        const bool want = (wantBits >> ch) & 1u, restart = (restartBits >> ch) & 1u;
+        const unsigned long long wm = __ballot(want);
+        bool got = false;
+        int px = 0, py = 0, band = 0;
+        long long sampleNum = 0;
+        if (restart) {  // next band of the same camera sample
+            const int pix = pool.I(I_PIXEL, slot);
+            px = (int)(short)(pix & 0xffff); py = pix >> 16;
+            sampleNum = pool.I(I_SAMPLE, slot);
+            band = pool.I(I_BAND, slot);
+            got = true;
         }
-        __syncthreads();
-        if (sWork[attempt][4] == 0) break;
         if (want) {
-            unsigned long long w = sWorkBase[attempt] + __popcll(mask & ((1ull << lane) - 1));
-            for (int k = 0; k < wave; ++k) w += sWork[attempt][k];
-            if (w >= wd.totalWork) { need = false; }
-            else {
-                const unsigned long long perSample = (unsigned long long)wd.nTilesShard * 256ull;
-                sampleNum = wd.sampleBegin + (long long)(w / perSample);
-                unsigned rem = (unsigned)(w % perSample);
+            const unsigned long long w = sWorkBase + sWant[ch][wave] + (unsigned long long)__popcll(wm & ltMask);
+            if (w < wd.totalWork) {
+                // work order: runs of wd.run consecutive samples of a pixel, pixel by pixel through the shard's tiles, then
+                // the next run (so the lanes of a wave hold neighbouring samples of a few pixels: the most coherent camera
+                // rays, and finished samples that can be summed before they reach the film)
+                const unsigned run = (unsigned)wd.run;
+                const unsigned long long perChunk = (unsigned long long)wd.nTilesShard * 256ull * run;
+                const unsigned long long chunk = w / perChunk;
+                const unsigned long long inChunk = w % perChunk;
+                sampleNum = wd.sampleBegin + (long long)(chunk * run + (inChunk % run));
+                unsigned rem = (unsigned)(inChunk / run);
                 int tileLocal = rem >> 8, pix = rem & 255;
                 int tile = wd.shardIndex + tileLocal * wd.shardCount;
                 int tx = tile % wd.nTilesX, ty = tile / wd.nTilesX;
@@ -1044,42 +1147,59 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                     got = true;
             }
         }
-    }
-    if (got) {
-        const uint64_t index = HaltonPixelOffset(s, px, py) + (uint64_t)sampleNum * (uint64_t)s.sampleStride;
-        // GetCameraSample (sampler.cpp:46-52): pFilm = dims 0,1; time = dim 2; pLens = dims 3,4
-        float u0 = SampleDimension(s, index, 0), u1 = SampleDimension(s, index, 1);
-        float pfx = (float)px + u0, pfy = (float)py + u1;
-        float lu = 0, lv = 0;
-        if (s.camera.lens_radius > 0) { lu = SampleDimension(s, index, 3); lv = SampleDimension(s, index, 4); }
-        Ray ray;
-        CameraRay(s, pfx, pfy, lu, lv, &ray);
-        ++cam;
-        pool.R(R_RAY0, slot) = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
-        pool.R(R_RAY1, slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, 1.f);   // etaScale = 1
-        pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
+        if (got) {
+            const uint64_t index = HaltonPixelOffset(s, px, py) + (uint64_t)sampleNum * (uint64_t)s.sampleStride;
+            // GetCameraSample (sampler.cpp:46-52): pFilm = dims 0,1; time = dim 2; pLens = dims 3,4
+            float u0 = SampleDimension(s, index, 0), u1 = SampleDimension(s, index, 1);
+            float pfx = (float)px + u0, pfy = (float)py + u1;
+            float lu = 0, lv = 0;
+            if (s.camera.lens_radius > 0) { lu = SampleDimension(s, index, 3); lv = SampleDimension(s, index, 4); }
+            Ray ray;
+            CameraRay(s, pfx, pfy, lu, lv, &ray);
+            ++cam;
+            pool.R(R_RAY0, slot) = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tMax);
+            pool.R(R_RAY1, slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, 1.f);   // etaScale = 1
+            pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
 
-        pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
-        pool.I(I_SAMPLE, slot) = (int)sampleNum;
-        pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
-        pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
-        if (!restart) pool.I(I_DIM, slot) = 5;
-        if (nBands > 1) {
-            pool.I(I_BAND, slot) = restart ? band + 1 : 0;
-            if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        pool.I(I_BOUNCES, slot) = 0;
-        flags = F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF;   // L = 0, beta = 1, not stored
+            pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
+            pool.I(I_SAMPLE, slot) = (int)sampleNum;
+            pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
+            pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
+            if (!restart) pool.I(I_DIM, slot) = 5;
+            if (nBands > 1) {
+                pool.I(I_BAND, slot) = restart ? band + 1 : 0;
+                if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            pool.I(I_BOUNCES, slot) = 0;
+            pool.I(I_FLAGS, slot) = F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF;   // L = 0, beta = 1, not stored
+            gotBits |= 1u << ch;
+        } else if (want) pool.I(I_FLAGS, slot) = 0;   // stays free (its finished path has been flushed)
+        const bool isCont = ((contBits >> ch) & 1u) != 0;
+        anyAlive |= got || isCont;
+        // the extend work list: new camera rays first (lanes of a traversal wave then hold neighbouring samples)
+        const unsigned long long pm = __ballot(got), cm = __ballot(isCont);
+        if (lane == 0) { sPrim[ch][wave] = (unsigned)__popcll(pm); sCont[ch][wave] = (unsigned)__popcll(cm); }
     }
-    if (valid) pool.I(I_FLAGS, slot) = flags;
-    __shared__ unsigned sAlive[5], sPrim[5], sCont[5];
-    BlockReserve(&ctr->alive.v, valid && (flags & F_ALIVE), sAlive);
-    // the extend work list: new camera rays first (lanes of a traversal wave then hold neighbouring samples)
-    const bool isPrim = valid && got, isCont = valid && (flags & F_ALIVE) && !got;
-    const unsigned posP = BlockReserve(&ctr->primCount.v, isPrim, sPrim);
-    const unsigned posC = BlockReserve(&ctr->contCount.v, isCont, sCont);
-    if (isPrim) pool.extQ[posP] = slot;
-    if (isCont) pool.extQ[pool.n - 1 - posC] = slot;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned (*cnt)[BLOCK / 64] = threadIdx.x == 0 ? sPrim : sCont;
+        unsigned tot = 0;
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = cnt[ch][w]; cnt[ch][w] = tot; tot += n; }
+        const unsigned base = tot ? atomicAdd(threadIdx.x == 0 ? &ctr->primCount.v : &ctr->contCount.v, tot) : 0;
+        if (threadIdx.x == 0) sPrimBase = base; else sContBase = base;
+    }
+    if (__any(anyAlive) && lane == 0) ctr->alive.v = 1;   // (a flag, not a count: the host only asks whether any path is left)
+    __syncthreads();
+    // ---------------------------------------------------------------- pass 3: the extend work list
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+        const bool isPrim = (gotBits >> ch) & 1u, isCont = (contBits >> ch) & 1u;
+        const unsigned long long pm = __ballot(isPrim), cm = __ballot(isCont);
+        if (isPrim) pool.extQ[sPrimBase + sPrim[ch][wave] + (unsigned)__popcll(pm & ltMask)] = slot;
+        if (isCont) pool.extQ[pool.n - 1 - (sContBase + sCont[ch][wave] + (unsigned)__popcll(cm & ltMask))] = slot;
+    }
     CountAdd(&Stats(ctr).cameraRays, cam);
     CountAdd(&Stats(ctr).badSamples, bad);
 }
@@ -2238,6 +2358,10 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
     wd.sampleBegin = rp->sample_begin;
     wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
+    int runCap = 64;
+    if (const char *e = getenv("MIPT_WORK_RUN")) runCap = std::max(1, atoi(e));
+    wd.run = 1;
+    while (2 * wd.run <= runCap && wd.spp % (2 * wd.run) == 0) wd.run *= 2;
     sub.iterations = 0;
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
@@ -2263,8 +2387,10 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
     HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));
     const dim3 grid((poolN + BLOCK - 1) / BLOCK), block(BLOCK);
+    const dim3 chunkGrid((grid.x + SLOT_CHUNKS - 1) / SLOT_CHUNKS);   // kernels that take SLOT_CHUNKS x 256 slots per block
     const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
     unsigned alive = 1;
+    unsigned long long drawn = 0;
     // Per-kernel-class time: HIP events at the kernel boundaries of every iteration,
     // read back after the per-iteration sync that the alive counter needs anyway.
     auto harvest = [&](int set, bool full) {
@@ -2285,16 +2411,20 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         hipEvent_t *ev = sub.evIter[set];
         HIPCHK(hipMemsetAsync(&sub.ctr->alive, 0, ITER_CLEAR_BYTES, st));
         HIPCHK(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k_generate, grid, block, 0, st, s, sub.pool, pt->film, sub.ctr, wd);
+        hipLaunchKernelGGL(k_generate, chunkGrid, block, 0, st, s, sub.pool, pt->film, sub.ctr, wd);
         HIPCHK(hipEventRecord(ev[1], st));
         HIPCHK(hipMemcpyAsync(&alive, &sub.ctr->alive.v, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&drawn, &sub.ctr->nextWork, sizeof(drawn), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (havePrev) harvest(set ^ 1, prevFull);
-        if (alive == 0) { harvest(set, false); break; }
+        // done when no path is alive and every work item has been drawn (an iteration can draw nothing but items outside
+        // the pixel bounds and leave the pool empty with work still to hand out)
+        if (alive == 0 && drawn >= wd.totalWork) { harvest(set, false); break; }
+        if (alive == 0) { harvest(set, false); havePrev = false; set ^= 1; if (++sub.iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; } continue; }
         HIPCHK(hipEventRecord(ev[7], st));
         LaunchTraversal(pt, sub, 0, travGrid);
         HIPCHK(hipEventRecord(ev[6], st));
-        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
+        hipLaunchKernelGGL(k_resolve_extend, chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         LaunchShade(pt, sub, grid);
         HIPCHK(hipEventRecord(ev[3], st));
@@ -2451,6 +2581,7 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
     wd.shardCount = wd.nTilesX * wd.nTilesY;
     wd.nTilesShard = 1;
     wd.spp = 1;
+    wd.run = 1;
     wd.sampleBegin = sample;
     wd.totalWork = 256;
     const uint32_t poolN = BLOCK;
@@ -2483,7 +2614,7 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         float *r = records + (size_t)(*n_records) * MI_PATH_RECORD_FLOATS;
         for (int k = 0; k < MI_PATH_RECORD_FLOATS; ++k) r[k] = 0.f;
         LaunchTraversal(pt, sub, 0, travGrid);
-        hipLaunchKernelGGL(k_resolve_extend, grid, block, 0, st, s, sub.pool, sub.ctr);
+        hipLaunchKernelGGL(k_resolve_extend, dim3(1), block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipStreamSynchronize(st));
         int bounces = 0, prim = -1, dim = 0;
         float ray0[4], ray1[4], hit[4];

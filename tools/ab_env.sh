@@ -1,18 +1,21 @@
 #!/bin/bash
-# Same-box A/B of one environment switch: tools/ab_env.sh VAR  (runs the short benches with VAR unset, then VAR=1).
-V=$1
-for mode in off on; do
-  if [ $mode = on ]; then export $V=1; fi
-  MIPT_STREAMS=1 timeout -k 10 200 python bench.py --steps 1 --warmup 1 --spp 256 --pool 8388608 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v1.json 2> gpurun_out/v1.err
-  timeout -k 10 200 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --exclusive-spp 0 > gpurun_out/v4.json 2> gpurun_out/v4.err
-  python - <<PY
+# Same-box A/B of environment settings on the default bench. Usage: tools/ab_env.sh <tag> "VAR=a" "VAR=b" ... [-- bench args]
+T=$1; shift
+ARGS=""
+SETS=()
+while [ $# -gt 0 ]; do
+  if [ "$1" == "--" ]; then shift; ARGS="$@"; break; fi
+  SETS+=("$1"); shift
+done
+for rep in 1 2; do
+  for st in "${SETS[@]}"; do
+    env $st timeout -k 10 300 python bench.py --steps 2 --warmup 1 --cpu-samples 0 $ARGS > gpurun_out/ab_${T}.json 2> gpurun_out/ab_${T}.err
+    python - <<PY
 import json
-out=["$V $mode"]
-for f in ("v1","v4"):
-    try:
-        d=json.load(open("gpurun_out/%s.json"%f)); r=d["roofline"]["kernel_time_s"]
-        out.append("%s %.1f (g %.3f t0 %.3f e %.3f sh %.3f s %.3f m %.3f) mean %.6f"%(f,d["value"],r["generate"],r["trav0"],r["extend"],r["shade"],r["shadow"],r["mis"],d["film_mean_per_sample"]))
-    except Exception as e: out.append(f+" -")
-print(" | ".join(out))
+try:
+    d=json.load(open("gpurun_out/ab_${T}.json")); r=d["roofline"]
+    print("$st", d["value"], "Mray/s", d["ms_per_step"], "ms", r["kernel_time_s"])
+except Exception as e: print("$st", "failed", e)
 PY
+  done
 done
