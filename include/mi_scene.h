@@ -32,6 +32,12 @@ typedef struct mi_scene_stats {
 
 int mi_scene_load_file(const char *path, const mi_scene_overrides *ov, mi_scene **out);
 int mi_scene_load_string(const char *text, const char *base_dir, const mi_scene_overrides *ov, mi_scene **out);
+/* A loaded scene as one binary file, for the ranks of a multi-GPU job (one process per GPU): rank 0 parses the .pbrt text
+ * and builds the BVH once (the reference's single process does both once, src/core/api.cpp:1617-1737) and saves; the other
+ * ranks load the arrays. Same-build, same-host hand-over, written atomically (rename); a truncated or foreign file is an
+ * error code. */
+int mi_scene_save_cache(const mi_scene *s, const char *path);
+int mi_scene_load_cache(const char *path, mi_scene **out);
 const mi_scene_desc *mi_scene_get_desc(const mi_scene *s);
 void mi_scene_get_stats(const mi_scene *s, mi_scene_stats *out);
 /* i-th warning (kind 0) / error (kind 1) message, NULL past the end. */

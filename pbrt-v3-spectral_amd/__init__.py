@@ -179,6 +179,8 @@ def host_lib():
         lib = C.CDLL(HOST_LIB)
         lib.mi_scene_load_file.argtypes = [C.c_char_p, C.POINTER(SceneOverrides), C.POINTER(C.c_void_p)]
         lib.mi_scene_load_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SceneOverrides), C.POINTER(C.c_void_p)]
+        lib.mi_scene_save_cache.argtypes = [C.c_void_p, C.c_char_p]
+        lib.mi_scene_load_cache.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.mi_scene_get_desc.argtypes = [C.c_void_p]
         lib.mi_scene_get_desc.restype = C.POINTER(SceneDesc)
         lib.mi_scene_get_stats.argtypes = [C.c_void_p, C.POINTER(SceneStats)]
@@ -227,8 +229,16 @@ class Scene:
     pbrtWorldEnd up to, not including, ``integrator->Render``; src/core/api.cpp:1617-1707)."""
 
     def __init__(self, path=None, text=None, base_dir=None, spp=-1, xres=-1, yres=-1, max_depth=-1, crop=None,
-                 light_strategy=None):
+                 light_strategy=None, cache=None):
         lib = host_lib()
+        if cache is not None:   # a scene another process loaded and saved (Scene.save_cache): no parsing, no BVH build
+            h = C.c_void_p()
+            if lib.mi_scene_load_cache(os.fsencode(cache), C.byref(h)) != 0:
+                raise RuntimeError("scene cache load failed: %s" % lib.mi_scene_last_error().decode())
+            self._h = h
+            self.desc_ptr = lib.mi_scene_get_desc(h)
+            self.desc = self.desc_ptr.contents
+            return
         ov = SceneOverrides(spp, xres, yres, max_depth, (C.c_float * 4)(*(crop or (-1, -1, -1, -1))),
                             light_strategy.encode() if light_strategy else None)
         h = C.c_void_p()
@@ -241,6 +251,11 @@ class Scene:
         self._h = h
         self.desc_ptr = lib.mi_scene_get_desc(h)
         self.desc = self.desc_ptr.contents
+
+    def save_cache(self, path):
+        """Write the loaded scene (arrays, BVH, tables) as one binary file for the other ranks of a job (Scene(cache=path))."""
+        if host_lib().mi_scene_save_cache(self._h, os.fsencode(path)) != 0:
+            raise RuntimeError("scene cache save failed: %s" % host_lib().mi_scene_last_error().decode())
 
     def close(self):
         if getattr(self, "_h", None):

@@ -924,29 +924,6 @@ void Api::WorldEnd() {
         const float *basis = Spectrum::RGBIllumBasis(k);
         for (int i = 0; i < MI_NSPEC; ++i) d.rgb_illum[k][i] = basis[i];
     }
-    scene->mipmaps.clear();
-    for (const HostMipMap &h : scene->mipStore) {
-        mi_mipmap m{};
-        m.n_levels = (int)h.levelOffset.size(); m.wrap = h.wrap; m.width = h.width; m.height = h.height;
-        m.texels = h.texels.data();
-        for (size_t l = 0; l < h.levelOffset.size() && l < MI_MAX_MIP_LEVELS; ++l) m.level_offset[l] = h.levelOffset[l];
-        scene->mipmaps.push_back(m);
-    }
-    d.n_mipmaps = (uint32_t)scene->mipmaps.size();
-    d.mipmaps = scene->mipmaps.empty() ? nullptr : scene->mipmaps.data();
-    d.n_textures = (uint32_t)scene->textures.size();
-    d.textures = scene->textures.empty() ? nullptr : scene->textures.data();
-    scene->envmaps.clear();
-    for (const HostEnvMap &e : scene->envStore) {
-        mi_envmap m{};
-        m.width = e.width; m.height = e.height; m.rgb = e.rgb.data();
-        m.nu = e.nu; m.nv = e.nv;
-        m.cond_func = e.condFunc.data(); m.cond_cdf = e.condCdf.data(); m.cond_func_int = e.condFuncInt.data();
-        m.marg_func = e.margFunc.data(); m.marg_cdf = e.margCdf.data(); m.marg_func_int = e.margFuncInt;
-        scene->envmaps.push_back(m);
-    }
-    d.n_envmaps = (uint32_t)scene->envmaps.size();
-    d.envmaps = scene->envmaps.empty() ? nullptr : scene->envmaps.data();
     scene->Finalize();
 }
 
@@ -1376,6 +1353,29 @@ HostScene *Load(Parser &p, Api &api, HostScene *scene, std::string *err) {
 void HostScene::Finalize() {
     mi_scene_desc &d = desc;
     d.abi_version = MI_ABI_VERSION;
+    mipmaps.clear();
+    for (const HostMipMap &h : mipStore) {
+        mi_mipmap m{};
+        m.n_levels = (int)h.levelOffset.size(); m.wrap = h.wrap; m.width = h.width; m.height = h.height;
+        m.texels = h.texels.data();
+        for (size_t l = 0; l < h.levelOffset.size() && l < MI_MAX_MIP_LEVELS; ++l) m.level_offset[l] = h.levelOffset[l];
+        mipmaps.push_back(m);
+    }
+    d.n_mipmaps = (uint32_t)mipmaps.size();
+    d.mipmaps = mipmaps.empty() ? nullptr : mipmaps.data();
+    d.n_textures = (uint32_t)textures.size();
+    d.textures = textures.empty() ? nullptr : textures.data();
+    envmaps.clear();
+    for (const HostEnvMap &e : envStore) {
+        mi_envmap m{};
+        m.width = e.width; m.height = e.height; m.rgb = e.rgb.data();
+        m.nu = e.nu; m.nv = e.nv;
+        m.cond_func = e.condFunc.data(); m.cond_cdf = e.condCdf.data(); m.cond_func_int = e.condFuncInt.data();
+        m.marg_func = e.margFunc.data(); m.marg_cdf = e.margCdf.data(); m.marg_func_int = e.margFuncInt;
+        envmaps.push_back(m);
+    }
+    d.n_envmaps = (uint32_t)envmaps.size();
+    d.envmaps = envmaps.empty() ? nullptr : envmaps.data();
     d.n_nodes = (uint32_t)nodes.size(); d.nodes = nodes.data();
     d.n_prims = (uint32_t)prims.size(); d.prims = prims.data();
     d.n_tris = (uint32_t)(triIndices.size() / 3); d.tri_indices = triIndices.data(); d.tri_mesh = triMesh.data();

@@ -68,6 +68,26 @@ int mi_scene_load_string(const char *text, const char *base_dir, const mi_scene_
     });
 }
 
+int mi_scene_save_cache(const mi_scene *s, const char *path) {
+    if (!s || !path) { g_err = "null argument"; return MI_ERR_INVALID; }
+    return Guarded([&]() -> int {
+        std::string err;
+        if (!SaveSceneCache(*s->hs, path, &err)) { g_err = err; return MI_ERR_INVALID; }
+        return MI_OK;
+    });
+}
+
+int mi_scene_load_cache(const char *path, mi_scene **out) {
+    if (!path || !out) { g_err = "null argument"; return MI_ERR_INVALID; }
+    return Guarded([&]() -> int {
+        std::string err;
+        HostScene *hs = LoadSceneCache(path, &err);
+        if (!hs) { g_err = err; return MI_ERR_INVALID; }
+        *out = new mi_scene{hs};
+        return MI_OK;
+    });
+}
+
 const mi_scene_desc *mi_scene_get_desc(const mi_scene *s) { return s ? &s->hs->desc : nullptr; }
 
 void mi_scene_get_stats(const mi_scene *s, mi_scene_stats *o) {

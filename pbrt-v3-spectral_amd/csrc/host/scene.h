@@ -119,6 +119,10 @@ HostScene *LoadSceneFile(const std::string &path, const LoadOverrides &ov, std::
 HostScene *LoadSceneString(const std::string &text, const std::string &baseDir, const LoadOverrides &ov,
                            std::string *err);
 
+// One loaded scene as a binary file (scene_cache.cpp): the hand-over between the ranks of a multi-GPU job.
+bool SaveSceneCache(const HostScene &scene, const std::string &path, std::string *err);
+HostScene *LoadSceneCache(const std::string &path, std::string *err);
+
 // Spectral film writer, src/core/film.cpp:226-308 (".dat": text header + 31 planes of float64).
 bool WriteSpectralDat(const std::string &filename, int w, int h, const float *filmSum, float scale,
                       std::string *err);

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -20,17 +21,31 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("ptdist", os.path.join(%(root)r, "pbrt-v3-spectral_amd", "distributed.py"))
 ptdist = importlib.util.module_from_spec(spec); spec.loader.exec_module(ptdist)
 rank, world, local = ptdist.init_from_env(backend="gloo")
-scene = pt.Scene(text=st.material_zoo(res=48, spp=4))
-si, sc = ptdist.shard_of(rank, world)
-film, weight, c, _ = ob.render(scene, n_threads=2, shard_index=si, shard_count=sc)
-tf, tw = torch.from_numpy(film), torch.from_numpy(weight)
+# rank 0 loads the scene and saves the binary cache, rank 1 reads it back (as bench.py does)
+cache = %(cache)r
+if rank == 0:
+    scene = pt.Scene(text=st.material_zoo(res=48, spp=4))
+    scene.save_cache(cache)
 ptdist.barrier()
-ptdist.reduce_film(tf, tw, dst=0)
+if rank != 0:
+    scene = pt.Scene(cache=cache)
+w, h = scene.film_size
+film32 = torch.zeros((h, w, 32), dtype=torch.float32)   # the layout of the renderer's resident film: 31 bins + weight
+state = {}
+def render(si, sc):   # the CPU oracle stands in for the device render (no GPU here); same shard arguments
+    film, weight, c, _ = ob.render(scene, n_threads=2, shard_index=si, shard_count=sc)
+    film32[..., :31] = torch.from_numpy(film); film32[..., 31] = torch.from_numpy(weight)
+    state["c"] = c
+frame = ptdist.ShardedFrame(render, film32, rank, world)   # the step function bench.py times
+ptdist.barrier()
+frame.step()
+c = state["c"]
 tot = ptdist.sum_over_ranks([c.camera_rays, c.regular_rays + c.shadow_rays])
 mx = ptdist.max_over_ranks(float(rank))
+per_rank = frame.per_rank_timings()
 if rank == 0:
-    np.save(%(out)r, tf.numpy()); np.save(%(outw)r, tw.numpy())
-    open(%(outc)r, "w").write("%%d %%d %%g" %% (tot[0], tot[1], mx))
+    np.save(%(out)r, film32[..., :31].numpy()); np.save(%(outw)r, film32[..., 31].numpy())
+    open(%(outc)r, "w").write("%%d %%d %%g %%d %%g" %% (tot[0], tot[1], mx, len(per_rank["render_s"]), per_rank["imbalance"]))
 '''
 
 
@@ -38,7 +53,7 @@ def test_two_rank_tile_sharding_and_film_reduce(tmp_path, pt, ob):
     import scenes_text as st
     out, outw, outc = str(tmp_path / "f.npy"), str(tmp_path / "w.npy"), str(tmp_path / "c.txt")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % dict(root=ROOT, out=out, outw=outw, outc=outc))
+    script.write_text(WORKER % dict(root=ROOT, out=out, outw=outw, outc=outc, cache=str(tmp_path / "scene.bin")))
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", str(script)]
@@ -48,9 +63,36 @@ def test_two_rank_tile_sharding_and_film_reduce(tmp_path, pt, ob):
     film, weight, c, _ = ob.render(scene, n_threads=2)
     got, gotw = np.load(out), np.load(outw)
     assert np.allclose(got, film, rtol=1e-6, atol=0) and np.array_equal(gotw, weight)
-    cam, rays, mx = open(outc).read().split()
+    cam, rays, mx, n_ranks, imbalance = open(outc).read().split()
     assert int(cam) == c.camera_rays == 48 * 48 * 4 and int(rays) == c.regular_rays + c.shadow_rays
-    assert float(mx) == 1.0
+    assert float(mx) == 1.0 and int(n_ranks) == 2 and 1.0 <= float(imbalance) < 2.0
+
+
+def test_scene_cache_round_trip_and_rejection(pt, ob, tmp_path):
+    """mi_scene_save_cache / mi_scene_load_cache: the loaded copy renders bit-identically (textures, environment map and
+    BVH included); a truncated file, a foreign file and a missing file are error codes."""
+    import scenes_text as st
+    st.write_texture_files(str(tmp_path))
+    st.write_alpha_png(str(tmp_path))
+    st.write_env_pfm(str(tmp_path / "env.pfm"))
+    for name, s in [("tex", pt.Scene(text=st.textured_zoo(res=24, spp=2), base_dir=str(tmp_path))),
+                    ("env", pt.Scene(text=st.zoo_with_infinite_light("map", res=24, spp=2), base_dir=str(tmp_path)))]:
+        path = str(tmp_path / (name + ".bin"))
+        s.save_cache(path)
+        s2 = pt.Scene(cache=path)
+        assert s2.stats == s.stats and s2.film_filename == s.film_filename and s2.warnings == s.warnings
+        a, wa, ca, _ = ob.render(s, n_threads=2)
+        b, wb, cb, _ = ob.render(s2, n_threads=2)
+        assert np.array_equal(a, b) and np.array_equal(wa, wb) and ca.as_dict() == cb.as_dict()
+        raw = open(path, "rb").read()
+        open(path, "wb").write(raw[: len(raw) // 2])
+        with pytest.raises(RuntimeError, match="truncated or inconsistent"):
+            pt.Scene(cache=path)
+    (tmp_path / "foreign.bin").write_bytes(b"not a cache at all" * 10)
+    with pytest.raises(RuntimeError, match="not a scene cache"):
+        pt.Scene(cache=str(tmp_path / "foreign.bin"))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        pt.Scene(cache=str(tmp_path / "missing.bin"))
 
 
 def test_shards_partition_the_tiles(pt, ob):
