@@ -67,11 +67,14 @@ enum : int {
 enum : int {
     R_RAY0 = 0,   // path ray: o.xyz, tMax
     R_RAY1,       //           d.xyz, etaScale
-    R_HIT,        // t, b0, b1, b2 of the last traversal (path ray, or MIS ray)
     R_SH0, R_SH1, // shadow ray (tMax = 1 - ShadowEpsilon): o.xyz d.x | d.y d.z - -
     R_MI0, R_MI1, // MIS ray: same packing
+    R_HIT,        // t, b0, b1, b2 of the last traversal (path ray, or MIS ray)
     R_COUNT
 };
+// The two quads of a ray are neighbours in memory ([ray][slot][2]: 32 B per slot), so the pair a shading lane stores --
+// and a traversal lane loads -- falls into ONE 64-B sector instead of two planes' sectors (the memory side moves whole
+// sectors: a scattered 16-B store cost ~45 B there, PMC of round 1).
 // ---- spectral planes. A 31-bin spectrum of a slot is stored as NQ = 8 float4 "quad planes": bins
 // 4c..4c+3 of slot i at q[(set + c) * pool + i] (bin 31 is padding, kept 0 in everything that is summed or
 // tested). One 16-B access per lane moves four bins, so a spectral pass issues a quarter of the memory
@@ -125,7 +128,9 @@ struct Pool {
     // a slot's 8 quads of one spectrum are one 128-B line: [spectrum][slot][quad] ([slot][spectrum][quad], the
     // spectra of a slot in one page, measured the same)
     DEV float4 &Q(int plane, uint32_t slot) const { return q[(((size_t)(plane >> 3) * n + slot) << 3) + (plane & 7)]; }
-    DEV float4 &R(int plane, uint32_t slot) const { return r[(size_t)plane * n + slot]; }
+    DEV float4 &R(int plane, uint32_t slot) const {
+        return plane < R_HIT ? r[(((size_t)(plane >> 1) * n + slot) << 1) + (plane & 1)] : r[(size_t)plane * n + slot];
+    }
     DEV int &I(int plane, uint32_t slot) const { return i[(size_t)plane * n + slot]; }
 };
 
@@ -499,7 +504,10 @@ constexpr int TRI_BATCH = MIPT_TRI_BATCH;
 #ifndef MIPT_TRAV_CHUNK
 #define MIPT_TRAV_CHUNK 128
 #endif
-constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserves per cursor atomic
+constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserves per cursor atomic (twice that for launches of
+                                             // 8M rays and more: the cursor word takes ~88 adds/us, and 30M rays in chunks of
+                                             // 128 are 234k adds -- same-box A/B: killeroo +3.7 % with 256, the 10M-triangle
+                                             // scene's 6M-ray launches -1 %, so the size follows the launch)
 
 #ifndef MIPT_TRAV_WAVES_PER_EU
 #define MIPT_TRAV_WAVES_PER_EU 4
@@ -513,6 +521,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     const unsigned nPrim = (MODE == 0) ? ctr->primCount.v : 0, nCont = (MODE == 0) ? ctr->contCount.v : 0;
     const unsigned total = (MODE == 0) ? nPrim + nCont : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
     const uint32_t *__restrict__ queue = (MODE == 0) ? pool.extQ : ((MODE == 1) ? pool.shadowQ : pool.misQ);
+    const unsigned travChunk = (total >= (1u << 23)) ? 2u * (unsigned)TRAV_CHUNK : (unsigned)TRAV_CHUNK;
     const float4 *__restrict__ primTri = s.primTri;
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
     bool has = false;
@@ -535,12 +544,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         if (!exhausted) {
             const unsigned long long idle = __ballot(!has);
             if (idle) {
-                if (chunkNext == chunkEnd) {  // the wave's private range is used up: reserve TRAV_CHUNK more
+                if (chunkNext == chunkEnd) {  // the wave's private range is used up: reserve a chunk more
                     unsigned base = 0;
-                    if (wlane == 0) base = atomicAdd(&ctr->travNext[MODE].v, (unsigned)TRAV_CHUNK);
+                    if (wlane == 0) base = atomicAdd(&ctr->travNext[MODE].v, travChunk);
                     base = __shfl(base, 0, 64);
                     chunkNext = min(base, total);
-                    chunkEnd = min(base + (unsigned)TRAV_CHUNK, total);
+                    chunkEnd = min(base + travChunk, total);
                     if (base >= total) exhausted = true;
                 }
                 const unsigned first = chunkNext;
@@ -1521,8 +1530,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                             Set4(out, k, Get4(bt, k) * Ld);
                                         }
                                     }
-                                    pool.Q(Q_LMIS + c, slot) = out;
+                                    tile.q[c][threadIdx.x] = out;
                                 }
+                                StoreSpectrumLines(tile, pool, Q_LMIS, slot, go);   // whole 128-B lines, as for the light sample
                                 if (fNonBlack && go) {
                                     Ray mr = SpawnRay(isect, wi);
                                     pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
@@ -2593,7 +2603,10 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
     const dim3 grid(1), block(BLOCK), travGrid(1);
     const Pool &pool = sub.pool;
     std::vector<int> flags(poolN);
-    auto F4 = [&](int plane, uint32_t slot, float *dst) { return hipMemcpy(dst, pool.r + (size_t)plane * poolN + slot, 16, hipMemcpyDeviceToHost); };
+    auto F4 = [&](int plane, uint32_t slot, float *dst) {   // Pool::R
+        const float4 *src = plane < R_HIT ? pool.r + ((((size_t)(plane >> 1) * poolN + slot) << 1) + (plane & 1)) : pool.r + (size_t)plane * poolN + slot;
+        return hipMemcpy(dst, src, 16, hipMemcpyDeviceToHost);
+    };
     auto I1 = [&](int plane, uint32_t slot, int *dst) { return hipMemcpy(dst, pool.i + (size_t)plane * poolN + slot, 4, hipMemcpyDeviceToHost); };
     auto Spec = [&](int set, uint32_t slot, float *dst31) {
         float line[32];
