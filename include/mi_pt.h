@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -261,18 +261,32 @@ typedef struct mi_film {
     float max_sample_luminance;
 } mi_film;
 
-/* ---- Halton sampler (src/samplers/halton.cpp:65-127) */
+/* ---- samplers. HALTON (src/samplers/halton.cpp:65-127) and SOBOL (src/samplers/sobol.cpp, lowdiscrepancy.h:229-274) are
+ * global samplers: sample (pixel, n) is a pure function of its index, so a parallel render reproduces the reference sample
+ * for sample. RANDOM (src/samplers/random.cpp:42-60) draws from one PCG32 stream per film tile in the reference, in the order
+ * its thread happens to consume them -- the count per sample depends on the path -- which no parallel schedule can
+ * reproduce; here every camera sample owns a PCG32 stream of its own (sequence number = sample-bounds pixel index *
+ * samples_per_pixel + n, rng.h:98-105), consumed in the reference's order: the same estimator on other random numbers. */
+typedef enum mi_sampler_type { MI_SAMPLER_HALTON = 0, MI_SAMPLER_SOBOL = 1, MI_SAMPLER_RANDOM = 2 } mi_sampler_type;
+#define MI_SOBOL_MATRIX_SIZE 52 /* SobolMatrixSize, src/core/sobolmatrices.h:48 */
 typedef struct mi_sampler {
-    int64_t samples_per_pixel;
+    int64_t samples_per_pixel; /* SOBOL: rounded up to a power of two (sobol.h:52) */
     int32_t base_scales[2], base_exponents[2];
     int32_t sample_stride;
     int32_t mult_inverse[2];
     int32_t sample_at_pixel_center;
     int32_t n_dims;            /* dimensions with tables below */
-    const int32_t *primes;     /* [n_dims] */
+    const int32_t *primes;     /* [n_dims] (also the bases of the spatial light distribution's probes, whatever the sampler) */
     const int32_t *prime_sums; /* [n_dims] offset of each base's permutation */
     const uint16_t *perms;     /* [n_perms] ComputeRadicalInversePermutations prefix */
     uint32_t n_perms;
+    /* ABI v6 */
+    int32_t type;              /* mi_sampler_type */
+    int32_t sobol_resolution, sobol_log2_resolution; /* RoundUpPow2(max extent of the sample bounds), its log2 */
+    int32_t n_sobol_dims;
+    const uint32_t *sobol_matrices; /* [n_sobol_dims * 52] SobolMatrices32 */
+    const uint64_t *sobol_vdc;      /* [52] VdCSobolMatrices[log2_resolution - 1] */
+    const uint64_t *sobol_vdc_inv;  /* [52] VdCSobolMatricesInv[log2_resolution - 1] */
 } mi_sampler;
 
 typedef struct mi_integrator {

@@ -102,15 +102,60 @@ inline uint64_t InverseRadicalInverse(uint64_t inverse, int nDigits) {  // lowdi
 template <typename T>
 inline T Mod(T a, T b) { T result = a - (a / b) * b; return (T)((result < 0) ? result + b : result); }
 
-struct Sampler {  // GlobalSampler + HaltonSampler state for one pixel sample
+// SobolIntervalToIndex, lowdiscrepancy.h:229-249 (the two pixel-index matrices of the film's resolution travel in mi_sampler)
+static uint64_t SobolIntervalToIndex(const mi_sampler &s, uint64_t frame, int px, int py) {
+    const uint32_t m = (uint32_t)s.sobol_log2_resolution;
+    if (m == 0) return 0;
+    const uint32_t m2 = m << 1;
+    uint64_t index = uint64_t(frame) << m2;
+    uint64_t delta = 0;
+    for (int c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= s.sobol_vdc[c];
+    uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= s.sobol_vdc_inv[c];
+    return index;
+}
+// SobolSampleFloat, lowdiscrepancy.h:259-274 (no scrambling: SobolSampler::SampleDimension passes none)
+static float SobolSampleFloat(const mi_sampler &s, int64_t a, int dimension) {
+    uint32_t v = 0;
+    for (int i = dimension * MI_SOBOL_MATRIX_SIZE; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= s.sobol_matrices[i];
+    return std::min(v * 0x1p-32f, OneMinusEpsilon);
+}
+
+struct PCG32 {  // RNG, rng.h:61-144
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    void SetSequence(uint64_t initseq) {
+        state = 0u;
+        inc = (initseq << 1u) | 1u;
+        UniformUInt32();
+        state += 0x853c49e6748fea9bULL;
+        UniformUInt32();
+    }
+    uint32_t UniformUInt32() {
+        uint64_t oldstate = state;
+        state = oldstate * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+        uint32_t rot = (uint32_t)(oldstate >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    Float UniformFloat() { return std::min(OneMinusEpsilon, Float(UniformUInt32() * 0x1p-32f)); }
+};
+
+struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one pixel sample; RandomSampler with one stream per sample
     const mi_scene_desc &d;
     int64_t offsetForCurrentPixel = 0;
     int64_t intervalSampleIndex = 0;
     int dimension = 0;
+    int curPx = 0, curPy = 0;
+    PCG32 rng;
     explicit Sampler(const mi_scene_desc &d) : d(d) {}
     void StartPixel(int px, int py) {  // halton.cpp:98-118 (offset part of GetIndexForSample)
         const mi_sampler &s = d.sampler;
+        curPx = px; curPy = py;
         offsetForCurrentPixel = 0;
+        if (s.type != MI_SAMPLER_HALTON) return;
         const int kMaxResolution = 128;
         if (s.sample_stride > 1) {
             int pm[2] = {Mod(px, kMaxResolution), Mod(py, kMaxResolution)};
@@ -123,19 +168,38 @@ struct Sampler {  // GlobalSampler + HaltonSampler state for one pixel sample
         }
     }
     void StartSample(int64_t sampleNum) {
-        dimension = 0;
-        intervalSampleIndex = offsetForCurrentPixel + sampleNum * d.sampler.sample_stride;
-    }
-    Float SampleDimension(int64_t index, int dim) const {  // halton.cpp:120-127
         const mi_sampler &s = d.sampler;
+        dimension = 0;
+        if (s.type == MI_SAMPLER_SOBOL)   // SobolSampler::GetIndexForSample, sobol.cpp:42-45
+            intervalSampleIndex = (int64_t)SobolIntervalToIndex(s, (uint64_t)sampleNum, curPx - d.film.sample_bounds[0], curPy - d.film.sample_bounds[1]);
+        else if (s.type == MI_SAMPLER_RANDOM) {   // one stream per camera sample (see mi_sampler_type)
+            const int64_t w = d.film.sample_bounds[2] - d.film.sample_bounds[0];
+            const int64_t pix = (int64_t)(curPy - d.film.sample_bounds[1]) * w + (curPx - d.film.sample_bounds[0]);
+            rng.SetSequence((uint64_t)(pix * s.samples_per_pixel + sampleNum));
+        } else intervalSampleIndex = offsetForCurrentPixel + sampleNum * s.sample_stride;
+    }
+    Float SampleDimension(int64_t index, int dim) const {  // halton.cpp:120-127 / sobol.cpp:47-59
+        const mi_sampler &s = d.sampler;
+        if (s.type == MI_SAMPLER_SOBOL) {
+            Float v = SobolSampleFloat(s, index, dim);
+            if (dim == 0 || dim == 1) {   // remap the dimensions used for the pixel sample
+                v = v * s.sobol_resolution + d.film.sample_bounds[dim];
+                v = Clamp(v - (dim == 0 ? curPx : curPy), (Float)0, OneMinusEpsilon);
+            }
+            return v;
+        }
         if (s.sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;
         if (dim == 0) return RadicalInverse(d, dim, index >> s.base_exponents[0]);
         else if (dim == 1) return RadicalInverse(d, dim, index / s.base_scales[1]);
         else return ScrambledRadicalInverseBase(s.primes[dim], &s.perms[s.prime_sums[dim]], index);
     }
     // arrayStartDim == arrayEndDim == 5 (no sample arrays requested): no skipping, sampler.cpp:178-195
-    Float Get1D() { return SampleDimension(intervalSampleIndex, dimension++); }
+    Float Get1D() {
+        if (d.sampler.type == MI_SAMPLER_RANDOM) { ++dimension; return rng.UniformFloat(); }   // random.cpp:44-48
+        return SampleDimension(intervalSampleIndex, dimension++);
+    }
     void Get2D(Float u[2]) {
+        if (d.sampler.type == MI_SAMPLER_RANDOM) { dimension += 2; u[0] = rng.UniformFloat(); u[1] = rng.UniformFloat(); return; }   // random.cpp:50-54
         u[0] = SampleDimension(intervalSampleIndex, dimension);
         u[1] = SampleDimension(intervalSampleIndex, dimension + 1);
         dimension += 2;
@@ -1029,6 +1093,8 @@ float oracle_sample_dimension(const mi_scene_desc *desc, int px, int py, int64_t
     s.StartSample(sample_num);
     return s.SampleDimension(s.intervalSampleIndex, dim);
 }
+// SobolSampleFloat(index, dim) itself (lowdiscrepancy.h:259-274), for the reference's LowDiscrepancy.Sobol test.
+float oracle_sobol_sample(const mi_scene_desc *desc, int64_t index, int dim) { return SobolSampleFloat(desc->sampler, index, dim); }
 // Single triangle test (tests/shapes.cpp Triangle.*): p = 9 floats, ray = 7 floats.
 int oracle_tri_test(const float *p, const float *ray, float *out4) {
     Ray r(V3(ray[0], ray[1], ray[2]), V3(ray[3], ray[4], ray[5]), ray[6]);

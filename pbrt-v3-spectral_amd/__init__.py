@@ -107,7 +107,10 @@ class Sampler(C.Structure):
     _fields_ = [("samples_per_pixel", C.c_int64), ("base_scales", C.c_int32 * 2), ("base_exponents", C.c_int32 * 2),
                 ("sample_stride", C.c_int32), ("mult_inverse", C.c_int32 * 2), ("sample_at_pixel_center", C.c_int32),
                 ("n_dims", C.c_int32), ("primes", C.POINTER(C.c_int32)), ("prime_sums", C.POINTER(C.c_int32)),
-                ("perms", C.POINTER(C.c_uint16)), ("n_perms", C.c_uint32)]
+                ("perms", C.POINTER(C.c_uint16)), ("n_perms", C.c_uint32),
+                ("type", C.c_int32), ("sobol_resolution", C.c_int32), ("sobol_log2_resolution", C.c_int32),
+                ("n_sobol_dims", C.c_int32), ("sobol_matrices", C.POINTER(C.c_uint32)),
+                ("sobol_vdc", C.POINTER(C.c_uint64)), ("sobol_vdc_inv", C.POINTER(C.c_uint64))]
 
 
 class Integrator(C.Structure):

@@ -85,7 +85,36 @@ DEV uint64_t HaltonPixelOffset(const DScene &s, int px, int py) {  // halton.cpp
     if (s.sampleStride <= 1) return 0;
     return s.pixelOffsetTable[ModI(py, 128) * 128 + ModI(px, 128)];
 }
-DEV float SampleDimension(const DScene &s, uint64_t index, int dim) {  // halton.cpp:120-127
+// ---- Sampler "sobol": SobolIntervalToIndex / SobolSampleFloat, lowdiscrepancy.h:229-274; sobol.cpp:42-59
+static DEV_CALL float SobolSampleFloat(const uint32_t *__restrict__ matrices, uint64_t a, int dimension) {
+    uint32_t v = 0;
+    for (int i = dimension * MI_SOBOL_MATRIX_SIZE; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= matrices[i];
+    return minf((float)v * 0x1p-32f, kOneMinusEpsilon);
+}
+// ---- Sampler "random": RNG (PCG32), rng.h:61-144; one stream per camera sample (include/mi_pt.h, mi_sampler_type)
+DEV uint32_t PcgNext(uint64_t &state, uint64_t inc) {
+    const uint64_t oldstate = state;
+    state = oldstate * 0x5851f42d4c957f2dULL + inc;
+    const uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    const uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+DEV float PcgFloat(uint64_t &state, uint64_t inc) { return minf(kOneMinusEpsilon, (float)PcgNext(state, inc) * 0x1p-32f); }
+DEV uint64_t RandomStreamInc(const DScene &s, int px, int py, long long sampleNum) {
+    const long long w = s.sampleBounds[2] - s.sampleBounds[0];
+    const long long pix = (long long)(py - s.sampleBounds[1]) * w + (px - s.sampleBounds[0]);
+    return (((uint64_t)(pix * s.samplesPerPixel + sampleNum)) << 1u) | 1u;
+}
+DEV uint64_t RandomStreamStart(uint64_t inc) {   // RNG::SetSequence, rng.h:98-105
+    uint64_t state = 0u;
+    PcgNext(state, inc);
+    state += 0x853c49e6748fea9bULL;
+    PcgNext(state, inc);
+    return state;
+}
+
+DEV float SampleDimension(const DScene &s, uint64_t index, int dim) {  // halton.cpp:120-127 (dimensions 0 and 1 need the pixel: CameraSampleDims)
     if (s.sampleAtPixelCenter && (dim == 0 || dim == 1)) return 0.5f;
     if (dim == 0) return RadicalInverse(s, 0, index >> s.baseExponents[0]);
     else if (dim == 1) return RadicalInverse(s, 1, index / (uint64_t)s.baseScales[1]);
@@ -98,7 +127,79 @@ static DEV_CALL float ScrambledDimension(const int32_t *primes, const int32_t *p
     return ScrambledRadicalInverseBase(primes[dim], primeMagic[dim], &perms[primeSums[dim]], index);
 }
 DEV float SampleDimensionFrom2(const DScene &s, uint64_t index, int dim) {
+    if (s.samplerType == MI_SAMPLER_SOBOL) return SobolSampleFloat(s.sobolMatrices, index, dim);
     return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, index, dim);
+}
+
+// A path's view of its sampler: the sample's index (HALTON / SOBOL) or the state of its PCG32 stream (RANDOM), and the next
+// dimension. Get1D = Sampler::Get1D for dimensions >= 5 (sampler.cpp:178-195, random.cpp:44-48). The stream's increment
+// is recomputed from the slot's pixel and sample number when a RANDOM draw happens (`pixelWord`, `sampleNum`: planes
+// I_PIXEL / I_SAMPLE), so the index-based samplers keep no extra value alive across the shading kernel.
+struct PathSampler {
+    uint64_t index;
+    int dim;
+};
+// (Nothing here may take the address of the kernel's DScene argument: that would move the whole argument block into
+// private memory and send every later field access through scratch -- measured: k_shade 2.3x slower.)
+DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelPlane, const int *__restrict__ samplePlane, uint32_t slot) {
+    if (s.samplerType == MI_SAMPLER_RANDOM) {
+        const int pixelWord = pixelPlane[slot];
+        const uint64_t inc = RandomStreamInc(s, (int)(short)(pixelWord & 0xffff), pixelWord >> 16, (long long)samplePlane[slot]);
+        uint64_t state = ps.index;
+        const float u = PcgFloat(state, inc);
+        ps.index = state;
+        ++ps.dim;
+        return u;
+    }
+    return SampleDimensionFrom2(s, ps.index, ps.dim++);
+}
+// GetCameraSample (sampler.cpp:46-52) of sample `sampleNum` of pixel (px, py): pFilm offsets = dims 0, 1; time = dim 2;
+// pLens = dims 3, 4. Returns the sample's index (or, RANDOM, its stream state after the five draws).
+struct SobolCamera { uint64_t index; float u0, u1, lu, lv; };
+static DEV_CALL SobolCamera CameraSampleSobol(const uint32_t *__restrict__ matrices, const uint64_t *__restrict__ vdc, const uint64_t *__restrict__ vdcInv,
+                                              int log2Resolution, int resolution, int sb0, int sb1, int px, int py, uint64_t frame, bool lens) {
+    SobolCamera r;
+    r.lu = r.lv = 0.f;
+    uint64_t index = 0;
+    const uint32_t m = (uint32_t)log2Resolution;
+    if (m != 0) {   // SobolIntervalToIndex, lowdiscrepancy.h:229-249
+        index = frame << (m << 1);
+        uint64_t delta = 0;
+        for (int c = 0; frame; frame >>= 1, ++c)
+            if (frame & 1) delta ^= vdc[c];
+        uint64_t b = ((((uint64_t)(uint32_t)(px - sb0)) << m) | (uint64_t)(uint32_t)(py - sb1)) ^ delta;
+        for (int c = 0; b; b >>= 1, ++c)
+            if (b & 1) index ^= vdcInv[c];
+    }
+    r.index = index;
+    float v0 = SobolSampleFloat(matrices, index, 0), v1 = SobolSampleFloat(matrices, index, 1);
+    v0 = v0 * (float)resolution + (float)sb0;   // remap the dimensions used for the pixel sample, sobol.cpp:54-57
+    v1 = v1 * (float)resolution + (float)sb1;
+    r.u0 = clampf(v0 - (float)px, 0.f, kOneMinusEpsilon);
+    r.u1 = clampf(v1 - (float)py, 0.f, kOneMinusEpsilon);
+    if (lens) { r.lu = SobolSampleFloat(matrices, index, 3); r.lv = SobolSampleFloat(matrices, index, 4); }
+    return r;
+}
+DEV uint64_t CameraSampleDims(const DScene &s, int px, int py, long long sampleNum, float *u0, float *u1, float *lu, float *lv) {
+    *lu = *lv = 0.f;
+    if (s.samplerType == MI_SAMPLER_RANDOM) {
+        const uint64_t inc = RandomStreamInc(s, px, py, sampleNum);
+        uint64_t state = RandomStreamStart(inc);
+        *u0 = PcgFloat(state, inc); *u1 = PcgFloat(state, inc);
+        (void)PcgFloat(state, inc);   // time
+        *lu = PcgFloat(state, inc); *lv = PcgFloat(state, inc);
+        return state;
+    }
+    if (s.samplerType == MI_SAMPLER_SOBOL) {
+        const SobolCamera r = CameraSampleSobol(s.sobolMatrices, s.sobolVdc, s.sobolVdcInv, s.sobolLog2Resolution, s.sobolResolution,
+                                                s.sampleBounds[0], s.sampleBounds[1], px, py, (uint64_t)sampleNum, s.camera.lens_radius > 0);
+        *u0 = r.u0; *u1 = r.u1; *lu = r.lu; *lv = r.lv;
+        return r.index;
+    }
+    const uint64_t index = HaltonPixelOffset(s, px, py) + (uint64_t)sampleNum * (uint64_t)s.sampleStride;
+    *u0 = SampleDimension(s, index, 0); *u1 = SampleDimension(s, index, 1);
+    if (s.camera.lens_radius > 0) { *lu = SampleDimension(s, index, 3); *lv = SampleDimension(s, index, 4); }
+    return index;
 }
 
 // ------------------------------------------------------------------ lights

@@ -70,6 +70,11 @@ struct DScene {
     float maxSampleLuminance;
     // sampler
     int baseScales[2], baseExponents[2], sampleStride, multInverse[2], sampleAtPixelCenter;
+    int samplerType;                       // mi_sampler_type
+    int sobolResolution, sobolLog2Resolution;
+    const uint32_t *sobolMatrices;         // [n_sobol_dims * 52]
+    const uint64_t *sobolVdc, *sobolVdcInv;
+    long long samplesPerPixel;             // (RANDOM: the stream number of a camera sample)
     // integrator
     int maxDepth;
     float rrThreshold;

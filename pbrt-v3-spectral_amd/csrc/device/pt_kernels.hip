@@ -493,7 +493,7 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 #define MIPT_TRAV_BLOCKS_PER_CU 4
 #endif
 #ifndef MIPT_REFILL_BELOW
-#define MIPT_REFILL_BELOW 32
+#define MIPT_REFILL_BELOW 44   // (same-box A/B with the two-level records: 44 against 32, killeroo +1 %, the 10M-triangle scene +2 %)
 #endif
 constexpr int TRAV_BLOCKS_PER_CU = MIPT_TRAV_BLOCKS_PER_CU;
 constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
@@ -1157,12 +1157,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             }
         }
         if (got) {
-            const uint64_t index = HaltonPixelOffset(s, px, py) + (uint64_t)sampleNum * (uint64_t)s.sampleStride;
             // GetCameraSample (sampler.cpp:46-52): pFilm = dims 0,1; time = dim 2; pLens = dims 3,4
-            float u0 = SampleDimension(s, index, 0), u1 = SampleDimension(s, index, 1);
+            float u0, u1, lu, lv;
+            const uint64_t index = CameraSampleDims(s, px, py, sampleNum, &u0, &u1, &lu, &lv);
             float pfx = (float)px + u0, pfy = (float)py + u1;
-            float lu = 0, lv = 0;
-            if (s.camera.lens_radius > 0) { lu = SampleDimension(s, index, 3); lv = SampleDimension(s, index, 4); }
             Ray ray;
             CameraRay(s, pfx, pfy, lu, lv, &ray);
             ++cam;
@@ -1221,7 +1219,6 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 }
 
 // (the shading kernel's dimensions start after the camera sample's, so dim >= 5 here)
-DEV float Get1D(const DScene &s, uint64_t index, int &dim) { return SampleDimensionFrom2(s, index, dim++); }
 
 // ------------------------------------------------------------------ shade
 // One path vertex per lane, for the slots of one material class (queue built by
@@ -1391,9 +1388,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     TexDifferentials td;
                     td.dudx = td.dvdx = td.dudy = td.dvdy = 0;
                     if (flags & F_DIFF) {   // SurfaceInteraction::ComputeDifferentials, interaction.cpp:99-143
-                        const uint64_t idx = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
                         float lu = 0.f, lv = 0.f;
-                        if (s.camera.lens_radius > 0) { lu = SampleDimension(s, idx, 3); lv = SampleDimension(s, idx, 4); }
+                        if (s.camera.lens_radius > 0) {   // the camera sample's lens position again
+                            const int pixw = pool.I(I_PIXEL, slot);
+                            float cu0, cu1;
+                            CameraSampleDims(s, (int)(short)(pixw & 0xffff), pixw >> 16, (long long)pool.I(I_SAMPLE, slot), &cu0, &cu1, &lu, &lv);
+                        }
                         const CamDifferentials cd = CameraDifferentials(s, pool.F(P_FILMX, slot), pool.F(P_FILMY, slot), lu, lv, ro, rd, s.invSqrtSpp);
                         td = ComputeDifferentials(isect.p, isect.n, isect.dpdu, tsh.dpdv, cd);
                     }
@@ -1428,8 +1428,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             }
             // BSDF ctor, reflection.h:170-176 (after Bump(): it reads the shading geometry)
             fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
-            const uint64_t index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
-            int dim = pool.I(I_DIM, slot);
+            PathSampler ps;
+            ps.index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
+            ps.dim = pool.I(I_DIM, slot);
+            const int *__restrict__ pixelPlane = pool.i + (size_t)I_PIXEL * pool.n, *__restrict__ samplePlane = pool.i + (size_t)I_SAMPLE * pool.n;
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
             // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
             if (NumComponents(fr, nonSpec) > 0) {
@@ -1439,10 +1441,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const uint32_t di = LightDistribIndex(s, isect.p);
                     float selPdf;
                     const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
-                                                        s.ldFuncInt[di], (int)s.nLights, Get1D(s, index, dim), &selPdf);
+                                                        s.ldFuncInt[di], (int)s.nLights, Get1D(s, ps, pixelPlane, samplePlane, slot), &selPdf);
                     if (selPdf != 0) {
-                        const float uL0 = Get1D(s, index, dim), uL1 = Get1D(s, index, dim);
-                        const float uS0 = Get1D(s, index, dim), uS1 = Get1D(s, index, dim);
+                        const float uL0 = Get1D(s, ps, pixelPlane, samplePlane, slot), uL1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
+                        const float uS0 = Get1D(s, ps, pixelPlane, samplePlane, slot), uS1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
                         const mi_light &light = s.lights[lightNum];
                         const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
                         const Divisor selDiv = MakeDivisor(selPdf);
@@ -1550,7 +1552,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 V3 wo = -rd, wi;
                 float pdf = 0;
                 int sflags = 0;
-                const float u0 = Get1D(s, index, dim), u1 = Get1D(s, index, dim);
+                const float u0 = Get1D(s, ps, pixelPlane, samplePlane, slot), u1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
                 BSDFEvalT<NL> ev;
                 const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
                 bool fNonBlack = false;
@@ -1589,7 +1591,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         bool killed = false;
                         if (maxRR < s.rrThreshold && bounces > 3) {
                             float q = maxf(.05f, 1 - maxRR);
-                            if (Get1D(s, index, dim) < q) killed = true;
+                            if (Get1D(s, ps, pixelPlane, samplePlane, slot) < q) killed = true;
                             else {
                                 const Divisor inv = MakeDivisor(1 - q);
 #pragma unroll 1
@@ -1612,7 +1614,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 }
                 if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
             }
-            pool.I(I_DIM, slot) = dim;
+            pool.I(I_DIM, slot) = ps.dim;
+            if (s.samplerType == MI_SAMPLER_RANDOM) {   // the stream moves on with the path
+                pool.I(I_IDXLO, slot) = (int)(uint32_t)ps.index;
+                pool.I(I_IDXHI, slot) = (int)(uint32_t)(ps.index >> 32);
+            }
         }
         if (!passThrough) {
             if (finished) {
@@ -1867,7 +1873,16 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (l.type == MI_LIGHT_DIFFUSE_AREA && (l.shape >= 0 ? (uint32_t)l.shape >= d->n_tris : (uint32_t)(~l.shape) >= d->n_spheres)) { g_err = "area light shape index out of range"; return MI_ERR_INVALID; }
     }
     if (d->integrator.n_ca_bands < 1 || d->integrator.n_ca_bands > MI_NSPEC) { g_err = "n_ca_bands must be in [1, 31]"; return MI_ERR_INVALID; }
-    if (d->sampler.n_dims < 6 + 8 * d->integrator.max_depth * d->integrator.n_ca_bands) {
+    if (d->sampler.type != MI_SAMPLER_HALTON && d->sampler.type != MI_SAMPLER_SOBOL && d->sampler.type != MI_SAMPLER_RANDOM) { g_err = "unknown mi_sampler.type"; return MI_ERR_INVALID; }
+    if (d->sampler.type == MI_SAMPLER_SOBOL) {
+        if (!d->sampler.sobol_matrices || !d->sampler.sobol_vdc || !d->sampler.sobol_vdc_inv || d->sampler.sobol_log2_resolution < 0 ||
+            d->sampler.sobol_log2_resolution > 25 || d->sampler.sobol_resolution != (1 << d->sampler.sobol_log2_resolution)) { g_err = "malformed Sobol' sampler tables"; return MI_ERR_INVALID; }
+        if (d->sampler.n_sobol_dims < 6 + 8 * d->integrator.max_depth * d->integrator.n_ca_bands) {
+            g_err = "Sobol' matrices cover too few dimensions for max_depth x n_ca_bands";
+            return MI_ERR_INVALID;
+        }
+    }
+    if (d->sampler.n_dims < (d->sampler.type == MI_SAMPLER_HALTON ? 6 + 8 * d->integrator.max_depth * d->integrator.n_ca_bands : 5)) {
         g_err = "Halton tables cover too few dimensions for max_depth x n_ca_bands (the reference's prime table ends at 1000)";
         return MI_ERR_INVALID;
     }
@@ -2157,6 +2172,12 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
     UP(d->sampler.perms, d->sampler.n_perms, s.perms);
     UP(d->film.filter_table, 256, s.filterTable);
+    s.sobolMatrices = nullptr; s.sobolVdc = nullptr; s.sobolVdcInv = nullptr;
+    if (d->sampler.type == MI_SAMPLER_SOBOL) {
+        UP(d->sampler.sobol_matrices, (size_t)d->sampler.n_sobol_dims * MI_SOBOL_MATRIX_SIZE, s.sobolMatrices);
+        UP(d->sampler.sobol_vdc, (size_t)MI_SOBOL_MATRIX_SIZE, s.sobolVdc);
+        UP(d->sampler.sobol_vdc_inv, (size_t)MI_SOBOL_MATRIX_SIZE, s.sobolVdcInv);
+    }
     {   // division magics and the per-pixel Halton offsets (GetIndexForSample, halton.cpp:98-118)
         std::vector<uint64_t> magic(d->sampler.n_dims);
         for (int i = 0; i < d->sampler.n_dims; ++i) {
@@ -2256,6 +2277,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     for (int i = 0; i < 2; ++i) { s.baseScales[i] = d->sampler.base_scales[i]; s.baseExponents[i] = d->sampler.base_exponents[i]; s.multInverse[i] = d->sampler.mult_inverse[i]; }
     s.sampleStride = d->sampler.sample_stride;
     s.sampleAtPixelCenter = d->sampler.sample_at_pixel_center;
+    s.samplerType = d->sampler.type;
+    s.samplesPerPixel = d->sampler.samples_per_pixel;
+    s.sobolResolution = d->sampler.sobol_resolution;
+    s.sobolLog2Resolution = d->sampler.sobol_log2_resolution;
     s.maxDepth = d->integrator.max_depth;
     s.rrThreshold = d->integrator.rr_threshold;
     s.nBands = d->integrator.n_ca_bands;

@@ -795,11 +795,21 @@ void Api::WorldEnd() {
     // ---- sampler (CreateHaltonSampler + ctor, halton.cpp:65-96,133-140)
     {
         scene->samplerName = samplerName;
-        if (samplerName != "halton")
-            Err("Sampler \"" + samplerName + "\" is outside the hot-path scope (SURVEY 2 row 23); using halton.");
         mi_sampler &s = d.sampler;
-        int nsamp = samplerParams.FindOneInt("pixelsamples", 16);
+        s.type = MI_SAMPLER_HALTON;
+        if (samplerName == "sobol") s.type = MI_SAMPLER_SOBOL;          // CreateSobolSampler, sobol.cpp:66-71
+        else if (samplerName == "random") s.type = MI_SAMPLER_RANDOM;   // CreateRandomSampler, random.cpp:62-65
+        else if (samplerName != "halton")
+            Err("Sampler \"" + samplerName + "\" is not built on this path (\"stratified\" and \"02sequence\" carry one RNG through the "
+                "pixels of a tile, SURVEY 8f item 3); using halton.");
+        int nsamp = samplerParams.FindOneInt("pixelsamples", s.type == MI_SAMPLER_HALTON ? 16 : (s.type == MI_SAMPLER_SOBOL ? 16 : 4));
         if (ov.spp > 0) nsamp = ov.spp;
+        if (s.type == MI_SAMPLER_SOBOL) {   // GlobalSampler(RoundUpPow2(samplesPerPixel)), sobol.h:52-57
+            int p2 = 1;
+            while (p2 < nsamp) p2 *= 2;
+            if (p2 != nsamp) Warn("Non power-of-two sample count rounded up to " + std::to_string(p2) + " for SobolSampler.");
+            nsamp = p2;
+        }
         s.samples_per_pixel = nsamp;
         s.sample_at_pixel_center = samplerParams.FindOneBool("samplepixelcenter", false) ? 1 : 0;
         int res[2] = {d.film.sample_bounds[2] - d.film.sample_bounds[0], d.film.sample_bounds[3] - d.film.sample_bounds[1]};
@@ -867,6 +877,14 @@ void Api::WorldEnd() {
         nDims = std::max(64, std::min(nDims, 1000));  // PrimeTableSize = 1000
         ComputeHaltonTables(nDims, &scene->primes, &scene->primeSums, &scene->perms);
         d.sampler.n_dims = nDims;
+        if (d.sampler.type == MI_SAMPLER_SOBOL) {
+            const int extent = std::max(d.film.sample_bounds[2] - d.film.sample_bounds[0], d.film.sample_bounds[3] - d.film.sample_bounds[1]);
+            const int nSobol = std::min(nDims, 256);
+            if (!ComputeSobolTables(extent, nSobol, scene, &d.sampler.sobol_resolution, &d.sampler.sobol_log2_resolution)) {
+                Err("Sampler \"sobol\": film resolution beyond the tabulated pixel-index matrices; using halton.");
+                d.sampler.type = MI_SAMPLER_HALTON;
+            } else d.sampler.n_sobol_dims = nSobol;
+        }
     }
     // ---- accelerator (CreateBVHAccelerator, bvh.cpp:740-762)
     {
@@ -1391,6 +1409,9 @@ void HostScene::Finalize() {
     d.sampler.prime_sums = primeSums.data();
     d.sampler.perms = perms.data();
     d.sampler.n_perms = (uint32_t)perms.size();
+    d.sampler.sobol_matrices = sobolMatrices.empty() ? nullptr : sobolMatrices.data();
+    d.sampler.sobol_vdc = sobolVdc.empty() ? nullptr : sobolVdc.data();
+    d.sampler.sobol_vdc_inv = sobolVdcInv.empty() ? nullptr : sobolVdcInv.data();
 }
 
 HostScene *LoadSceneFile(const std::string &path, const LoadOverrides &ov, std::string *err) {

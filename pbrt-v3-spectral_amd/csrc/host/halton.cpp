@@ -8,6 +8,7 @@
 
 namespace mipt {
 namespace {
+#include "sobol_tables.inc"
 
 struct PCG32 {  // rng.h:61-144
     uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
@@ -57,6 +58,24 @@ void ComputeHaltonTables(int nDims, std::vector<int32_t> *primes, std::vector<in
         }
         p += count;
     }
+}
+
+// Sampler "sobol" (sobol.h:51-62): resolution = RoundUpPow2(max extent of the sample bounds); the generator matrices of the
+// first nDims dimensions and the two pixel-index matrices of that resolution (SobolIntervalToIndex, lowdiscrepancy.h:229-249).
+bool ComputeSobolTables(int extent, int nDims, HostScene *scene, int *resolution, int *log2Resolution) {
+    int res = 1, lg = 0;
+    while (res < extent) { res *= 2; ++lg; }
+    *resolution = res;
+    *log2Resolution = lg;
+    if (lg > kSobolResolutions || nDims > kSobolDims) return false;
+    scene->sobolMatrices.assign(kSobolMatrices32, kSobolMatrices32 + (size_t)nDims * kSobolMatrixSize);
+    scene->sobolVdc.assign(kSobolMatrixSize, 0);
+    scene->sobolVdcInv.assign(kSobolMatrixSize, 0);
+    if (lg > 0) {
+        scene->sobolVdc.assign(kVdCSobolMatrices[lg - 1], kVdCSobolMatrices[lg - 1] + kSobolMatrixSize);
+        scene->sobolVdcInv.assign(kVdCSobolMatricesInv[lg - 1], kVdCSobolMatricesInv[lg - 1] + kSobolMatrixSize);
+    }
+    return true;
 }
 
 }  // namespace mipt

@@ -53,6 +53,8 @@ struct HostScene {
     // sampler tables
     std::vector<int32_t> primes, primeSums;
     std::vector<uint16_t> perms;
+    std::vector<uint32_t> sobolMatrices;          // Sampler "sobol": the first n_sobol_dims generator matrices
+    std::vector<uint64_t> sobolVdc, sobolVdcInv;  // ... and the pixel-index matrices of the film's resolution
     // output
     std::string filmFilename = "pbrt.exr";
     bool spectralFlag = true;
@@ -81,6 +83,8 @@ void BuildBVH(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, SplitM
 void ComputeHaltonTables(int nDims, std::vector<int32_t> *primes, std::vector<int32_t> *primeSums,
                          std::vector<uint16_t> *perms);
 float RadicalInverseHost(int baseIndex, uint64_t a);  // unscrambled, lowdiscrepancy.cpp:389-424
+// Sobol' tables for a film whose sample bounds span `extent` pixels (sobol.h:51-62); false when the resolution is beyond the tables.
+bool ComputeSobolTables(int extent, int nDims, HostScene *scene, int *resolution, int *log2Resolution);
 
 // Light-selection distributions, src/core/lightdistrib.cpp:48-300.
 void BuildLightDistribution(HostScene *scene, const std::string &strategy);

@@ -11,7 +11,7 @@
 namespace mipt {
 namespace {
 
-const char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '2'};
+const char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '3'};
 
 struct Out {
     FILE *f;
@@ -58,6 +58,7 @@ void Fields(IO &io, S &s) {   // the same walk writes and reads
     io.Vec(s.meshes); io.Vec(s.spheres); io.Vec(s.materials); io.Vec(s.lights); io.Vec(s.textures);
     io.Vec(s.ldFunc); io.Vec(s.ldCdf); io.Vec(s.ldFuncInt);
     io.Vec(s.primes); io.Vec(s.primeSums); io.Vec(s.perms);
+    io.Vec(s.sobolMatrices); io.Vec(s.sobolVdc); io.Vec(s.sobolVdcInv);
     io.Str(s.filmFilename); io.Str(s.integratorName); io.Str(s.samplerName); io.Str(s.lightStrategy);
     io.Strs(s.warnings); io.Strs(s.errors);
 }

@@ -305,6 +305,30 @@ def test_procedural_many_mesh_scene_against_oracle(pt, ob, tmp_path):
     _parity(pt, ob, s, "procedural 200k triangles 96x96 16spp", exact=False, rel_tol=1e-3, counter_tol=5e-4)
 
 
+@pytest.mark.parametrize("sampler,lens", [("sobol", False), ("sobol", True), ("random", False), ("random", True)])
+def test_sobol_and_random_samplers_against_oracle(pt, ob, sampler, lens):
+    """Sampler "sobol" (sobol.cpp, lowdiscrepancy.h:229-274: the sample of (pixel, n) is a pure function of its index, as
+    with Halton) and Sampler "random" (one PCG32 stream per camera sample, include/mi_pt.h mi_sampler_type) on the material
+    zoo, with and without a lens (dimensions 3 / 4; the random stream draws them whether or not there is a lens)."""
+    txt = st.material_zoo(res=64, spp=16, depth=6).replace('Sampler "halton"', 'Sampler "%s"' % sampler)
+    if lens:
+        txt = txt.replace('Camera "perspective" "float fov" [40]', 'Camera "perspective" "float fov" [40] "float lensradius" [.15] "float focaldistance" [8]')
+    s = pt.Scene(text=txt)
+    assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2}[sampler]
+    _parity(pt, ob, s, "zoo sampler %s lens=%s" % (sampler, lens))
+
+
+def test_sobol_sampler_on_the_killeroo_frame(pt, ob):
+    """700x700 (Sobol' resolution 1024, log2 10), 4 spp: exact parity on the BASELINE scene under the second global sampler."""
+    import os
+    text = open(KILLEROO).read().replace('Sampler "halton"', 'Sampler "sobol"')
+    assert 'Sampler "sobol"' in text
+    s = pt.Scene(text=text, base_dir=os.path.dirname(KILLEROO), spp=4)
+    assert s.desc.sampler.sobol_resolution == 1024 and s.desc.sampler.sobol_log2_resolution == 10
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "killeroo sobol 4spp")
+    assert integ.counters.camera_rays == 700 * 700 * 4
+
+
 def _killeroo_spectralpath(pt, n_bands, **kw):
     import os
     text = open(KILLEROO).read().replace('Integrator "path"',

@@ -401,3 +401,62 @@ def test_checkerboard_known_answers(pt, ob):
     assert abs(a[0] - 0.75) < 1e-5 and np.allclose(spec, 2 * 0.25 + 6 * 0.75, rtol=1e-5)
     a, spec = look(1, (1.0001, 0.5), (0.25, 0), (0, 0.25))       # "none": point sampled whatever the footprint
     assert a[0] == 1.0 and np.all(spec == np.float32(6.0))
+
+
+# ------------------------------------------------------------------ Sampler "sobol" / "random" 
+def _sampler_scene(pt, name, res, spp, extra=""):
+    txt = st._HEAD % dict(res=res, spp=spp, depth=1, extra="") + 'Shape "sphere"\nWorldEnd\n'
+    return pt.Scene(text=txt.replace('Sampler "halton" "integer pixelsamples" [%d]' % spp,
+                                     'Sampler "%s" "integer pixelsamples" [%d] %s' % (name, spp, extra)))
+
+
+def test_sobol_first_dimension_is_the_base_2_radical_inverse(pt, ob):
+    """tests/sampling.cpp:128-133: SobolSampleFloat(i, 0, 0) == ReverseBits32(i) * 2^-32 for i < 8192."""
+    s = _sampler_scene(pt, "sobol", 16, 4)
+    assert s.desc.sampler.type == 1 and s.errors == []
+    lib = ob.lib()
+    lib.oracle_sobol_sample.argtypes = [C.POINTER(type(s.desc)), C.c_int64, C.c_int]
+    lib.oracle_sobol_sample.restype = C.c_float
+    for i in range(8192):
+        want = np.float32(int("{:032b}".format(i)[::-1], 2)) * np.float32(2.3283064365386963e-10)
+        assert lib.oracle_sobol_sample(s.desc_ptr, i, 0) == want, i
+
+
+@pytest.mark.parametrize("log_samples", [2, 4, 7, 10])
+def test_sobol_pixel_samples_fill_the_elementary_intervals(pt, ob, log_samples):
+    """tests/sampling.cpp:139-186 (LowDiscrepancy.ElementaryIntervals, the Sobol' case): the 2^k film samples of pixel
+    (0, 0) of a 10x10 film put exactly one sample into every elementary interval 2^-i x 2^-(k-i) -- which pins
+    SobolIntervalToIndex, the pixel remap of dimensions 0 / 1 and the first two generator matrices at once."""
+    n = 1 << log_samples
+    s = _sampler_scene(pt, "sobol", 10, n)
+    assert s.desc.sampler.sobol_resolution == 16 and s.desc.sampler.sobol_log2_resolution == 4
+    lib = ob.lib()
+    for px, py in ((0, 0), (7, 3)):
+        pts = np.array([[lib.oracle_sample_dimension(s.desc_ptr, px, py, k, 0), lib.oracle_sample_dimension(s.desc_ptr, px, py, k, 1)]
+                        for k in range(n)], np.float64)
+        assert (pts >= 0).all() and (pts < 1).all()
+        for i in range(log_samples + 1):
+            nx, ny = 1 << i, 1 << (log_samples - i)
+            idx = np.floor(pts[:, 1] * ny).astype(int) * nx + np.floor(pts[:, 0] * nx).astype(int)
+            assert len(np.unique(idx)) == n, (px, py, i)
+
+
+def test_sobol_rounds_the_sample_count_up_to_a_power_of_two(pt):
+    s = _sampler_scene(pt, "sobol", 8, 12)
+    assert s.spp == 16 and any("rounded up to 16" in w for w in s.warnings)
+
+
+@pytest.mark.parametrize("sampler", ["sobol", "random"])
+def test_furnace_scenes_with_the_other_samplers(pt, ob, sampler):
+    """tests/analytic_scenes.cpp:250-267 runs every furnace scene under every sampler: radiance 1 +- 0.02."""
+    for text in (st.furnace_point(), st.furnace_area(), st.furnace_uber()):
+        text = text.replace('Sampler "halton"', 'Sampler "%s"' % sampler)
+        s = pt.Scene(text=text)
+        assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2}[sampler]
+        film, weight, c, _ = ob.render(s, n_threads=4)
+        assert abs(float((film / weight[..., None]).mean()) - 1.0) < 0.02, sampler
+
+
+def test_other_pixel_samplers_are_reported(pt):
+    s = _sampler_scene(pt, "stratified", 8, 4)
+    assert any("stratified" in e for e in s.errors) and s.desc.sampler.type == 0
