@@ -1170,8 +1170,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
 
             pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
             pool.I(I_SAMPLE, slot) = (int)sampleNum;
-            pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
-            pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
+            if (!(restart && s.samplerType == MI_SAMPLER_RANDOM)) {   // (a restarted band draws on from where its stream stands)
+                pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
+                pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
+            }
             if (!restart) pool.I(I_DIM, slot) = 5;
             if (nBands > 1) {
                 pool.I(I_BAND, slot) = restart ? band + 1 : 0;

@@ -498,7 +498,7 @@ def random_scene(seed, res=32, spp=8):
     filt = rng.choice(["box", "triangle", "gaussian", "mitchell"])
     out.append('PixelFilter "%s"' % filt)
     out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (res, res))
-    out.append('Sampler "halton" "integer pixelsamples" [%d]' % spp)
+    out.append('Sampler "%s" "integer pixelsamples" [%d]' % (rng.choice(["halton", "halton", "sobol", "random"]), spp))
     integ = "spectralpath" if rng.random() < .25 else "path"
     extra = ' "integer numCABands" [%d]' % int(rng.integers(2, 5)) if integ == "spectralpath" else ""
     out.append('Integrator "%s" "integer maxdepth" [%d] "string lightsamplestrategy" "%s"%s'
@@ -570,6 +570,17 @@ def random_scene(seed, res=32, spp=8):
             alpha = ' "texture alpha" "mask"' if rng.random() < .35 else (' "texture shadowalpha" "mask"' if rng.random() < .2 else "")
             out.append('  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.8 0  1 -.8 0  1 .8 0  -1 .8 0] "float uv" [0 0 1 0 1 1 0 1]%s' % alpha)
         out.append("AttributeEnd")
+    # object instancing (api.cpp:1544-1615): a named object of two shapes with their own materials, instanced under
+    # rotated, scaled and mirrored transforms
+    if rng.random() < .6:
+        out.append('AttributeBegin\n  %s\nObjectBegin "thing"' % material())
+        out.append('  Shape "sphere" "float radius" [%.2f]' % r(.15, .35))
+        out.append('  %s\n  Translate 0 %.2f 0\n  %s' % (material(), r(.3, .6), _curved_patch(3, 2)))
+        out.append("ObjectEnd\nAttributeEnd")
+        for _ in range(int(rng.integers(1, 4))):
+            out.append("AttributeBegin\n  Translate %.2f %.2f %.2f\n  Rotate %.1f 0 1 0\n  Scale %.2f %.2f %.2f" %
+                       (r(-3, 3), r(.3, 2), r(-2, 2), r(0, 360), r(.5, 1.5) * (-1 if rng.random() < .3 else 1), r(.5, 1.5), r(.5, 1.5)))
+            out.append('  ObjectInstance "thing"\nAttributeEnd')
     out.append("WorldEnd")
     return "\n".join(out) + "\n"
 
