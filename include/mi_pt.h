@@ -394,6 +394,23 @@ int mi_pt_texture_lookup(mi_pt *pt, int32_t tex, uint32_t n, const float *querie
  * scene does not use "lightsamplestrategy" "spatial" (or has no lights). Host pointers. */
 int mi_pt_light_distribution(mi_pt *pt, float *func, float *func_int, uint64_t capacity_voxels);
 
+/* ---- HLBVH build on the device (Accelerator "bvh" "string splitmethod" "hlbvh"; BVHAccel::HLBVHBuild,
+ * src/accelerators/bvh.cpp:404-638): Morton codes, stable radix sort, one LBVH treelet per run of equal top 12 bits
+ * (emitLBVH), and the treelets flattened into the depth-first 32-byte node array. The SAH tree over the (at most 4096)
+ * treelet roots (buildUpperSAH, bvh.cpp:534-638) is small serial host work: the caller supplies it as `upper`, which
+ * receives the treelets' root bounds (6 floats each: min xyz, max xyz) and node counts and returns the upper interior
+ * nodes (children given as final indices), their own final indices, the total node count and the final index of each
+ * treelet's first node. prim_bounds: n x {min xyz, max xyz}; nodes_out: capacity nodes_capacity (2 n is always enough);
+ * ordered_out: n primitive numbers in leaf order. The tree is the one the reference builds on one thread (leaves in
+ * Morton order): the host restatement in libmipt_host.so builds the same nodes, bit for bit. */
+typedef int (*mi_bvh_upper_fn)(void *user, uint32_t n_treelets, const float *root_bounds, const int32_t *treelet_sizes,
+                               mi_bvh_node *upper_nodes, int32_t *upper_index, uint32_t *n_upper, uint32_t *n_total,
+                               int32_t *treelet_offset);
+int mi_bvh_build_hlbvh(int device_ordinal, const float *prim_bounds, uint32_t n, int32_t max_prims_in_node, mi_bvh_upper_fn upper,
+                       void *user, mi_bvh_node *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes, int32_t *ordered_out,
+                       double *seconds);
+const char *mi_bvh_last_error(void);
+
 /* Parity tool: the state of ONE camera sample (pixel px, py; Halton sample number `sample`) vertex by vertex, for a
  * side-by-side comparison with the oracle's log of the same sample (oracle_path_log) when a film differs. One record of
  * MI_PATH_RECORD_FLOATS floats per path vertex (one wavefront iteration):

@@ -28,6 +28,7 @@ typedef struct mi_scene_overrides {
 typedef struct mi_scene_stats {
     int32_t n_triangles, n_spheres, n_meshes, interior_nodes, leaf_nodes, n_lights, n_materials;
     int32_t n_warnings, n_errors;
+    int32_t accel_on_device; /* 1: the BVH was built by libmipt_hip.so's kernels (splitmethod "hlbvh" with a GPU present) */
 } mi_scene_stats;
 
 int mi_scene_load_file(const char *path, const mi_scene_overrides *ov, mi_scene **out);

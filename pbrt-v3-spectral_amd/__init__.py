@@ -160,7 +160,7 @@ class SceneOverrides(C.Structure):
 
 class SceneStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_triangles", "n_spheres", "n_meshes", "interior_nodes", "leaf_nodes",
-                                          "n_lights", "n_materials", "n_warnings", "n_errors")]
+                                          "n_lights", "n_materials", "n_warnings", "n_errors", "accel_on_device")]
 
 
 RENDER_FILM_ON_DEVICE = 1

@@ -894,14 +894,25 @@ void Api::WorldEnd() {
         if (sm == "sah") method = SplitMethod::SAH;
         else if (sm == "middle") method = SplitMethod::Middle;
         else if (sm == "equal") method = SplitMethod::EqualCounts;
-        else if (sm == "hlbvh") { Warn("BVH split method \"hlbvh\" not built on this path (SURVEY 8f item 4). Using \"sah\"."); }
+        else if (sm == "hlbvh") method = SplitMethod::HLBVH;
         else Warn("BVH split method \"" + sm + "\" unknown.  Using \"sah\".");
         int maxPrims = accelParams.FindOneInt("maxnodeprims", 4);
         std::vector<Bounds3> bounds(pending.size());
         for (size_t i = 0; i < pending.size(); ++i) bounds[i] = pending[i].bounds;
         std::vector<int> order;
         const auto tb0 = std::chrono::steady_clock::now();
-        BuildBVH(bounds, maxPrims, method, &scene->nodes, &order, &scene->stats.interiorNodes, &scene->stats.leafNodes);
+        if (method == SplitMethod::HLBVH) {
+            // on the device when there is one (mi_bvh_build_hlbvh); the host restatement builds the same tree, node for node
+            std::string why;
+            double secs = 0;
+            const char *where = getenv("MIPT_HLBVH");   // "host": do not try the device
+            bool onDevice = !(where && std::string(where) == "host") &&
+                            BuildHLBVHOnDevice(bounds, maxPrims, 0, &scene->nodes, &order, &scene->stats.interiorNodes, &scene->stats.leafNodes, &secs, &why);
+            if (!onDevice) BuildHLBVH(bounds, maxPrims, &scene->nodes, &order, &scene->stats.interiorNodes, &scene->stats.leafNodes);
+            scene->hlbvhOnDevice = onDevice;
+            if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] HLBVH on the %s%s%s\n", onDevice ? "device" : "host", onDevice ? "" : ": ", onDevice ? "" : why.c_str());
+        } else
+            BuildBVH(bounds, maxPrims, method, &scene->nodes, &order, &scene->stats.interiorNodes, &scene->stats.leafNodes);
         if (getenv("MIPT_TIMING"))
             fprintf(stderr, "[mipt] BVH build over %zu primitives: %.3f s\n", bounds.size(),
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());

@@ -97,6 +97,7 @@ void mi_scene_get_stats(const mi_scene *s, mi_scene_stats *o) {
     o->interior_nodes = st.interiorNodes; o->leaf_nodes = st.leafNodes;
     o->n_lights = st.nLights; o->n_materials = st.nMaterials;
     o->n_warnings = (int)s->hs->warnings.size(); o->n_errors = (int)s->hs->errors.size();
+    o->accel_on_device = s->hs->hlbvhOnDevice ? 1 : 0;
 }
 
 const char *mi_scene_message(const mi_scene *s, int kind, int i) {

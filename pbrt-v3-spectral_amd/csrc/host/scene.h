@@ -58,6 +58,7 @@ struct HostScene {
     // output
     std::string filmFilename = "pbrt.exr";
     bool spectralFlag = true;
+    bool hlbvhOnDevice = false;   // splitmethod "hlbvh": the tree came from the device build
     std::string integratorName = "path", samplerName = "halton", lightStrategy = "spatial";
     std::vector<std::string> warnings, errors;
     SceneStats stats;
@@ -74,10 +75,20 @@ bool LoopSubdivide(int nLevels, const std::vector<int> &indices, const std::vect
 
 // SAH BVH2 build + depth-first flatten, src/accelerators/bvh.cpp:183-402,640-658.
 struct BuildPrim { Bounds3 bounds; };
-enum class SplitMethod { SAH, Middle, EqualCounts };
+enum class SplitMethod { SAH, Middle, EqualCounts, HLBVH };
 void BuildBVH(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, SplitMethod method,
               std::vector<mi_bvh_node> *nodes, std::vector<int> *orderedPrims, int *interior,
               int *leaves);
+
+// HLBVH, src/accelerators/bvh.cpp:404-638, in the order one thread builds it (bvh.cpp in this directory). The pieces are
+// exposed because the device build (mi_bvh_build_hlbvh) shares the upper SAH tree and is tested against the host tree.
+void BuildHLBVH(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, std::vector<mi_bvh_node> *nodes,
+                std::vector<int> *orderedPrims, int *interior, int *leaves);
+int BuildUpperSAH(uint32_t nTreelets, const float *rootBounds, const int32_t *treeletSizes, std::vector<mi_bvh_node> *upperNodes,
+                  std::vector<int> *upperIndex, int32_t *treeletOffset);   // returns the total node count
+// The same tree built by libmipt_hip.so's kernels (hlbvh_device.cpp); false (with `why`) when no device / library is there.
+bool BuildHLBVHOnDevice(const std::vector<Bounds3> &primBounds, int maxPrimsInNode, int device, std::vector<mi_bvh_node> *nodes,
+                        std::vector<int> *orderedPrims, int *interior, int *leaves, double *seconds, std::string *why);
 
 // Halton tables, src/core/lowdiscrepancy.cpp:2490-2504 (+ rng.h PCG32, sampling.h Shuffle).
 void ComputeHaltonTables(int nDims, std::vector<int32_t> *primes, std::vector<int32_t> *primeSums,
