@@ -164,7 +164,7 @@ struct WorkDesc {
     unsigned long long totalWork;
     int nTilesX, nTilesY, nTilesShard, shardIndex, shardCount;
     long long spp, sampleBegin;
-    int run;   // consecutive samples of a pixel handed out together (a power of two dividing spp, at most MIPT_WORK_RUN = 64)
+    int run;   // consecutive samples of a pixel handed out together (a power of two dividing spp, at most MIPT_WORK_RUN = 16)
 };
 
 DEV unsigned long long WaveSum(unsigned long long v) {
@@ -2395,7 +2395,8 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
     wd.sampleBegin = rp->sample_begin;
     wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
-    int runCap = 64;
+    int runCap = 16;   // (same-box A/B: 16 gives the shortest frame; longer runs shave k_generate further but put one pixel's
+                       // paths into whole waves of the other kernels, which costs them 2-5 %)
     if (const char *e = getenv("MIPT_WORK_RUN")) runCap = std::max(1, atoi(e));
     wd.run = 1;
     while (2 * wd.run <= runCap && wd.spp % (2 * wd.run) == 0) wd.run *= 2;
