@@ -61,6 +61,7 @@ constexpr int STACK_SPILL = 64 - STACK_LDS;     // deeper entries (pbrt allows 6
 // ---- float planes
 enum : int {
     P_FILMX = 0, P_FILMY,
+    P_TENC0, P_TENC1, P_TENC2, P_TENC3,   // the ray's tMax when the k-th postponed quadric was met (closest-hit traversals)
     P_COUNT
 };
 // ---- float4 record planes: values that are read and written together travel in one 16-B access
@@ -422,8 +423,6 @@ DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit 
     TravState st;
     StartTraversal(s, r, tMax, st, nodeCount);
     bool found = false;
-    int pend[MAX_PENDING_SPHERES];
-    int nPend = 0;
     const float4 *__restrict__ primTri = s.primTri;
     int leafOffset = 0, leafCount = 0;
     while (NextLeaf<W>(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount)) {
@@ -431,17 +430,14 @@ DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit 
             const int prim = leafOffset + i;
             const float4 v0 = primTri[3 * prim];
             const unsigned pf = __float_as_uint(v0.w);
-            if (pf & PRIM_FLAG_SPHERE) {
-                if (nPend < MAX_PENDING_SPHERES) pend[nPend++] = prim;
-                else {  // more quadrics than postponement slots: test this one now
-                    const int sph = __float_as_int(primTri[3 * prim + 1].w);
-                    float t;
-                    if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
-                        if (ANY) return true;
-                        tMax = t;
-                        hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
-                        found = true;
-                    }
+            if (pf & PRIM_FLAG_SPHERE) {   // tested where it is met, against the tMax of that moment (the reference's order)
+                const int sph = __float_as_int(primTri[3 * prim + 1].w);
+                float t;
+                if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
+                    if (ANY) return true;
+                    tMax = t;
+                    hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+                    found = true;
                 }
                 continue;
             }
@@ -458,17 +454,6 @@ DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit 
                     found = true;
                 }
             }
-        }
-    }
-    for (int j = 0; j < nPend; ++j) {
-        const int prim = (j == 0) ? pend[0] : ((j == 1) ? pend[1] : pend[2]);
-        const int sph = __float_as_int(primTri[3 * prim + 1].w);
-        float t;
-        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
-            if (ANY) return true;
-            tMax = t;
-            hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
-            found = true;
         }
     }
     return found;
@@ -609,7 +594,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 const float4 v0 = primTri[3 * prim];
                 const unsigned pf = __float_as_uint(v0.w);
                 if (pf & PRIM_FLAG_SPHERE) {
-                    if ((nPend & 0xff) < MAX_PEND) { pool.I(I_PEND0 + (nPend & 0xff), slot) = prim; ++nPend; }
+                    if ((nPend & 0xff) < MAX_PEND) {
+                        pool.I(I_PEND0 + (nPend & 0xff), slot) = prim;
+                        if (!ANY) pool.F(P_TENC0 + (nPend & 0xff), slot) = tMax;   // (see ResolveQuadrics)
+                        ++nPend;
+                    }
                     else nPend |= PEND_OVERFLOW;
                 } else {
                     const float4 v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
@@ -664,35 +653,46 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     if (MODE == 0) { CountAdd(&st8.extendNodes, nodeCount); CountAdd(&st8.extendTris, triCount); CountAdd(&st8.extendRays, rayCount); }
 }
 
-// Quadrics recorded by k_trav, tested in encounter order against the ray's final tMax
-// (closest hit is order independent). On overflow the ray is re-traversed by the
-// reference-order routine with inline quadric tests.
+// Quadrics recorded by k_trav, tested after the triangles at full lane utilisation -- with the outcome of the reference's
+// order. Sphere::Intersect rejects a root whose error-bounded UPPER end lies beyond tMax (sphere.cpp:77-82), so when a
+// triangle and a sphere are met within that error bound of each other (a sphere resting on a quad: fuzz scene 2004), which
+// one is the hit depends on which was met first. So each postponed quadric keeps the ray's tMax of the moment it was met
+// (P_TENC*), and this replays the reference's sequence: quadric j is tested against min(that tMax, the closest quadric
+// accepted before it); a triangle hit that the traversal found AFTER the last accepted quadric survives only if it is
+// closer than that quadric. (Shadow rays: tMax never changes, the order does not matter.) On overflow the ray is
+// re-traversed by the reference-order routine with inline quadric tests.
 template <bool ANY>
 DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
                          Hit *h, bool foundTri, unsigned &nodes, unsigned &tris) {
     const int np = pool.I(I_NPEND, slot);
-    bool found = foundTri;
     if (np & PEND_OVERFLOW) {
         Hit h2;
         h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
         unsigned n2 = 0, t2 = 0;  // statistics were already counted by k_trav
-        found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, n2, t2);
+        const bool found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, n2, t2);
         if (found) *h = h2;
         return found;
     }
-    float tMax = (!ANY && foundTri) ? h->t : tMaxIn;
+    if (ANY) {
+        for (int j = 0; j < (np & 0xff); ++j) {
+            const int prim = pool.I(I_PEND0 + j, slot);
+            float t;
+            if (SphereHitT(s.spheres[__float_as_int(s.primTri[3 * prim + 1].w)], ro, rd, tMaxIn, &t)) return true;
+        }
+        return foundTri;
+    }
+    float tBest = kInfinity, tEncBest = 0.f;
+    int primBest = -1;
     for (int j = 0; j < (np & 0xff); ++j) {
         const int prim = pool.I(I_PEND0 + j, slot);
-        const int sph = __float_as_int(s.primTri[3 * prim + 1].w);
+        const float tEnc = pool.F(P_TENC0 + j, slot);
         float t;
-        if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
-            if (ANY) return true;
-            tMax = t;
-            h->prim = prim; h->t = t; h->b0 = h->b1 = h->b2 = 0;
-            found = true;
-        }
+        if (SphereHitT(s.spheres[__float_as_int(s.primTri[3 * prim + 1].w)], ro, rd, minf(tEnc, tBest), &t)) { tBest = t; primBest = prim; tEncBest = tEnc; }
     }
-    return found;
+    if (primBest < 0) return foundTri;
+    if (foundTri && tEncBest > h->t && h->t <= tBest) return true;   // the triangle was found later, and in front of the quadric
+    h->prim = primBest; h->t = tBest; h->b0 = h->b1 = h->b2 = 0;
+    return true;
 }
 
 // Slots per block of the kernels that walk the whole pool (k_generate, k_resolve_extend): SLOT_CHUNKS x 256. Every block

@@ -15,6 +15,10 @@ st.write_env_pfm(os.path.join(tmp, "env.pfm"))
 
 
 def mk(name, depth, spp):
+    if name.startswith("random:"):   # random:<seed>:<res>  (tests/scenes_text.py random_scene, as tools/fuzz_parity.py draws them)
+        _, seed, res = name.split(":")
+        st.write_texture_files(tmp); st.write_alpha_png(tmp)
+        return pt.Scene(text=st.random_scene(int(seed), res=int(res), spp=spp), base_dir=tmp, max_depth=depth)
     if name.startswith("zoo_"):
         return pt.Scene(text=st.material_zoo(res=96, spp=spp, depth=6, strategy=name[4:]), max_depth=depth)
     if name == "cornell128":
