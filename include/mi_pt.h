@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -55,11 +55,23 @@ typedef struct mi_bvh_node {
 
 /* One GeometricPrimitive (src/core/primitive.h:70-95) in BVH leaf order. */
 typedef struct mi_prim {
-    int32_t shape;      /* >=0: triangle index; <0: ~sphere index */
+    int32_t shape;      /* >=0: triangle index; <0: ~sphere index (ignored when `instance` is set) */
     int32_t material;   /* index into materials, -1 = none (interface only) */
     int32_t area_light; /* index into lights, -1 = not emissive */
-    int32_t pad;
+    int32_t instance;   /* 0: a GeometricPrimitive; k + 1: the TransformedPrimitive of mi_scene_desc.instances[k] (ABI v7) */
 } mi_prim;
+
+/* One ObjectInstance (TransformedPrimitive, src/core/primitive.cpp:78-99; api.cpp:1570-1615): the primitives of a named
+ * object, kept in the space they were declared in behind a BVH of their own (`root`: that tree's root in
+ * mi_scene_desc.nodes, whose interior / leaf offsets are absolute like the world tree's), reached by carrying the ray into
+ * that space with WorldToInstance (Transform::operator()(Ray), transform.h:262-277: origin error bound, dt shift of the
+ * origin and of tMax) and carrying the SurfaceInteraction back with InstanceToWorld (transform.cpp:262-297). Matrices row
+ * major, m[r*4+c]; w2i is the stored inverse of i2w (Transform::mInv), not a recomputation. Objects hold no area lights. */
+typedef struct mi_instance {
+    float i2w[16], w2i[16];
+    uint32_t root;
+    uint32_t pad[3];
+} mi_instance;
 
 /* Per TriangleMesh flags (src/shapes/triangle.cpp:54-92). */
 #define MI_MESH_HAS_N 1u
@@ -322,6 +334,7 @@ typedef struct mi_scene_desc {
     float rgb_illum[7][MI_NSPEC]; /* rgbIllum2Spect{White,Cyan,Magenta,Yellow,Red,Green,Blue} (spectrum.h:322-398) */
     uint32_t n_textures; const mi_texture *textures;   /* ABI v5 */
     uint32_t n_mipmaps;  const mi_mipmap *mipmaps;
+    uint32_t n_instances; const mi_instance *instances; /* ABI v7 */
 } mi_scene_desc;
 
 /* Counters with the reference's STAT names (src/core/integrator.cpp:48,

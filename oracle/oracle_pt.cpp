@@ -232,9 +232,37 @@ struct Scene {
         return (tMin < ray.tMax) && (tMax > 0);
     }
 
-    // GeometricPrimitive::Intersect, primitive.cpp:119-135
+    // Transform::operator()(const SurfaceInteraction&), transform.cpp:262-297, with InstanceToWorld (w2i = its stored inverse)
+    static void ToWorld(const mi_instance &in, SurfaceInteraction *si) {
+        const float *m = in.i2w, *mInv = in.w2i;
+        V3 pErr;
+        si->p = XfPointErr2(m, si->p, si->pError, &pErr);
+        si->pError = pErr;
+        si->n = Normalize(XfNormal(mInv, si->n));
+        si->wo = Normalize(XfVector(m, si->wo));
+        si->dpdu = XfVector(m, si->dpdu);
+        si->dpdv = XfVector(m, si->dpdv);
+        si->dndu = XfNormal(mInv, si->dndu);
+        si->dndv = XfNormal(mInv, si->dndv);
+        si->shading.n = Normalize(XfNormal(mInv, si->shading.n));
+        si->shading.dpdu = XfVector(m, si->shading.dpdu);
+        si->shading.dpdv = XfVector(m, si->shading.dpdv);
+        si->shading.dndu = XfNormal(mInv, si->shading.dndu);
+        si->shading.dndv = XfNormal(mInv, si->shading.dndv);
+        si->shading.n = Faceforward(si->shading.n, si->n);
+    }
+
+    // GeometricPrimitive::Intersect, primitive.cpp:119-135; TransformedPrimitive::Intersect, primitive.cpp:78-92
     bool PrimIntersect(int primIdx, const Ray &ray, SurfaceInteraction *isect, Counters &c) const {
         const mi_prim &p = d.prims[primIdx];
+        if (p.instance > 0) {
+            const mi_instance &in = d.instances[p.instance - 1];
+            Ray r2 = XfRay(in.w2i, ray);   // Inverse(InstanceToWorld)(r)
+            if (!BVHIntersect((int)in.root, r2, isect, c)) return false;
+            ray.tMax = r2.tMax;
+            ToWorld(in, isect);
+            return true;
+        }
         Float tHit;
         if (p.shape >= 0) {
             ++c.triTests;
@@ -248,6 +276,10 @@ struct Scene {
     }
     bool PrimIntersectP(int primIdx, const Ray &ray, Counters &c) const {
         const mi_prim &p = d.prims[primIdx];
+        if (p.instance > 0) {   // TransformedPrimitive::IntersectP, primitive.cpp:94-99
+            const mi_instance &in = d.instances[p.instance - 1];
+            return BVHIntersectP((int)in.root, XfRay(in.w2i, ray), c);
+        }
         if (p.shape >= 0) {
             ++c.triTests;
             return TriIntersectP(d, p.shape, ray);
@@ -255,13 +287,22 @@ struct Scene {
         return SphereIntersectP(d.spheres[~p.shape], ray);
     }
 
-    bool Intersect(const Ray &ray, SurfaceInteraction *isect, Counters &c) const {  // scene.cpp:45-49 + bvh.cpp:662-700
+    bool Intersect(const Ray &ray, SurfaceInteraction *isect, Counters &c) const {  // scene.cpp:45-49
         ++c.regularRays;
         if (d.n_nodes == 0) return false;
+        return BVHIntersect(0, ray, isect, c);
+    }
+    bool IntersectP(const Ray &ray, Counters &c) const {  // scene.cpp:51-55
+        ++c.shadowRays;
+        if (d.n_nodes == 0) return false;
+        return BVHIntersectP(0, ray, c);
+    }
+
+    bool BVHIntersect(int root, const Ray &ray, SurfaceInteraction *isect, Counters &c) const {  // bvh.cpp:662-700
         bool hit = false;
         V3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
         int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
-        int toVisitOffset = 0, currentNodeIndex = 0;
+        int toVisitOffset = 0, currentNodeIndex = root;
         int nodesToVisit[64];
         while (true) {
             const mi_bvh_node *node = &d.nodes[currentNodeIndex];
@@ -288,13 +329,11 @@ struct Scene {
         }
         return hit;
     }
-    bool IntersectP(const Ray &ray, Counters &c) const {  // scene.cpp:51-55 + bvh.cpp:702-738
-        ++c.shadowRays;
-        if (d.n_nodes == 0) return false;
+    bool BVHIntersectP(int root, const Ray &ray, Counters &c) const {  // bvh.cpp:702-738
         V3 invDir(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
         int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
         int nodesToVisit[64];
-        int toVisitOffset = 0, currentNodeIndex = 0;
+        int toVisitOffset = 0, currentNodeIndex = root;
         while (true) {
             const mi_bvh_node *node = &d.nodes[currentNodeIndex];
             ++c.nodesVisited;

@@ -30,7 +30,11 @@ class BvhNode(C.Structure):
 
 
 class Prim(C.Structure):
-    _fields_ = [("shape", C.c_int32), ("material", C.c_int32), ("area_light", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("shape", C.c_int32), ("material", C.c_int32), ("area_light", C.c_int32), ("instance", C.c_int32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("i2w", C.c_float * 16), ("w2i", C.c_float * 16), ("root", C.c_uint32), ("pad", C.c_uint32 * 3)]
 
 
 class Mesh(C.Structure):
@@ -133,7 +137,8 @@ class SceneDesc(C.Structure):
                 ("integrator", Integrator), ("cie_y", C.c_float * NSPEC),
                 ("n_envmaps", C.c_uint32), ("envmaps", C.POINTER(EnvMap)), ("rgb_illum", (C.c_float * NSPEC) * 7),
                 ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture)),
-                ("n_mipmaps", C.c_uint32), ("mipmaps", C.POINTER(MipMap))]
+                ("n_mipmaps", C.c_uint32), ("mipmaps", C.POINTER(MipMap)),
+                ("n_instances", C.c_uint32), ("instances", C.POINTER(Instance))]
 
 
 class Counters(C.Structure):

@@ -22,6 +22,7 @@ namespace dpt {
 
 #define PRIM_FLAG_SPHERE 1u
 #define PRIM_FLAG_DEGENERATE 2u
+#define PRIM_FLAG_INSTANCE 64u   // a TransformedPrimitive: primTri[3 * prim + 1].w holds the instance number (mi_prim.instance - 1)
 #define PRIM_FLAG_ALPHA 32u   // the triangle's mesh has an "alpha" / "shadowalpha" mask (mi_mesh.alpha_tex)
 #define PRIM_CLASS_SHIFT 2      /* bits 2-4: shading class of the primitive's material (7 = no BSDF) */
 
@@ -30,6 +31,12 @@ struct DScene {
     const float4 *wnodes;  // wide nodes (see pt_kernels.hip): bvhWidth 2 -> 64 B per BVH2 interior node (both children's boxes);
                            // bvhWidth 4 -> 128 B per two-level subtree (up to four grandchild boxes + the visit orders)
     int bvhWidth;
+    // ObjectInstance as TransformedPrimitive (mi_instance): the instances, the wide record each one's tree starts at, and
+    // that tree's root box (two float4 per instance: min, max)
+    const mi_instance *instances;
+    const int32_t *instWideRoot;
+    const float4 *instRootBounds;
+    uint32_t nInstances;
     const float4 *primTri;
     const mi_prim *prims;
     const int32_t *triIndices;

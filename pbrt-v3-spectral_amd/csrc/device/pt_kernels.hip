@@ -96,6 +96,7 @@ DEV void Set4(float4 &v, int k, float x) { if (k == 0) v.x = x; else if (k == 1)
 enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT,
              I_NPEND, I_PEND0, I_PEND1, I_PEND2, I_PEND3,  // quadrics postponed by the traversal kernel
              I_BAND,                                       // spectralpath: band (path number) of the camera sample
+             I_HITINST,                                    // instance the hit primitive was reached through, -1 = none (scenes with instances)
              I_COUNT };
 constexpr int MAX_PEND = 4;
 constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
@@ -212,6 +213,7 @@ DEV unsigned BlockReserve(unsigned *counter, bool pred, unsigned *scratch) {
 struct Hit {
     int prim;
     float t, b0, b1, b2;
+    int inst = -1;   // the object instance the hit primitive was reached through (mi_instance index), -1: a world primitive
 };
 
 // BVHAccel::Intersect / IntersectP (bvh.cpp:662-738) with Bounds3::IntersectP
@@ -385,12 +387,12 @@ DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, f
 // traversal is finished (returns false, st.cur == -1).
 template <int W>
 DEV bool NextLeaf(const float4 *__restrict__ wnodes, const RayCtx &r, float tMax, TravState &st, TravSpill &spill,
-                  int lane, int *leafOffset, int *leafCount, unsigned &nodeCount) {
+                  int lane, int *leafOffset, int *leafCount, unsigned &nodeCount, int floor = 0) {
     while (st.cur != -1) {
         int tkChild = 0, tkMeta = 0;
         bool got = false;
         if (st.cur >= 0) got = OpenNode<W>(wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
-        while (!got && st.sp > 0) {  // a popped node is entered only if still in front of tMax
+        while (!got && st.sp > floor) {  // a popped node is entered only if still in front of tMax
             float t;
             StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
             got = t < tMax;
@@ -413,30 +415,52 @@ DEV void StartTraversal(const DScene &s, const RayCtx &r, float tMax, TravState 
 constexpr int MAX_PENDING_SPHERES = 3;
 
 // Plain per-ray traversal with inline quadric tests (mi_pt_trace and the overflow path
-// of ResolveQuadrics).
-template <bool ANY, int W>
-DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
+// of ResolveQuadrics). TOP: the world's tree, whose leaves may hold object instances -- a TransformedPrimitive
+// (primitive.cpp:78-99) takes the ray to the instance's space and traverses the object's tree with it, above the entries
+// the world's traversal has on the stack (`floor`); a hit inside hands its tMax back to the world ray.
+template <bool ANY, int W, bool TOP>
+DEV bool TraverseTree(const DScene &s, int rootRecord, bool rootHit, const V3 &ro, const V3 &rd, float &tMax, int floor, int inst,
+                      Hit *hit, unsigned &nodeCount, unsigned &triCount) {
     const int lane = threadIdx.x;
     RayCtx r;
     InitRayCtx(r, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     TravSpill spill;
     TravState st;
-    StartTraversal(s, r, tMax, st, nodeCount);
+    st.sp = floor;
+    st.cur = rootHit ? rootRecord : -1;
     bool found = false;
     const float4 *__restrict__ primTri = s.primTri;
     int leafOffset = 0, leafCount = 0;
-    while (NextLeaf<W>(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount)) {
+    while (NextLeaf<W>(s.wnodes, r, tMax, st, spill, lane, &leafOffset, &leafCount, nodeCount, floor)) {
         for (int i = 0; i < leafCount; ++i) {
             const int prim = leafOffset + i;
             const float4 v0 = primTri[3 * prim];
             const unsigned pf = __float_as_uint(v0.w);
+            if constexpr (TOP && W == 4) {
+                if (pf & PRIM_FLAG_INSTANCE) {
+                    const int k = __float_as_int(primTri[3 * prim + 1].w);
+                    const Ray ir = XfRay(s.instances[k].w2i, Ray(ro, rd, tMax));   // Inverse(InstanceToWorld)(r)
+                    RayCtx rc;
+                    InitRayCtx(rc, ir.o.x, ir.o.y, ir.o.z, ir.d.x, ir.d.y, ir.d.z);
+                    const float4 bMin = s.instRootBounds[2 * k], bMax = s.instRootBounds[2 * k + 1];
+                    float tBox, tIn = ir.tMax;
+                    ++nodeCount;
+                    const bool boxHit = BoxTest(rc, bMin.x, bMin.y, bMin.z, bMax.x, bMax.y, bMax.z, tIn, &tBox);
+                    if (TraverseTree<ANY, W, false>(s, s.instWideRoot[k], boxHit, ir.o, ir.d, tIn, st.sp, k, hit, nodeCount, triCount)) {
+                        if (ANY) return true;
+                        tMax = tIn;   // r.tMax = ray.tMax
+                        found = true;
+                    }
+                    continue;
+                }
+            }
             if (pf & PRIM_FLAG_SPHERE) {   // tested where it is met, against the tMax of that moment (the reference's order)
                 const int sph = __float_as_int(primTri[3 * prim + 1].w);
                 float t;
                 if (SphereHitT(s.spheres[sph], ro, rd, tMax, &t)) {
                     if (ANY) return true;
                     tMax = t;
-                    hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0;
+                    hit->prim = prim; hit->t = t; hit->b0 = hit->b1 = hit->b2 = 0; hit->inst = inst;
                     found = true;
                 }
                 continue;
@@ -450,13 +474,21 @@ DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit 
                 if (ANY) return true;
                 if (!(pf & PRIM_FLAG_DEGENERATE)) {
                     tMax = th.t;
-                    hit->prim = prim; hit->t = th.t; hit->b0 = th.b0; hit->b1 = th.b1; hit->b2 = th.b2;
+                    hit->prim = prim; hit->t = th.t; hit->b0 = th.b0; hit->b1 = th.b1; hit->b2 = th.b2; hit->inst = inst;
                     found = true;
                 }
             }
         }
     }
     return found;
+}
+template <bool ANY, int W>
+DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
+    RayCtx r;
+    InitRayCtx(r, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+    TravState st;
+    StartTraversal(s, r, tMax, st, nodeCount);
+    return TraverseTree<ANY, W, true>(s, 0, st.cur >= 0, ro, rd, tMax, 0, -1, hit, nodeCount, triCount);
 }
 
 template <bool ANY>
@@ -498,7 +530,12 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 #define MIPT_TRAV_WAVES_PER_EU 4
 #endif
 // ALPHA: the scene has meshes with alpha masks (the mask test is compiled into this instance only)
-template <int MODE, bool ALPHA, int W>
+// INST: the scene has object instances (TransformedPrimitive, primitive.cpp:78-99). A lane that meets an instance in a world
+// leaf pushes ONE return entry (the rest of that leaf and the world ray's tMax; meta < 0 marks it), swaps its ray for
+// Inverse(InstanceToWorld)(ray) and walks the object's tree above that entry; popping the entry reloads the world ray from
+// the pool and resumes the leaf -- with the instance ray's tMax if something was hit inside (`r.tMax = ray.tMax`). The
+// sequence of box tests, primitive tests and tMax updates per ray is the reference's recursion unrolled.
+template <int MODE, bool ALPHA, int W, bool INST = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
     const int lane = threadIdx.x;
@@ -520,6 +557,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     int nPend = 0, hitPrim = -1;
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
     int leafOff = 0, leafCnt = 0;
+    int curInst = -1, hitInst = -1;   // INST: the instance the lane is inside, and the one its closest hit so far lies in
+    bool hitInCur = false;            // INST: something was hit since the lane entered curInst
     TriRay triRay;
     triRay.kz = 2; triRay.Sx = triRay.Sy = 0; triRay.Sz = 1;
     bool exhausted = false;
@@ -555,11 +594,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             nPend = 0; hitPrim = -1;
                             hitT = hitB0 = hitB1 = hitB2 = 0;
                             leafCnt = 0;
+                            curInst = hitInst = -1; hitInCur = false;
                             ++rayCount;
                             if (st.cur >= 0) has = true;
                             else {  // the ray misses the world bound: nothing to traverse
                                 pool.I(I_HITPRIM, slot) = -1;
                                 pool.I(I_NPEND, slot) = 0;
+                                if (INST && MODE == 0) pool.I(I_HITINST, slot) = -1;
                                 if (!ANY) pool.R(R_HIT, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
                             }
                         }
@@ -593,6 +634,31 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 ++leafOff; --leafCnt;
                 const float4 v0 = primTri[3 * prim];
                 const unsigned pf = __float_as_uint(v0.w);
+                bool entered = false;
+                if (INST && (pf & PRIM_FLAG_INSTANCE)) {
+                    // TransformedPrimitive::Intersect[P]: the ray in the instance's space, then the object's BVH from its root
+                    const int k = __float_as_int(primTri[3 * prim + 1].w);
+                    StackPush(spill, lane, st.sp, leafOff, -(leafCnt + 1), tMax);
+                    const Ray ir = XfRay(s.instances[k].w2i, Ray(V3(r.ox, r.oy, r.oz), V3(r.dx, r.dy, r.dz), tMax));
+                    InitRayCtx(r, ir.o.x, ir.o.y, ir.o.z, ir.d.x, ir.d.y, ir.d.z);
+                    triRay = MakeTriRay(ir.d);
+                    tMax = ir.tMax;
+                    curInst = k; hitInCur = false;
+                    leafCnt = 0;
+                    const float4 bMin = s.instRootBounds[2 * k], bMax = s.instRootBounds[2 * k + 1];
+                    float tBox;
+                    ++nodeCount;
+                    got = BoxTest(r, bMin.x, bMin.y, bMin.z, bMax.x, bMax.y, bMax.z, tMax, &tBox);
+                    tkChild = s.instWideRoot[k]; tkMeta = 0;
+                    entered = true;
+                } else if (INST && curInst >= 0 && (pf & PRIM_FLAG_SPHERE)) {
+                    // a quadric of an instanced object: tested where it is met, with the instance's ray
+                    float t;
+                    if (SphereHitT(s.spheres[__float_as_int(primTri[3 * prim + 1].w)], V3(r.ox, r.oy, r.oz), V3(r.dx, r.dy, r.dz), tMax, &t)) {
+                        if (ANY) { hitPrim = prim; finished = true; }
+                        else { tMax = t; hitPrim = prim; hitT = t; hitB0 = hitB1 = hitB2 = 0; hitInst = curInst; hitInCur = true; }
+                    }
+                } else
                 if (pf & PRIM_FLAG_SPHERE) {
                     if ((nPend & 0xff) < MAX_PEND) {
                         pool.I(I_PEND0 + (nPend & 0xff), slot) = prim;
@@ -617,15 +683,28 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         else if (!(pf & PRIM_FLAG_DEGENERATE)) {
                             tMax = th.t;
                             hitPrim = prim; hitT = th.t; hitB0 = th.b0; hitB1 = th.b1; hitB2 = th.b2;
+                            if (INST) { hitInst = curInst; hitInCur = true; }
                         }
                     }
                 }
-                needPop = !finished && leafCnt == 0;
+                needPop = entered ? !got : (!finished && leafCnt == 0);
             }
             if (needPop) {  // a popped node is entered only if still in front of tMax
                 while (!got && st.sp > 0) {
                     float t;
                     StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
+                    if (INST && tkMeta < 0) {   // back from the instance: the world ray again, and the rest of the leaf
+                        const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
+                        const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
+                        if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
+                        else InitRayCtx(r, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+                        triRay = MakeTriRay(V3(r.dx, r.dy, r.dz));
+                        if (!hitInCur) tMax = t;   // (a hit inside: r.tMax = ray.tMax)
+                        curInst = -1;
+                        tkMeta = -tkMeta - 1;      // primitives left in the world leaf
+                        got = tkMeta > 0;
+                        continue;
+                    }
                     got = t < tMax;
                 }
                 finished = !got;
@@ -638,6 +717,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 pool.I(I_HITPRIM, slot) = hitPrim;
                 pool.I(I_NPEND, slot) = nPend;
                 if (!ANY) pool.R(R_HIT, slot) = make_float4(hitT, hitB0, hitB1, hitB2);
+                if (INST && MODE == 0) pool.I(I_HITINST, slot) = hitInst;
                 has = false;
                 leafCnt = 0;
             }
@@ -691,7 +771,7 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
     }
     if (primBest < 0) return foundTri;
     if (foundTri && tEncBest > h->t && h->t <= tBest) return true;   // the triangle was found later, and in front of the quadric
-    h->prim = primBest; h->t = tBest; h->b0 = h->b1 = h->b2 = 0;
+    h->prim = primBest; h->t = tBest; h->b0 = h->b1 = h->b2 = 0; h->inst = -1;
     return true;
 }
 
@@ -723,10 +803,12 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
                 V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
                 Hit h;
                 h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
+                if (s.nInstances) h.inst = pool.I(I_HITINST, slot);
                 const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
                 prim = found ? h.prim : -1;
                 pool.I(I_HITPRIM, slot) = prim;
                 pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
+                if (s.nInstances) pool.I(I_HITINST, slot) = h.inst;
             }
             cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
         }
@@ -1213,6 +1295,28 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     CountAdd(&Stats(ctr).badSamples, bad);
 }
 
+// Transform::operator()(const SurfaceInteraction&), transform.cpp:262-297, with an instance's InstanceToWorld: the fields the
+// path reads (SurfaceInteraction) and the ones textures and bump mapping read besides (TriShading).
+DEV void InteractionToWorld(const mi_instance &in, SurfaceInteraction *si) {
+    const float *m = in.i2w, *mInv = in.w2i;
+    V3 pErr;
+    si->p = XfPointErr2(m, si->p, si->pError, &pErr);
+    si->pError = pErr;
+    si->n = Normalize(XfNormal(mInv, si->n));
+    si->wo = Normalize(XfVector(m, si->wo));
+    si->dpdu = XfVector(m, si->dpdu);
+    si->shN = Normalize(XfNormal(mInv, si->shN));
+    si->shDpdu = XfVector(m, si->shDpdu);
+    si->shN = Faceforward(si->shN, si->n);
+}
+DEV void ShadingToWorld(const mi_instance &in, TriShading *ts) {
+    const float *m = in.i2w, *mInv = in.w2i;
+    ts->dpdv = XfVector(m, ts->dpdv);
+    ts->shDpdv = XfVector(m, ts->shDpdv);
+    ts->dndu = XfNormal(mInv, ts->dndu);
+    ts->dndv = XfNormal(mInv, ts->dndv);
+}
+
 // Build the SurfaceInteraction of a recorded hit.
 DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si) {
     const mi_prim p = s.prims[prim];
@@ -1310,7 +1414,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         V3 ro(ray0.x, ray0.y, ray0.z), rd(ray1.x, ray1.y, ray1.z);
         SurfaceInteraction isect;
         bool finished = false, passThrough = false;
-        if (needIsect) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, ro, rd, hr.y, hr.z, hr.w, &isect); }
+        // a hit inside an object instance: the interaction is built with the ray in the instance's space and taken to the
+        // world by InstanceToWorld (TransformedPrimitive::Intersect, primitive.cpp:78-92)
+        int inst = -1;
+        V3 roS = ro, rdS = rd;   // the ray in the space the hit shape was intersected in
+        if constexpr ((TM & TM_INSTANCES) != 0) {
+            if (needIsect) inst = pool.I(I_HITINST, slot);
+            if (inst >= 0) { const Ray ir = XfRay(s.instances[inst].w2i, Ray(ro, rd, kInfinity)); roS = ir.o; rdS = ir.d; }
+        }
+        if (needIsect) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, roS, rdS, hr.y, hr.z, hr.w, &isect); }
+        SurfaceInteraction isectObj;
+        if constexpr ((TM & TM_INSTANCES) != 0) {
+            if (inst >= 0) { isectObj = isect; InteractionToWorld(s.instances[inst], &isect); }
+        }
         // emitted light at the vertex, path.cpp:91-101
         if ((bounces == 0 || (flags & F_SPECULAR)) && found) {
             const int li = s.prims[prim].area_light;
@@ -1381,10 +1497,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const int shape = s.prims[prim].shape;
                     if (shape >= 0) {
                         const float4 hr = pool.R(R_HIT, slot);
-                        TriTexCoords(s, shape, hr.y, hr.z, hr.w, isect, &u, &v, &tsh);
+                        TriTexCoords(s, shape, hr.y, hr.z, hr.w, inst >= 0 ? isectObj : isect, &u, &v, &tsh);
                         haveUV = true;
                     } else
-                        haveUV = SphereTexCoords(s.spheres[~shape], ro, rd, &u, &v, &tsh);
+                        haveUV = SphereTexCoords(s.spheres[~shape], roS, rdS, &u, &v, &tsh);
+                    if constexpr ((TM & TM_INSTANCES) != 0) {
+                        if (inst >= 0) ShadingToWorld(s.instances[inst], &tsh);
+                    }
                 }
                 if (haveUV) {
                     TexDifferentials td;
@@ -1769,6 +1888,7 @@ struct mi_pt {
     uint32_t nTextures = 0;
     std::vector<int> textureTypes;
     bool hasAlphaMasks = false;      // picks the traversal kernels compiled with the alpha-mask test
+    bool hasInstances = false;       // ... and with the TransformedPrimitive code (those carry the alpha-mask test too)
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
@@ -1859,6 +1979,11 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     }
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const mi_prim &p = d->prims[i];
+        if (p.instance != 0) {
+            if (p.instance < 0 || (uint32_t)p.instance > d->n_instances || !d->instances) { g_err = "primitive instance index out of range"; return MI_ERR_INVALID; }
+            if (d->instances[p.instance - 1].root >= d->n_nodes) { g_err = "instance BVH root out of range"; return MI_ERR_INVALID; }
+            continue;
+        }
         if (p.shape >= 0 ? (uint32_t)p.shape >= d->n_tris : (uint32_t)(~p.shape) >= d->n_spheres) { g_err = "primitive shape index out of range"; return MI_ERR_INVALID; }
         if (p.material >= (int)d->n_materials || p.area_light >= (int)d->n_lights) { g_err = "primitive material/light index out of range"; return MI_ERR_INVALID; }
     }
@@ -1913,9 +2038,18 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         const mi_bvh_node *nodes = d->nodes;
         std::vector<int32_t> widx(nN, -1);
         std::vector<uint32_t> order;   // BVH2 roots of the records, in record order
-        {
+        // the trees: the world's (root 0) and one per instanced object (mi_instance.root)
+        std::vector<uint32_t> treeRoots(1, 0u);
+        for (uint32_t k = 0; k < d->n_instances; ++k)
+            if (std::find(treeRoots.begin(), treeRoots.end(), d->instances[k].root) == treeRoots.end()) treeRoots.push_back(d->instances[k].root);
+        for (const uint32_t treeRoot : treeRoots) {
+            if (nodes[treeRoot].n_prims > 0) {   // a single-leaf tree gets a record of its own: the leaf in slot 0
+                widx[treeRoot] = (int32_t)order.size();
+                order.push_back(treeRoot);
+                continue;
+            }
             std::vector<uint32_t> stack;
-            if (nodes[0].n_prims == 0) stack.push_back(0);
+            stack.push_back(treeRoot);
             while (!stack.empty()) {
                 const uint32_t i = stack.back();
                 stack.pop_back();
@@ -1965,16 +2099,19 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             memcpy(&rec[7].x, &c01, 4); memcpy(&rec[7].y, &c23, 4);
             memcpy(&rec[7].z, &ord[0], 4); memcpy(&rec[7].w, &ord[1], 4);
         };
-        if (nodes[0].n_prims > 0) {   // single-leaf tree: the root itself in slot 0
-            int link[4] = {nodes[0].offset, 0, 0, 0};
-            unsigned cnt[4] = {nodes[0].n_prims, 0xffffu, 0xffffu, 0xffffu};
-            setBox(&w[0], 0, nodes[0]);
-            const int gN[2] = {1, 0}, gA[2] = {0, 0};
-            finish(&w[0], link, cnt, 0, gN, gA);
-        } else {
+        {
             for (size_t r = order.size(); r-- > 0;) {   // records in reverse: a child record's stack need is known before its parent's
                 const uint32_t i = order[r];
                 float4 *rec = &w[r * 8];
+                if (nodes[i].n_prims > 0) {   // single-leaf tree: the root itself in slot 0
+                    int link1[4] = {nodes[i].offset, 0, 0, 0};
+                    unsigned cnt1[4] = {nodes[i].n_prims, 0xffffu, 0xffffu, 0xffffu};
+                    setBox(rec, 0, nodes[i]);
+                    const int gN1[2] = {1, 0}, gA1[2] = {0, 0};
+                    finish(rec, link1, cnt1, 0, gN1, gA1);
+                    need[r] = 0;
+                    continue;
+                }
                 int link[4] = {0, 0, 0, 0};
                 unsigned cnt[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
                 int gN[2] = {0, 0}, gA[2] = {0, 0}, below = 0, present = 0;
@@ -1997,14 +2134,31 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 finish(rec, link, cnt, nodes[i].axis, gN, gA);
             }
         }
-        if (need[0] > STACK_LDS + STACK_SPILL) {
+        int needAll = need[0];   // the world tree's need, plus -- inside an instance -- two return entries and the object tree's
+        for (uint32_t k = 0; k < d->n_instances; ++k) needAll = std::max(needAll, need[0] + 2 + need[widx[d->instances[k].root]]);
+        if (needAll > STACK_LDS + STACK_SPILL) {
             // (pbrt's own 64-entry stack bounds the BVH2 depth; a wide record can hold up to three entries per two levels)
             s.bvhWidth = 2;
         } else {
             const float4 *dev;
             UP(w.data(), w.size(), dev);
             s.wnodes = dev;
+            std::vector<int32_t> instRoot(std::max<uint32_t>(d->n_instances, 1), 0);
+            std::vector<float4> instBounds((size_t)std::max<uint32_t>(d->n_instances, 1) * 2, float4{0, 0, 0, 0});
+            for (uint32_t k = 0; k < d->n_instances; ++k) {
+                const mi_bvh_node &rn = nodes[d->instances[k].root];
+                instRoot[k] = widx[d->instances[k].root];
+                instBounds[2 * k] = float4{rn.bmin[0], rn.bmin[1], rn.bmin[2], 0};
+                instBounds[2 * k + 1] = float4{rn.bmax[0], rn.bmax[1], rn.bmax[2], 0};
+            }
+            UP(instRoot.data(), instRoot.size(), s.instWideRoot);
+            UP(instBounds.data(), instBounds.size(), s.instRootBounds);
         }
+    }
+    if (s.bvhWidth == 2 && d->n_instances > 0) {
+        g_err = "object instances are traversed over the two-level BVH records (MIPT_BVH_WIDTH=4), which this scene's tree depth does not allow";
+        mi_pt_destroy(pt);
+        return MI_ERR_UNSUPPORTED;
     }
     if (s.bvhWidth == 2) {   // wide-2 nodes: one 64-B record per interior node with both children's boxes
         const uint32_t nN = d->n_nodes;
@@ -2105,7 +2259,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             float4 a{0, 0, 0, 0}, b{0, 0, 0, 0}, c{0, 0, 0, 0};
             unsigned flags = 0;
             int shapeIdx = 0;
-            if (p.shape >= 0) {
+            if (p.instance == 0 && p.shape >= 0) {
                 const int32_t *v = &d->tri_indices[3 * p.shape];
                 const float *P = d->P;
                 a = float4{P[3 * v[0]], P[3 * v[0] + 1], P[3 * v[0] + 2], 0};
@@ -2147,9 +2301,14 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                     if (cx * cx + cy * cy + cz * cz == 0) flags |= PRIM_FLAG_DEGENERATE;
                 }
                 if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) { flags |= PRIM_FLAG_ALPHA; pt->hasAlphaMasks = true; }
-            } else {
+            } else if (p.instance == 0) {
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
+            }
+            if (p.instance != 0) {   // a TransformedPrimitive: no shape of its own
+                a = b = c = float4{0, 0, 0, 0};
+                flags = PRIM_FLAG_INSTANCE;
+                shapeIdx = p.instance - 1;
             }
             flags |= (unsigned)(p.material >= 0 ? matClass[p.material] : MISS_CLASS) << PRIM_CLASS_SHIFT;
             memcpy(&a.w, &flags, 4);
@@ -2161,6 +2320,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         s.primTri = dev;
     }
     UP(d->prims, d->n_prims, s.prims);
+    s.nInstances = d->n_instances;
+    s.instances = nullptr;
+    if (d->n_instances) UP(d->instances, d->n_instances, s.instances);
+    pt->hasInstances = d->n_instances > 0;
     UP(d->tri_indices, (size_t)d->n_tris * 3, s.triIndices);
     UP(d->tri_mesh, d->n_tris, s.triMesh);
     UP(d->P, (size_t)d->n_verts * 3, s.P);
@@ -2340,7 +2503,11 @@ static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid
     hipStream_t st = sub.stream;
 #define TRAV_LAUNCH(MODE_, ALPHA_, W_) hipLaunchKernelGGL((k_trav<MODE_, ALPHA_, W_>), travGrid, block, 0, st, s, sub.pool, sub.ctr)
 #define TRAV_LAUNCH_W(MODE_, ALPHA_) do { if (s.bvhWidth == 4) TRAV_LAUNCH(MODE_, ALPHA_, 4); else TRAV_LAUNCH(MODE_, ALPHA_, 2); } while (0)
-    if (pt->hasAlphaMasks) {
+    if (pt->hasInstances) {   // (mi_pt_create: instanced scenes always have the two-level records)
+        if (mode == 0) hipLaunchKernelGGL((k_trav<0, true, 4, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else if (mode == 1) hipLaunchKernelGGL((k_trav<1, true, 4, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_trav<2, true, 4, true>), travGrid, block, 0, st, s, sub.pool, sub.ctr);
+    } else if (pt->hasAlphaMasks) {
         if (mode == 0) TRAV_LAUNCH_W(0, true);
         else if (mode == 1) TRAV_LAUNCH_W(1, true);
         else TRAV_LAUNCH_W(2, true);
@@ -2358,7 +2525,14 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
     const dim3 shadeGrid(grid.x + MAX_CLASSES);
-    constexpr unsigned TM_GENERIC = TM_ALL & ~TM_TEXTURED;
+    constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_TEXTURED;
+    if (pt->hasInstances) {   // scenes with object instances: the two fully general instances of the kernel, by lobe count
+        const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
+        const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge;
+        if (two) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, two);
+        if (more) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, more);
+        return;
+    }
     if (pt->hasInfiniteLight) {
         if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
         if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
@@ -2368,12 +2542,12 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     }
     if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
     if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
-    if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
+    if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
     if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
     if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
     if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
-    if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
-    if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
+    if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
+    if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
 }
 
 // One sub-renderer = one path pool with its queues and counters on its own HIP stream.

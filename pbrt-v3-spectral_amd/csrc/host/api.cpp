@@ -124,6 +124,7 @@ struct PendingPrim {
     int material;
     int light;
     Bounds3 bounds;
+    int instance = 0;   // k + 1: the TransformedPrimitive of instance k
 };
 
 struct Api {
@@ -143,13 +144,20 @@ struct Api {
     ParamSet filterParams, filmParams, samplerParams, accelParams, integratorParams, cameraParams;
     Transform cameraToWorld;
     std::vector<PendingPrim> pending;
-    // Object instancing (api.cpp:1544-1615). The reference keeps an instance's primitives in their own BVH behind a
-    // TransformedPrimitive and transforms each ray into it; this build has one BVH over world-space geometry,
-    // so an ObjectInstance re-creates the recorded shapes under InstanceToWorld * (the CTM they were declared with):
-    // the same surfaces, hit points that differ from the reference's in rounding only.
+    // Object instancing (api.cpp:1544-1615). As in the reference, an object's primitives are created once, in the space they
+    // were declared in, and every ObjectInstance is a TransformedPrimitive in the world's BVH: the world-space box of the
+    // object and InstanceToWorld; the object's primitives get a BVH of their own at WorldEnd. (MIPT_INSTANCES=expand
+    // re-creates the recorded shapes under InstanceToWorld * (their CTM) instead -- round 1's world-space copies: the same
+    // surfaces, hit points that differ from the reference's in rounding.)
     struct RecordedShape { std::string name; ParamSet params; Transform ctm; GraphicsState gs; };
     std::map<std::string, std::vector<RecordedShape>> instances;
     std::vector<RecordedShape> *currentInstance = nullptr;
+    struct ObjectDef { std::vector<PendingPrim> prims; Bounds3 bounds; bool created = false; int root = -1; };
+    std::map<std::string, ObjectDef> objectDefs;
+    std::vector<std::string> objectOrder;                 // objects in the order they were first instanced
+    struct InstanceRec { std::string object; Transform i2w; };
+    std::vector<InstanceRec> instanceRecs;
+    bool expandInstances = false;
     std::map<std::string, std::shared_ptr<PLYMeshData>> plyCache;   // an instanced plymesh is read once
     std::map<std::string, Spectrum> cachedSpectra;                  // paramset.cpp:48, SPD files by name
     bool worldEnded = false;
@@ -160,6 +168,7 @@ struct Api {
     void Err(const std::string &m) { scene->errors.push_back(m); }
 
     Api(HostScene *s, const LoadOverrides &o) : scene(s), ov(o) {
+        if (const char *e = getenv("MIPT_INSTANCES")) expandInstances = std::string(e) == "expand";
         // default material: matte with default params (GraphicsState ctor, api.cpp:214-222)
         ParamSet empty;
         gs.currentMaterial = std::make_shared<MaterialInstance>();
@@ -468,13 +477,42 @@ struct Api {
         if (it == instances.end()) { Err("Unable to find instance named \"" + name + "\""); return; }
         const Transform instanceToWorld = ctm;
         const GraphicsState saved = gs;
-        for (const RecordedShape &r : it->second) {
-            ctm = instanceToWorld * r.ctm;
-            gs = r.gs;
-            Shape(r.name, r.params);
+        if (expandInstances) {
+            for (const RecordedShape &r : it->second) {
+                ctm = instanceToWorld * r.ctm;
+                gs = r.gs;
+                Shape(r.name, r.params);
+            }
+            ctm = instanceToWorld;
+            gs = saved;
+            return;
         }
-        ctm = instanceToWorld;
-        gs = saved;
+        ObjectDef &od = objectDefs[name];
+        if (!od.created) {   // the object's shapes, once, where they were declared
+            od.created = true;
+            objectOrder.push_back(name);
+            std::vector<PendingPrim> world;
+            world.swap(pending);
+            for (const RecordedShape &r : it->second) {
+                ctm = r.ctm;
+                gs = r.gs;
+                Shape(r.name, r.params);
+            }
+            od.prims.swap(pending);
+            pending.swap(world);
+            ctm = instanceToWorld;
+            gs = saved;
+            for (const PendingPrim &pp : od.prims) od.bounds = Union(od.bounds, pp.bounds);
+        }
+        if (od.prims.empty()) return;   // api.cpp:1580
+        instanceRecs.push_back(InstanceRec{name, instanceToWorld});
+        PendingPrim pp;
+        pp.shape = 0;
+        pp.material = -1;
+        pp.light = -1;
+        pp.instance = (int)instanceRecs.size();
+        pp.bounds = instanceToWorld.Bounds(od.bounds);   // TransformedPrimitive::WorldBound: MotionBounds of a static transform
+        pending.push_back(pp);
     }
 
     void LightSource(const std::string &name, const ParamSet &ps) {  // MakeLight, api.cpp:747-771
@@ -923,7 +961,40 @@ void Api::WorldEnd() {
             p.shape = pp.shape;
             p.material = pp.material;
             p.area_light = pp.light;
+            p.instance = pp.instance;
             scene->prims[i] = p;
+        }
+        // the objects' own BVHs (MakeAccelerator over the object's primitives at its first ObjectInstance, api.cpp:1583-1590),
+        // appended to the node and primitive arrays with absolute offsets; then the instances that point at them
+        for (const std::string &name : objectOrder) {
+            ObjectDef &od = objectDefs[name];
+            if (od.prims.empty()) continue;
+            std::vector<Bounds3> ob(od.prims.size());
+            for (size_t i = 0; i < od.prims.size(); ++i) ob[i] = od.prims[i].bounds;
+            std::vector<mi_bvh_node> onodes;
+            std::vector<int> oorder;
+            int oi = 0, ol = 0;
+            if (method == SplitMethod::HLBVH) BuildHLBVH(ob, maxPrims, &onodes, &oorder, &oi, &ol);
+            else BuildBVH(ob, maxPrims, method, &onodes, &oorder, &oi, &ol);
+            const int baseNode = (int)scene->nodes.size(), basePrim = (int)scene->prims.size();
+            for (mi_bvh_node &n : onodes) n.offset += (n.n_prims > 0) ? basePrim : baseNode;
+            scene->nodes.insert(scene->nodes.end(), onodes.begin(), onodes.end());
+            for (int k : oorder) {
+                const PendingPrim &pp = od.prims[k];
+                mi_prim p{};
+                p.shape = pp.shape; p.material = pp.material; p.area_light = pp.light; p.instance = 0;
+                scene->prims.push_back(p);
+            }
+            od.root = baseNode;
+            scene->stats.interiorNodes += oi;
+            scene->stats.leafNodes += ol;
+        }
+        for (const InstanceRec &ir : instanceRecs) {
+            mi_instance mi{};
+            std::memcpy(mi.i2w, ir.i2w.m.m, sizeof(float) * 16);
+            std::memcpy(mi.w2i, ir.i2w.mInv.m, sizeof(float) * 16);
+            mi.root = (uint32_t)objectDefs[ir.object].root;
+            scene->instances.push_back(mi);
         }
     }
     // ---- lights: Preprocess (distant.h:52-54) + selection distribution
@@ -1413,6 +1484,7 @@ void HostScene::Finalize() {
     d.n_spheres = (uint32_t)spheres.size(); d.spheres = spheres.data();
     d.n_materials = (uint32_t)materials.size(); d.materials = materials.data();
     d.n_lights = (uint32_t)lights.size(); d.lights = lights.data();
+    d.n_instances = (uint32_t)instances.size(); d.instances = instances.empty() ? nullptr : instances.data();
     d.light_distrib.func = ldFunc.empty() ? nullptr : ldFunc.data();
     d.light_distrib.cdf = ldCdf.empty() ? nullptr : ldCdf.data();
     d.light_distrib.func_int = ldFuncInt.empty() ? nullptr : ldFuncInt.data();

@@ -48,6 +48,7 @@ struct HostScene {
     std::vector<HostMipMap> mipStore;   // storage behind desc.mipmaps
     std::vector<mi_mipmap> mipmaps;
     std::vector<mi_texture> textures;
+    std::vector<mi_instance> instances;   // ObjectInstance as TransformedPrimitive (their BVHs follow the world's in `nodes`)
     // light distribution
     std::vector<float> ldFunc, ldCdf, ldFuncInt;
     // sampler tables

@@ -11,7 +11,7 @@
 namespace mipt {
 namespace {
 
-const char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '3'};
+const char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '4'};
 
 struct Out {
     FILE *f;
@@ -55,7 +55,7 @@ template <typename IO, typename S>
 void Fields(IO &io, S &s) {   // the same walk writes and reads
     io.Vec(s.nodes); io.Vec(s.prims); io.Vec(s.triIndices); io.Vec(s.triMesh);
     io.Vec(s.P); io.Vec(s.N); io.Vec(s.UV);
-    io.Vec(s.meshes); io.Vec(s.spheres); io.Vec(s.materials); io.Vec(s.lights); io.Vec(s.textures);
+    io.Vec(s.meshes); io.Vec(s.spheres); io.Vec(s.materials); io.Vec(s.lights); io.Vec(s.textures); io.Vec(s.instances);
     io.Vec(s.ldFunc); io.Vec(s.ldCdf); io.Vec(s.ldFuncInt);
     io.Vec(s.primes); io.Vec(s.primeSums); io.Vec(s.perms);
     io.Vec(s.sobolMatrices); io.Vec(s.sobolVdc); io.Vec(s.sobolVdcInv);
@@ -135,7 +135,7 @@ HostScene *LoadSceneCache(const std::string &path, std::string *err) {
     const bool consistent = in.ok && s->nodes.size() == d.n_nodes && s->prims.size() == d.n_prims && s->triIndices.size() == 3ull * d.n_tris &&
                             s->triMesh.size() == d.n_tris && s->P.size() == 3ull * d.n_verts && s->N.size() == 3ull * d.n_verts &&
                             s->UV.size() == 2ull * d.n_verts && s->meshes.size() == d.n_meshes && s->spheres.size() == d.n_spheres &&
-                            s->materials.size() == d.n_materials && s->lights.size() == d.n_lights && s->textures.size() == d.n_textures &&
+                            s->materials.size() == d.n_materials && s->lights.size() == d.n_lights && s->textures.size() == d.n_textures && s->instances.size() == d.n_instances &&
                             s->envStore.size() == d.n_envmaps && s->mipStore.size() == d.n_mipmaps && (int)s->primes.size() == d.sampler.n_dims &&
                             s->primeSums.size() == s->primes.size() && s->perms.size() == d.sampler.n_perms;
     if (!consistent) { delete s; *err = "scene cache \"" + path + "\" is truncated or inconsistent"; return nullptr; }

@@ -483,6 +483,96 @@ def bump_scene(res=64, spp=16, depth=4):
     return BUMP_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch())
 
 
+INSTANCED_SCENE = """
+LookAt 0 2.2 -8  0 0.9 0  0 1 0
+Camera "perspective" "float fov" [42] %(lens)s
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [16 15 14]
+  Translate 1 5.5 -2
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]
+AttributeEnd
+LightSource "point" "rgb I" [12 12 14] "point from" [-3 3 -5]
+Texture "bumps" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [3] "float vscale" [3] "float scale" [.04]
+Texture "colour" "spectrum" "imagemap" "string filename" "tex_c.pfm"
+Texture "leaf" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [3] "float vscale" [2]
+# the object: declared once under a transform of its own (a sphere, a bump-mapped textured patch with normals, an
+# alpha-masked panel, a glass ball), each shape with the material bound at its declaration
+AttributeBegin
+  Rotate 15 0 0 1
+  ObjectBegin "thing"
+    Material "plastic" "rgb Kd" [.7 .2 .1] "rgb Ks" [.3 .3 .3] "float roughness" [.05]
+    Shape "sphere" "float radius" [.45]
+    AttributeBegin
+      Material "uber" "texture Kd" "colour" "rgb Ks" [.3 .3 .3] "rgb Kr" [.1 .1 .1] "texture bumpmap" "bumps"
+      Translate 0 .9 0
+      Scale .5 .5 .5
+      %(patch)s
+    AttributeEnd
+    AttributeBegin
+      Material "matte" "rgb Kd" [.1 .5 .2]
+      Translate .9 .3 0
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.5 -.5 0  .5 -.5 0  .5 .5 0  -.5 .5 0] "float uv" [0 0 1 0 1 1 0 1]
+            "texture alpha" "leaf"
+    AttributeEnd
+    AttributeBegin
+      Material "glass" "float index" [1.5]
+      Translate -.8 .2 -.3
+      Shape "sphere" "float radius" [.3]
+    AttributeEnd
+  ObjectEnd
+AttributeEnd
+# a single-shape object (no tree above the shape in the reference; a one-leaf tree here)
+ObjectBegin "ball"
+  Material "mirror"
+  Shape "sphere" "float radius" [.35]
+ObjectEnd
+Material "matte" "texture Kd" "colour"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-7 0 -7  7 0 -7  7 0 7  -7 0 7] "float uv" [0 0 1 0 1 1 0 1]
+Material "matte" "rgb Kd" [.6 .6 .6]
+Shape "sphere" "float radius" [.5] "float phimax" [270]
+AttributeBegin
+  Translate -2.2 .6 .5
+  Rotate 40 0 1 0
+  ObjectInstance "thing"
+AttributeEnd
+AttributeBegin
+  Translate 2 .8 1
+  Rotate -70 0 1 0
+  Scale 1.4 .8 1.2
+  ObjectInstance "thing"
+AttributeEnd
+AttributeBegin
+  Translate 0 1.2 2.5
+  Scale -1 1 1
+  Rotate 25 1 0 0
+  ObjectInstance "thing"
+AttributeEnd
+AttributeBegin
+  Translate .3 .4 -1.5
+  ObjectInstance "ball"
+AttributeEnd
+AttributeBegin
+  Translate -1 2.2 1
+  Scale 1.5 .7 1
+  ObjectInstance "ball"
+AttributeEnd
+WorldEnd
+"""
+
+
+def instanced_scene(res=64, spp=16, depth=5, lens=False):
+    """ObjectBegin / ObjectInstance (api.cpp:1544-1615) as TransformedPrimitives over objects with trees of their own:
+    rotated, non-uniformly scaled and mirrored uses of an object with a quadric, a bump-mapped textured mesh with normals, an
+    alpha-masked panel and a glass ball; a single-shape object; world shapes between them. Needs write_texture_files() and
+    write_alpha_png()."""
+    return INSTANCED_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                  lens='"float lensradius" [.05] "float focaldistance" [8]' if lens else "")
+
+
 def random_scene(seed, res=32, spp=8):
     """A seeded random scene over the supported feature set (fuzzing the HIP path against the oracle): random meshes
     with / without normals and uv, spheres, every material family with random parameters (image-textured, bump-mapped

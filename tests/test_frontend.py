@@ -545,10 +545,42 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
     assert (m.width, m.height, m.n_levels) == (1, 1, 1) and all(abs(m.texels[i] - 0.21404114) < 1e-6 for i in range(3))
 
 
-def test_object_instances_expand_to_the_declared_shapes(pt):
-    """ObjectBegin / ObjectEnd / ObjectInstance (api.cpp:1431-1435,1544-1615): an instance re-creates the object's shapes under
-    InstanceToWorld * (CTM at declaration), with the material and orientation bound at declaration; a mirrored instance flips
+def test_object_instances_are_transformed_primitives(pt):
+    """ObjectInstance (api.cpp:1562-1615) makes a TransformedPrimitive: the object's shapes exist once, in the space of their
+    declaration, under a BVH of their own; each use is one world primitive that names an mi_instance (InstanceToWorld and
+    the object's root node) and is bounded by InstanceToWorld(object bounds)."""
+    head = 'Camera "perspective"\nWorldBegin\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+    obj = 'ObjectBegin "thing"\n  Material "plastic"\n  Translate 1 0 0\n  ' + tri + '  Shape "sphere" "float radius" [.5]\nObjectEnd\n'
+    text = (head + obj + 'Material "matte"\n' + tri + 'AttributeBegin\nTranslate 3 0 0\nObjectInstance "thing"\nAttributeEnd\n'
+            'AttributeBegin\nScale 2 2 2\nObjectInstance "thing"\nAttributeEnd\nWorldEnd\n')
+    s = pt.Scene(text=text)
+    assert s.errors == []
+    d = s.desc
+    assert (d.n_tris, d.n_spheres, d.n_instances, d.n_prims) == (2, 1, 2, 5)
+    prims = [d.prims[i] for i in range(d.n_prims)]
+    uses = [p for p in prims if p.instance != 0]
+    assert sorted(p.instance for p in uses) == [1, 2] and len([p for p in prims if p.instance == 0]) == 3
+    i0, i1 = d.instances[0], d.instances[1]
+    assert i0.root == i1.root and 0 < i0.root < d.n_nodes
+    m0, m1 = np.array(list(i0.i2w)).reshape(4, 4), np.array(list(i1.i2w)).reshape(4, 4)
+    assert np.allclose(m0, [[1, 0, 0, 3], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]) and np.allclose(m1, np.diag([2, 2, 2, 1]))
+    assert np.allclose(np.array(list(i1.w2i)).reshape(4, 4) @ m1, np.eye(4))
+    root = d.nodes[i0.root]
+    # the object: triangle (1..2, 0..1, 0) and sphere of radius .5 at (1, 0, 0), in the object's own space
+    assert np.allclose(list(root.bmin), [.5, -.5, -.5]) and np.allclose(list(root.bmax), [2, 1, .5])
+    # the world tree (root 0) bounds the plain triangle and both uses
+    assert np.allclose(list(d.nodes[0].bmin), [0, -1, -1]) and np.allclose(list(d.nodes[0].bmax), [5, 2, 1])
+    # primitives of the object keep the material bound at their declaration (plastic = kind 1); the uses have none
+    obj_prims = [p for p in prims if p.instance == 0 and d.materials[p.material].kind == 1]
+    assert len(obj_prims) == 2 and all(p.material < 0 for p in uses)
+
+
+def test_object_instances_expand_to_the_declared_shapes(pt, monkeypatch):
+    """MIPT_INSTANCES=expand: an instance re-creates the object's shapes under InstanceToWorld * (CTM at declaration)
+    (api.cpp:1431-1435,1544-1615), with the material and orientation bound at declaration; a mirrored instance flips
     the mesh's handedness flag; misuse is reported with the reference's messages."""
+    monkeypatch.setenv("MIPT_INSTANCES", "expand")
     head = 'Camera "perspective"\nWorldBegin\n'
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] "normal N" [0 0 1 0 0 1 0 0 1]\n'
     obj = ('Translate 0 0 1\nObjectBegin "thing"\n  Material "plastic" "rgb Kd" [.1 .2 .3]\n  Translate 1 0 0\n  ' + tri +

@@ -486,6 +486,48 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
         assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
 
 
+def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
+    """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
+    walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
+    quadrics, textures, bump maps and alpha masks inside the object, under rotated, stretched and mirrored uses."""
+    st.write_texture_files(str(tmp_path))
+    st.write_alpha_png(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.instanced_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == [] and s.desc.n_instances == 5
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "object instances lens=%s" % lens)
+    # recorded rays: the same primitive of the object, the same t, whichever use was hit; the same occlusion
+    rng = np.random.default_rng(5)
+    n = 6000
+    o = np.tile(np.array([0, 2.2, -8], np.float32), (n, 1)) + rng.normal(0, .3, (n, 3)).astype(np.float32)
+    tgt = np.stack([rng.uniform(-3.5, 3.5, n), rng.uniform(0, 3, n), rng.uniform(-2, 3, n)], -1).astype(np.float32)
+    rays = np.concatenate([o, tgt - o, np.full((n, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    for any_hit in (False, True):
+        dh = integ.trace(rays, any_hit=any_hit)
+        oh, _ = ob.trace(s, rays, any_hit=any_hit)
+        if any_hit:
+            assert np.array_equal(dh[:, 0].view(np.int32) >= 0, oh[:, 0].view(np.int32) >= 0)
+        else:
+            assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32))
+            assert np.array_equal(dh[:, 1], oh[:, 1])
+            closest = dh[:, 0].view(np.int32).copy()
+    members = set()   # the primitives under the objects' roots (a first child follows its parent in the array)
+    for k in range(s.desc.n_instances):
+        todo = [int(s.desc.instances[k].root)]
+        while todo:
+            i = todo.pop()
+            nd = s.desc.nodes[i]
+            if nd.n_prims > 0: members.update(range(nd.offset, nd.offset + nd.n_prims))
+            else: todo += [i + 1, nd.offset]
+    assert np.isin(closest, sorted(members)).sum() > 200   # (rays did land on the objects' primitives)
+    # and the same picture as with the instances expanded into world shapes (a different tree and float path: statistically)
+    monkeypatch.setenv("MIPT_INSTANCES", "expand")
+    flat = pt.Scene(text=st.instanced_scene(lens=True), base_dir=str(tmp_path))
+    assert flat.errors == [] and flat.desc.n_instances == 0
+    ff, fw = pt.CreatePathIntegrator(flat).Render()
+    assert _rel_l2(ff, film) < 0.05
+
+
 def test_random_scenes_against_oracle(pt, ob, tmp_path):
     """Fuzz: 24 seeded random scenes over the whole supported feature set (scenes_text.random_scene) through the HIP path and
     the oracle (exact mode: same decisions in every path). Per scene: identical filter weights, ray counters equal, image

@@ -27,7 +27,7 @@ def _check_tree(s, max_prims):
     offset, nprims = np.array(nodes["offset"]), np.array(nodes["n_prims"])
     seen = np.zeros(s.desc.n_prims, int)
     next_leaf = 0
-    stack = [0]
+    stack = sorted({0} | {int(s.desc.instances[k].root) for k in range(s.desc.n_instances)})   # the world's tree and the objects'
     while stack:   # depth first: first child = i + 1, second = offset
         i = stack.pop()
         if nprims[i] > 0:

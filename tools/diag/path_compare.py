@@ -1,5 +1,7 @@
 """Diagnostic (GPU box): vertex-by-vertex comparison of device and oracle for the samples that differ.
-Usage: path_compare.py <scene name of sample_divergence.mk> [spp] [max samples shown]"""
+Usage: path_compare.py <scene name of sample_divergence.mk> [spp] [max samples shown] [all]
+"all": walk every camera sample of the frame instead of the ones whose one-sample film differs (needed when the filter is
+not the box filter or the sampler is not Halton: then a sample's film is not one pixel) and print only paths that differ."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -11,15 +13,24 @@ name = sys.argv[1]
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nshow = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 s = mk(name, -1, spp)
-bad = per_sample(s, list(range(1, spp)))
-print(name, "differing samples:", len(bad))
+walk_all = len(sys.argv) > 4 and sys.argv[4] == "all"
+if walk_all:
+    w, h = s.film_size
+    bad = [(x, y, k) for y in range(h) for x in range(w) for k in range(spp)]
+else:
+    bad = per_sample(s, list(range(1, spp)))
+    print(name, "differing samples:", len(bad))
 integ = pt.CreatePathIntegrator(s)
 FIELDS = [("bounces", 0, 1), ("prim", 1, 2), ("dim_before", 2, 3), ("ended", 3, 4), ("ray_o", 4, 7), ("t_hit", 7, 8), ("ray_d", 8, 11),
           ("etaScale_in", 11, 12), ("next_o", 12, 15), ("dim_after", 15, 16), ("next_d", 16, 19), ("etaScale_out", 19, 20),
           ("beta", 20, 51), ("L", 51, 82)]
-for (x, y, k) in list(bad)[:nshow]:
+shown = 0
+for (x, y, k) in list(bad):
+    if shown >= nshow: break
     d = integ.debug_path(x, y, k)
     o = ob.path_log(s, x, y, k)
+    if walk_all and len(d) == len(o) and np.array_equal(d[:, :20].view(np.uint32), o[:, :20].view(np.uint32)): continue
+    shown += 1
     print("pixel (%d,%d) k=%d: device %d vertices, oracle %d" % (x, y, k, len(d), len(o)))
     for v in range(min(len(d), len(o))):
         diffs = []
