@@ -482,19 +482,20 @@ DEV bool TraverseTree(const DScene &s, int rootRecord, bool rootHit, const V3 &r
     }
     return found;
 }
-template <bool ANY, int W>
+// INST: compiled for scenes with object instances (the nested traversal costs the calling kernel ~40 VGPRs)
+template <bool ANY, int W, bool INST>
 DEV bool TraverseW(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
     RayCtx r;
     InitRayCtx(r, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     TravState st;
     StartTraversal(s, r, tMax, st, nodeCount);
-    return TraverseTree<ANY, W, true>(s, 0, st.cur >= 0, ro, rd, tMax, 0, -1, hit, nodeCount, triCount);
+    return TraverseTree<ANY, W, INST>(s, 0, st.cur >= 0, ro, rd, tMax, 0, -1, hit, nodeCount, triCount);
 }
 
-template <bool ANY>
+template <bool ANY, bool INST>
 DEV bool Traverse(const DScene &s, const V3 &ro, const V3 &rd, float tMax, Hit *hit, unsigned &nodeCount, unsigned &triCount) {
-    if (s.bvhWidth == 4) return TraverseW<ANY, 4>(s, ro, rd, tMax, hit, nodeCount, triCount);
-    return TraverseW<ANY, 2>(s, ro, rd, tMax, hit, nodeCount, triCount);
+    if (s.bvhWidth == 4) return TraverseW<ANY, 4, INST>(s, ro, rd, tMax, hit, nodeCount, triCount);
+    return TraverseW<ANY, 2, false>(s, ro, rd, tMax, hit, nodeCount, triCount);
 }
 
 DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si);
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 // accepted before it); a triangle hit that the traversal found AFTER the last accepted quadric survives only if it is
 // closer than that quadric. (Shadow rays: tMax never changes, the order does not matter.) On overflow the ray is
 // re-traversed by the reference-order routine with inline quadric tests.
-template <bool ANY>
+template <bool ANY, bool INST>
 DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
                          Hit *h, bool foundTri, unsigned &nodes, unsigned &tris) {
     const int np = pool.I(I_NPEND, slot);
@@ -749,7 +750,7 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
         Hit h2;
         h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
         unsigned n2 = 0, t2 = 0;  // statistics were already counted by k_trav
-        const bool found = Traverse<ANY>(s, ro, rd, tMaxIn, &h2, n2, t2);
+        const bool found = Traverse<ANY, INST>(s, ro, rd, tMaxIn, &h2, n2, t2);
         if (found) *h = h2;
         return found;
     }
@@ -784,6 +785,7 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
 #endif
 constexpr int SLOT_CHUNKS = MIPT_SLOT_CHUNKS;
 
+template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
     // append to the class queues: one atomic per class and block
     __shared__ unsigned sCnt[SLOT_CHUNKS][BLOCK / 64][MAX_CLASSES], sBase[MAX_CLASSES];
@@ -803,12 +805,12 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
                 V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
                 Hit h;
                 h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
-                if (s.nInstances) h.inst = pool.I(I_HITINST, slot);
-                const bool found = ResolveQuadrics<false>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
+                if (INST) h.inst = pool.I(I_HITINST, slot);
+                const bool found = ResolveQuadrics<false, INST>(s, pool, slot, ro, rd, r0.w, &h, prim >= 0, nodes, tris);
                 prim = found ? h.prim : -1;
                 pool.I(I_HITPRIM, slot) = prim;
                 pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
-                if (s.nInstances) pool.I(I_HITINST, slot) = h.inst;
+                if (INST) pool.I(I_HITINST, slot) = h.inst;
             }
             cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
         }
@@ -842,6 +844,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
     }
 }
 
+template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
@@ -856,7 +859,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
             const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
             V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
             Hit h;
-            occluded = ResolveQuadrics<true>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
+            occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
         }
         myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
     }
@@ -895,6 +898,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
 }
 
 
+template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0, nodes = 0, tris = 0;
@@ -915,7 +919,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevC
             haveRay = true;
         };
         bool found = h.prim >= 0;
-        if (pool.I(I_NPEND, slot) != 0) { loadRay(); found = ResolveQuadrics<false>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
+        if (pool.I(I_NPEND, slot) != 0) { loadRay(); found = ResolveQuadrics<false, INST>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
         bool added = false;
         if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
             const bool lZero = (flags & F_L_ZERO) != 0;
@@ -1837,8 +1841,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, ui
     Hit h;
     h.prim = -1; h.t = 0; h.b0 = h.b1 = h.b2 = 0;
     int prim;
-    if (anyHit) prim = Traverse<true>(s, ro, rd, r[6], &h, nodes, tris) ? 0 : -1;
-    else prim = Traverse<false>(s, ro, rd, r[6], &h, nodes, tris) ? h.prim : -1;
+    if (anyHit) prim = Traverse<true, true>(s, ro, rd, r[6], &h, nodes, tris) ? 0 : -1;
+    else prim = Traverse<false, true>(s, ro, rd, r[6], &h, nodes, tris) ? h.prim : -1;
     float *o = hits + (size_t)i * 4;
     o[0] = __int_as_float(prim);
     o[1] = (prim >= 0 && !anyHit) ? h.t : 0.f;
@@ -2636,15 +2640,18 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipEventRecord(ev[7], st));
         LaunchTraversal(pt, sub, 0, travGrid);
         HIPCHK(hipEventRecord(ev[6], st));
-        hipLaunchKernelGGL(k_resolve_extend, chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_extend<true>), chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_extend<false>), chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[2], st));
         LaunchShade(pt, sub, grid);
         HIPCHK(hipEventRecord(ev[3], st));
         LaunchTraversal(pt, sub, 1, travGrid);
-        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[4], st));
         LaunchTraversal(pt, sub, 2, travGrid);
-        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());   // a launch of this iteration that was refused (bad configuration) stops the render here
         havePrev = true; prevFull = true;
@@ -2829,7 +2836,8 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         float *r = records + (size_t)(*n_records) * MI_PATH_RECORD_FLOATS;
         for (int k = 0; k < MI_PATH_RECORD_FLOATS; ++k) r[k] = 0.f;
         LaunchTraversal(pt, sub, 0, travGrid);
-        hipLaunchKernelGGL(k_resolve_extend, dim3(1), block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_extend<true>), dim3(1), block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_extend<false>), dim3(1), block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipStreamSynchronize(st));
         int bounces = 0, prim = -1, dim = 0;
         float ray0[4], ray1[4], hit[4];
@@ -2840,9 +2848,11 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         r[8] = ray1[0]; r[9] = ray1[1]; r[10] = ray1[2]; r[11] = ray1[3];
         LaunchShade(pt, sub, grid);
         LaunchTraversal(pt, sub, 1, travGrid);
-        hipLaunchKernelGGL(k_resolve_shadow, grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         LaunchTraversal(pt, sub, 2, travGrid);
-        hipLaunchKernelGGL(k_resolve_mis, grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int fl = 0;
