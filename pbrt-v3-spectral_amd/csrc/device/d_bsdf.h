@@ -261,6 +261,7 @@ DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int whi
 #define TM_SPECULAR(tm) (TM_HAS(tm, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(tm, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(tm, MI_BXDF_FRESNEL_SPECULAR))
 constexpr unsigned TM_ALL = 0xffffffffu;
 constexpr unsigned TM_SCALED = 1u << 31;
+constexpr unsigned TM_SAMPLERS = 1u << 15;   // the instance draws from the Sobol' and random samplers too (without it: Halton only)
 constexpr unsigned TM_INSTANCES = 1u << 29;  // the scene has object instances: hits carry the instance they were reached through
 constexpr unsigned TM_TEXTURED = 1u << 30;  // some lobe takes its spectrum from an image texture  // some lobe is a ScaledBxDF (mix material)
 #define TM_LIGHT(tm, t) ((((tm) >> (24 + (t))) & 1u) != 0u)   // bits 24..: mi_light_type present in the scene

@@ -141,7 +141,11 @@ struct PathSampler {
 };
 // (Nothing here may take the address of the kernel's DScene argument: that would move the whole argument block into
 // private memory and send every later field access through scratch -- measured: k_shade 2.3x slower.)
+// HALTON_ONLY: the shading instances of Halton-sampled scenes (every BASELINE workload) are compiled without the other two
+// samplers (TM_SAMPLERS, d_bsdf.h)
+template <bool HALTON_ONLY = false>
 DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelPlane, const int *__restrict__ samplePlane, uint32_t slot) {
+    if constexpr (HALTON_ONLY) return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim++);
     if (s.samplerType == MI_SAMPLER_RANDOM) {
         const int pixelWord = pixelPlane[slot];
         const uint64_t inc = RandomStreamInc(s, (int)(short)(pixelWord & 0xffff), pixelWord >> 16, (long long)samplePlane[slot]);

@@ -131,7 +131,10 @@ DEV V3 PermuteZ(const V3 &v, int kz) {  // (v[kx], v[ky], v[kz]) with kx = kz+1,
     const float z = k0 ? v.x : (k1 ? v.y : v.z);
     return V3(x, y, z);
 }
-DEV bool TriTestRay(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const TriRay &tr, float tMax, TriHit *hit) {
+// (detOut / tScaledOut: the two quantities of the only tMax-dependent line of the test, for callers that re-apply it with a
+// smaller tMax -- the cooperative leaf test of k_trav)
+DEV bool TriTestRay(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, const TriRay &tr, float tMax, TriHit *hit,
+                    float *detOut = nullptr, float *tScaledOut = nullptr) {
     V3 p0t = PermuteZ(p0 - ro, tr.kz), p1t = PermuteZ(p1 - ro, tr.kz), p2t = PermuteZ(p2 - ro, tr.kz);
     const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
@@ -172,6 +175,7 @@ DEV bool TriTestRay(const V3 &p0, const V3 &p1, const V3 &p2, const V3 &ro, cons
     float deltaT = 3 * (gammaf(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absf(invDet);
     if (t <= deltaT) return false;
     hit->t = t; hit->b0 = b0; hit->b1 = b1; hit->b2 = b2;
+    if (detOut) { *detOut = det; *tScaledOut = tScaled; }
     return true;
 }
 

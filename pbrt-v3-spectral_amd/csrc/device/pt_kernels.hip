@@ -383,6 +383,10 @@ DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, f
     }
 }
 
+// A leaf's primitive count in the traversal records carries LEAF_SIMPLE when every primitive of the leaf is a triangle (no
+// quadric to postpone, no instance to enter): those leaves go through the cooperative test of k_trav.
+constexpr int LEAF_SIMPLE = 0x4000, LEAF_COUNT_MASK = 0x3fff;
+
 // Advance until the lane holds a leaf (returns true with leafOffset/leafCount) or the
 // traversal is finished (returns false, st.cur == -1).
 template <int W>
@@ -398,7 +402,7 @@ DEV bool NextLeaf(const float4 *__restrict__ wnodes, const RayCtx &r, float tMax
             got = t < tMax;
         }
         if (!got) { st.cur = -1; return false; }
-        if (tkMeta > 0) { *leafOffset = tkChild; *leafCount = tkMeta; st.cur = -2; return true; }
+        if (tkMeta > 0) { *leafOffset = tkChild; *leafCount = tkMeta & LEAF_COUNT_MASK; st.cur = -2; return true; }
         st.cur = tkChild;
     }
     return false;
@@ -516,9 +520,13 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 constexpr int TRAV_BLOCKS_PER_CU = MIPT_TRAV_BLOCKS_PER_CU;
 constexpr int REFILL_BELOW = MIPT_REFILL_BELOW;
 #ifndef MIPT_TRI_BATCH
-#define MIPT_TRI_BATCH 8
+#define MIPT_TRI_BATCH 16
 #endif
 constexpr int TRI_BATCH = MIPT_TRI_BATCH;
+#ifndef MIPT_COOP_KMAX
+#define MIPT_COOP_KMAX 4
+#endif
+constexpr int COOP_KMAX = MIPT_COOP_KMAX;   // (triangle, ray) pairs a waiting lane hands to the wave per pass (pbrt's default leaf size)
 #ifndef MIPT_TRAV_CHUNK
 #define MIPT_TRAV_CHUNK 128
 #endif
@@ -558,11 +566,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     int nPend = 0, hitPrim = -1;
     float hitT = 0, hitB0 = 0, hitB1 = 0, hitB2 = 0;
     int leafOff = 0, leafCnt = 0;
+    bool leafSimple = false;          // the leaf in hand holds triangles only (LEAF_SIMPLE)
+    __shared__ int sTask[BLOCK];      // cooperative leaf test: per wave, task -> (owner lane, position in its leaf)
     int curInst = -1, hitInst = -1;   // INST: the instance the lane is inside, and the one its closest hit so far lies in
     bool hitInCur = false;            // INST: something was hit since the lane entered curInst
     TriRay triRay;
     triRay.kz = 2; triRay.Sx = triRay.Sy = 0; triRay.Sz = 1;
     bool exhausted = false;
+#ifdef MIPT_TRAV_STATS
+    unsigned long long dbgPasses = 0, dbgHas = 0, dbgWalk = 0, dbgWalkPasses = 0, dbgTriPasses = 0, dbgTri = 0;
+#endif
     unsigned chunkNext = 0, chunkEnd = 0;  // wave-uniform: the range of the work list this wave reserved
     while (true) {
         // ---- fetch rays for idle lanes
@@ -623,6 +636,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             const bool inLeaf = has && leafCnt > 0;
             const int nLeaf = __popcll(__ballot(inLeaf));
             const bool anyWalk = __any(walking);
+#ifdef MIPT_TRAV_STATS
+            ++dbgPasses; dbgHas += __popcll(__ballot(has)); dbgWalk += __popcll(__ballot(walking));
+            if (anyWalk) ++dbgWalkPasses;
+            if (nLeaf > 0 && (nLeaf >= TRI_BATCH || !anyWalk)) { ++dbgTriPasses; dbgTri += nLeaf; }
+#endif
             bool needPop = false, got = false, finished = false;
             int tkChild = 0, tkMeta = 0;
             if (walking) {
@@ -630,7 +648,93 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 needPop = !got;
                 st.cur = -1;
             }
-            if (inLeaf && (nLeaf >= TRI_BATCH || !anyWalk)) {
+            const bool triPass = nLeaf > 0 && (nLeaf >= TRI_BATCH || !anyWalk);   // (wave-uniform)
+            // ---- cooperative leaf test. A lane waiting at a triangles-only leaf hands up to COOP_KMAX of its (ray, triangle)
+            // pairs to the wave: the pairs of all waiting lanes are numbered owner by owner, lane w tests pair w with the
+            // owner's ray against the owner's tMax of this moment, and the owner then takes the outcome the sequential loop
+            // of BVHAccel::Intersect would have reached: of the pairs that hit, in leaf order, each is accepted unless the
+            // test's one tMax-dependent line (tScaled against tMax * det, triangle.cpp:262-266) rejects it with the tMax
+            // left by the hit accepted before it. One pass finishes a whole leaf at the utilisation of (pairs / 64) instead
+            // of one triangle per waiting lane (a fifth of the wave on the 10M-triangle scene).
+            if (triPass && __any(inLeaf && leafSimple)) {
+                const bool coop = inLeaf && leafSimple;
+                const int want = coop ? min(leafCnt, COOP_KMAX) : 0;
+                int base = 0, total = 0;
+#pragma unroll
+                for (int b = 0; b < COOP_KMAX; ++b) {
+                    const unsigned long long m = __ballot(want > b);
+                    base += __popcll(m & ((1ull << wlane) - 1));
+                    total += __popcll(m);
+                }
+                const int grant = max(0, min(want, 64 - base));
+                int *taskOwner = &sTask[threadIdx.x & ~63];
+                for (int k = 0; k < grant; ++k) taskOwner[base + k] = wlane | (k << 8);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int nTask = min(total, 64);
+                const bool worker = wlane < nTask;
+                const int ow = worker ? taskOwner[wlane] : wlane;
+                const int owner = ow & 63, tk = ow >> 8;
+                const int wOff = __shfl(leafOff, owner, 64);
+                const float wox = __shfl(r.ox, owner, 64), woy = __shfl(r.oy, owner, 64), woz = __shfl(r.oz, owner, 64);
+                TriRay wtr;
+                wtr.kz = __shfl(triRay.kz, owner, 64);
+                wtr.Sx = __shfl(triRay.Sx, owner, 64); wtr.Sy = __shfl(triRay.Sy, owner, 64); wtr.Sz = __shfl(triRay.Sz, owner, 64);
+                const float wT = __shfl(tMax, owner, 64);
+                bool res = false;
+                float rT = 0, rB0 = 0, rB1 = 0, rB2 = 0, rDet = 0, rTs = 0;
+                if (worker) {
+                    const int prim = wOff + tk;
+                    const float4 v0 = primTri[3 * prim], v1 = primTri[3 * prim + 1], v2 = primTri[3 * prim + 2];
+                    const unsigned pf = __float_as_uint(v0.w);
+                    TriHit th;
+                    if (TriTestRay(V3(v0.x, v0.y, v0.z), V3(v1.x, v1.y, v1.z), V3(v2.x, v2.y, v2.z), V3(wox, woy, woz), wtr, wT, &th, &rDet, &rTs)) {
+                        bool counts = true;
+                        if constexpr (ALPHA)
+                            if (pf & PRIM_FLAG_ALPHA)
+                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
+                        res = counts && (ANY || !(pf & PRIM_FLAG_DEGENERATE));
+                        rT = th.t; rB0 = th.b0; rB1 = th.b1; rB2 = th.b2;
+                    }
+                }
+                const unsigned long long hitMask = __ballot(res);
+                const unsigned seg = grant > 0 ? (unsigned)(hitMask >> base) & ((1u << grant) - 1u) : 0u;   // bit k: my k-th pair hit
+                if (ANY) {
+                    if (seg) { hitPrim = leafOff + (__ffs(seg) - 1); finished = true; triCount += (unsigned)__ffs(seg); }
+                    else triCount += (unsigned)grant;
+                } else {
+                    int win = -1;
+                    const bool multi = __popc(seg) >= 2;
+                    if (__any(multi)) {   // two hits in one leaf: replay the sequence exactly
+                        unsigned rem = multi ? seg : 0u;
+                        float cur = tMax;
+                        while (__any(rem != 0u)) {
+                            const int k = rem ? (__ffs(rem) - 1) : 0;
+                            const int src = rem ? base + k : wlane;
+                            const float dk = __shfl(rDet, src, 64), tsk = __shfl(rTs, src, 64), tk2 = __shfl(rT, src, 64);
+                            if (rem) {
+                                const bool beyond = dk < 0 ? (tsk < cur * dk) : (tsk > cur * dk);
+                                if (!beyond) { cur = tk2; win = k; }
+                                rem &= rem - 1u;
+                            }
+                        }
+                    }
+                    if (!multi && seg) win = __ffs(seg) - 1;
+                    const int src = win >= 0 ? base + win : wlane;
+                    const float hT = __shfl(rT, src, 64), hB0 = __shfl(rB0, src, 64), hB1 = __shfl(rB1, src, 64), hB2 = __shfl(rB2, src, 64);
+                    if (win >= 0) {
+                        tMax = hT;
+                        hitPrim = leafOff + win; hitT = hT; hitB0 = hB0; hitB1 = hB1; hitB2 = hB2;
+                        if (INST) { hitInst = curInst; hitInCur = true; }
+                    }
+                    triCount += (unsigned)grant;
+                }
+                if (grant > 0) {
+                    leafOff += grant; leafCnt -= grant;
+                    needPop = !finished && leafCnt == 0;
+                }
+            }
+            if (triPass && inLeaf && !leafSimple) {
                 const int prim = leafOff;
                 ++leafOff; --leafCnt;
                 const float4 v0 = primTri[3 * prim];
@@ -711,7 +815,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 finished = !got;
             }
             if (got) {
-                if (tkMeta > 0) { leafOff = tkChild; leafCnt = tkMeta; }
+                if (tkMeta > 0) { leafOff = tkChild; leafCnt = tkMeta & LEAF_COUNT_MASK; leafSimple = (tkMeta & LEAF_SIMPLE) != 0; }
                 else st.cur = tkChild;
             }
             if (finished) {
@@ -726,6 +830,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (active == 0 || (!exhausted && active < REFILL_BELOW)) break;
         }
     }
+#ifdef MIPT_TRAV_STATS
+    if (blockIdx.x == 7 && threadIdx.x == 0 && total > 1000000)
+        printf("TRAVSTAT mode %d total %u passes %llu has/pass %.1f walkPasses %llu walk/walkPass %.1f triPasses %llu tri/triPass %.1f\n", MODE, total, dbgPasses,
+               (double)dbgHas / dbgPasses, dbgWalkPasses, (double)dbgWalk / (dbgWalkPasses ? dbgWalkPasses : 1), dbgTriPasses, (double)dbgTri / (dbgTriPasses ? dbgTriPasses : 1));
+#endif
     DevStats &st8 = Stats(ctr);
     if (MODE == 1) CountAdd(&st8.shadowRays, rayCount);
     else CountAdd(&st8.regularRays, rayCount);
@@ -1395,6 +1504,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         blk -= nb;
     }
     const uint32_t qi = blk * BLOCK + threadIdx.x;
+    constexpr bool HALTON_ONLY = (TM & TM_SAMPLERS) == 0;
     __shared__ SpectrumTile tile;
     unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
     bool wantShadow = false, wantMis = false;
@@ -1566,10 +1676,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const uint32_t di = LightDistribIndex(s, isect.p);
                     float selPdf;
                     const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
-                                                        s.ldFuncInt[di], (int)s.nLights, Get1D(s, ps, pixelPlane, samplePlane, slot), &selPdf);
+                                                        s.ldFuncInt[di], (int)s.nLights, Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), &selPdf);
                     if (selPdf != 0) {
-                        const float uL0 = Get1D(s, ps, pixelPlane, samplePlane, slot), uL1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
-                        const float uS0 = Get1D(s, ps, pixelPlane, samplePlane, slot), uS1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
+                        const float uL0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uL1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
+                        const float uS0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uS1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                         const mi_light &light = s.lights[lightNum];
                         const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
                         const Divisor selDiv = MakeDivisor(selPdf);
@@ -1677,7 +1787,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 V3 wo = -rd, wi;
                 float pdf = 0;
                 int sflags = 0;
-                const float u0 = Get1D(s, ps, pixelPlane, samplePlane, slot), u1 = Get1D(s, ps, pixelPlane, samplePlane, slot);
+                const float u0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), u1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                 BSDFEvalT<NL> ev;
                 const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
                 bool fNonBlack = false;
@@ -1716,7 +1826,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         bool killed = false;
                         if (maxRR < s.rrThreshold && bounces > 3) {
                             float q = maxf(.05f, 1 - maxRR);
-                            if (Get1D(s, ps, pixelPlane, samplePlane, slot) < q) killed = true;
+                            if (Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot) < q) killed = true;
                             else {
                                 const Divisor inv = MakeDivisor(1 - q);
 #pragma unroll 1
@@ -1740,7 +1850,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
             }
             pool.I(I_DIM, slot) = ps.dim;
-            if (s.samplerType == MI_SAMPLER_RANDOM) {   // the stream moves on with the path
+            if (!HALTON_ONLY && s.samplerType == MI_SAMPLER_RANDOM) {   // the stream moves on with the path
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)ps.index;
                 pool.I(I_IDXHI, slot) = (int)(uint32_t)(ps.index >> 32);
             }
@@ -2033,6 +2143,17 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         UP((const float4 *)d->nodes, (size_t)d->n_nodes * 2, nodes);
         s.nodes = nodes;
     }
+    for (uint32_t i = 0; i < d->n_nodes; ++i)
+        if (d->nodes[i].n_prims > (unsigned)LEAF_COUNT_MASK) { g_err = "a BVH leaf holds more than 16383 primitives"; mi_pt_destroy(pt); return MI_ERR_UNSUPPORTED; }
+    // a leaf's count as the traversal records carry it: | LEAF_SIMPLE when the leaf holds triangles only
+    auto leafMeta = [&](const mi_bvh_node &leaf) -> unsigned {
+        bool simple = getenv("MIPT_NO_COOP_LEAVES") == nullptr;
+        for (uint32_t k = 0; k < leaf.n_prims && simple; ++k) {
+            const mi_prim &p = d->prims[leaf.offset + k];
+            simple = p.instance == 0 && p.shape >= 0;
+        }
+        return (unsigned)leaf.n_prims | (simple ? (unsigned)LEAF_SIMPLE : 0u);
+    };
     s.bvhWidth = 4;   // MIPT_BVH_WIDTH=2: one record per BVH2 interior node, i.e. the reference's own node-visit counts
     if (const char *e = getenv("MIPT_BVH_WIDTH")) s.bvhWidth = (atoi(e) == 2) ? 2 : 4;
     if (s.bvhWidth == 4 && d->n_nodes > 0) {
@@ -2109,7 +2230,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 float4 *rec = &w[r * 8];
                 if (nodes[i].n_prims > 0) {   // single-leaf tree: the root itself in slot 0
                     int link1[4] = {nodes[i].offset, 0, 0, 0};
-                    unsigned cnt1[4] = {nodes[i].n_prims, 0xffffu, 0xffffu, 0xffffu};
+                    unsigned cnt1[4] = {leafMeta(nodes[i]), 0xffffu, 0xffffu, 0xffffu};
                     setBox(rec, 0, nodes[i]);
                     const int gN1[2] = {1, 0}, gA1[2] = {0, 0};
                     finish(rec, link1, cnt1, 0, gN1, gA1);
@@ -2129,7 +2250,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                         const mi_bvh_node &gn = nodes[sl[k]];
                         const int slot = 2 * c + k;
                         setBox(rec, slot, gn);
-                        if (gn.n_prims > 0) { link[slot] = gn.offset; cnt[slot] = gn.n_prims; }
+                        if (gn.n_prims > 0) { link[slot] = gn.offset; cnt[slot] = leafMeta(gn); }
                         else { link[slot] = widx[sl[k]]; cnt[slot] = 0; below = std::max(below, need[widx[sl[k]]]); }
                         ++present;
                     }
@@ -2138,8 +2259,8 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 finish(rec, link, cnt, nodes[i].axis, gN, gA);
             }
         }
-        int needAll = need[0];   // the world tree's need, plus -- inside an instance -- two return entries and the object tree's
-        for (uint32_t k = 0; k < d->n_instances; ++k) needAll = std::max(needAll, need[0] + 2 + need[widx[d->instances[k].root]]);
+        int needAll = need[0];   // the world tree's need, plus -- inside an instance -- the return entry and the object tree's
+        for (uint32_t k = 0; k < d->n_instances; ++k) needAll = std::max(needAll, need[0] + 1 + need[widx[d->instances[k].root]]);
         if (needAll > STACK_LDS + STACK_SPILL) {
             // (pbrt's own 64-entry stack bounds the BVH2 depth; a wide record can hold up to three entries per two levels)
             s.bvhWidth = 2;
@@ -2174,7 +2295,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         auto putChild = [&](float4 *rec, int which, uint32_t child, int axis) {
             const mi_bvh_node &c = d->nodes[child];
             int link, meta;
-            if (c.n_prims > 0) { link = c.offset; meta = c.n_prims; }
+            if (c.n_prims > 0) { link = c.offset; meta = (int)leafMeta(c); }
             else { link = widx[child]; meta = 0; }
             if (which == 0) {
                 rec[0] = float4{c.bmin[0], c.bmin[1], c.bmin[2], c.bmax[0]};
@@ -2537,19 +2658,23 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
         if (more) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, more);
         return;
     }
-    if (pt->hasInfiniteLight) {
-        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
-        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-    } else {
-        if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
-        if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
-    }
+    // the two hot instances (matte-like and plastic-like classes) exist with and without environment-light code and
+    // with the Halton sampler alone or all three
+#define SHADE_LAUNCH(TM_, CLASSES_) hipLaunchKernelGGL((k_shade<2, TM_>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, CLASSES_)
+#define SHADE_LAUNCH_HOT(TM_, CLASSES_) do { if (!(CLASSES_)) break; \
+        if (halton) { if (pt->hasInfiniteLight) SHADE_LAUNCH(TM_ | TM_LIGHTS_ALL, CLASSES_); else SHADE_LAUNCH(TM_ | TM_LIGHTS_NO_ENV, CLASSES_); } \
+        else { if (pt->hasInfiniteLight) SHADE_LAUNCH(TM_ | TM_LIGHTS_ALL | TM_SAMPLERS, CLASSES_); else SHADE_LAUNCH(TM_ | TM_LIGHTS_NO_ENV | TM_SAMPLERS, CLASSES_); } } while (0)
+    const bool halton = s.samplerType == MI_SAMPLER_HALTON;
+    SHADE_LAUNCH_HOT(TM_DIFFUSE, pt->diffuseClasses);
+    SHADE_LAUNCH_HOT(TM_PLASTIC, pt->plasticClasses);
+#undef SHADE_LAUNCH_HOT
+#undef SHADE_LAUNCH
     if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
     if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
     if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
     if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
-    if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
-    if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
+    if (pt->texturedDiffuse) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedDiffuse);
+    if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
     if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
     if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
 }
