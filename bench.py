@@ -67,12 +67,12 @@ def main():
 
     # concurrent sub-renderer streams need their own hardware queues (HIP maps streams onto 4 by default)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # N = 1: one sub-renderer, so that every timed launch has the GPU to itself (the roofline figure).
-    # N > 1: a rank's shard is 1/N of the frame, launches are short and their tails weigh more; four
-    # concurrent sub-renderers per GPU hide them (tools/shard_tune.py: 0.174 s -> 0.162 s for an 1/8 shard).
+    # One sub-renderer per GPU at every N: every timed launch has the GPU to itself (the roofline figure), and with
+    # round 2's kernels concurrent pools no longer pay (one-GPU rehearsal of the shards, tools/shard_scaling.py:
+    # slowest 1/2 shard 0.433 s with one pool, 0.453 s with four; 1/4 shard 0.229 / 0.228 s; 1/8 shard 0.122 / 0.121 s).
     if a.streams > 0:
         os.environ["MIPT_STREAMS"] = str(a.streams)
-    os.environ.setdefault("MIPT_STREAMS", "1" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "4")
+    os.environ.setdefault("MIPT_STREAMS", "1")
     import torch
     import pbrt_v3_spectral_amd as pt
     import importlib.util
