@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -167,8 +167,14 @@ typedef struct mi_material {
     mi_bxdf bxdf[MI_MAX_BXDFS];
     mi_lobe_tex tex[MI_MAX_BXDFS];
     int32_t bump_tex; /* "bumpmap": float image texture displacing the shading geometry (Material::Bump, material.cpp:47-84), -1 = none */
-    int32_t pad[3];
+    /* "roughness" / "uroughness" / "vroughness" given as float image textures (plastic.cpp:57-62, uber.cpp:88-96,
+     * substrate.cpp:55-60, metal.cpp:66-73, translucent.cpp:70-72): texture of the u / v roughness of the material's
+     * microfacet lobes, -1 = the constant alpha in mi_bxdf.p[0] / p[1]. The value at the hit, through RoughnessToAlpha when
+     * MI_ROUGH_REMAP is set, replaces that constant in every microfacet / FresnelBlend lobe of the material. */
+    int32_t rough_tex[2];
+    uint32_t rough_flags;
 } mi_material;
+#define MI_ROUGH_REMAP 1u
 
 /* ImageTexture<RGBSpectrum, Spectrum> with UVMapping2D (src/textures/imagemap.h, src/core/texture.cpp:91-99) over a
  * MIPMap<RGBSpectrum> (src/core/mipmap.h). The pyramid is built on the host exactly as the reference builds it (y flip,

@@ -174,6 +174,13 @@ inline Spec FrConductor(Float cosThetaI, const Spec &etai, const Spec &etat, con
     return 0.5 * (Rp + Rs);
 }
 
+// TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:140-145
+inline Float RoughnessToAlphaF(Float roughness) {
+    roughness = std::max(roughness, (Float)1e-3);
+    Float x = LogF(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+
 struct BxDF {
     const mi_bxdf *b;
     bool texR = false, texS = false;   // the spectrum of this hit comes from an image texture (mi_lobe_tex)
@@ -183,7 +190,10 @@ struct BxDF {
     Spec K() const { return Spec::From(b->K); }
     Spec Scale() const { return Spec::From(b->scale); }
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
-    TRDist Dist() const { return TRDist{b->p[0], b->p[1], b->p[5] != 0.f}; }
+    // roughness from float textures (mi_material.rough_tex): the alphas of this hit in place of b->p[0] / p[1]
+    bool ovU = false, ovV = false;
+    Float alphaU = 0, alphaV = 0;
+    TRDist Dist() const { return TRDist{ovU ? alphaU : b->p[0], ovV ? alphaV : b->p[1], b->p[5] != 0.f}; }
 
     Spec Fresnel(Float cosI) const {
         switch (b->fresnel) {
@@ -457,9 +467,20 @@ struct BSDF {
         ss = Normalize(si.shading.dpdu);
         ts = Cross(ns, ss);
         nBxDFs = 0;
+        // `rough = roughness->Evaluate(*si); if (remapRoughness) rough = RoughnessToAlpha(rough)`, plastic.cpp:57-62 etc.
+        bool ov[2] = {false, false};
+        Float alpha[2] = {0, 0};
+        for (int a = 0; a < 2; ++a)
+            if (d && td && m.rough_tex[a] >= 0) {
+                Float r = (a == 1 && m.rough_tex[1] == m.rough_tex[0]) ? -1.f : EvalFloatImageTexture(*d, m.rough_tex[a], si.uv[0], si.uv[1], *td);
+                if (a == 1 && m.rough_tex[1] == m.rough_tex[0]) alpha[1] = alpha[0];
+                else alpha[a] = (m.rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlphaF(r) : r;
+                ov[a] = true;
+            }
         for (int i = 0; i < m.n_bxdfs; ++i) {
             BxDF bx;
             bx.b = &m.bxdf[i];
+            bx.ovU = ov[0]; bx.ovV = ov[1]; bx.alphaU = alpha[0]; bx.alphaV = alpha[1];
             const mi_lobe_tex &lt = m.tex[i];
             if (m.textured && d && td && (lt.tex_R >= 0 || lt.tex_S >= 0)) {
                 bool texBlack = true;

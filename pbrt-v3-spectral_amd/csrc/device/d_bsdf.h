@@ -327,9 +327,23 @@ DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin, const LobeTe
     return (le.lobe & 0x200) ? bx[le.lobe & 0xff].scale[bin] * v : v;
 }
 
+// Microfacet roughness from float textures ("texture roughness" / "uroughness" / "vroughness": plastic.cpp:57-62,
+// uber.cpp:88-96, substrate.cpp:55-60, ...): the alphas of the material's microfacet lobes at this vertex, in place of the
+// constants in mi_bxdf.p[0..1] (mi_material.rough_tex; every such material gives all its microfacet lobes the same pair).
+struct AlphaOv {
+    float u, v;
+    bool onU, onV;
+};
+// TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:140-145
+DEV float RoughnessToAlpha(float roughness) {
+    roughness = maxf(roughness, 1e-3f);
+    const float x = logF(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
 struct BSDFFrame {
     V3 ns, ng, ss, ts;
     const mi_material *m;
+    AlphaOv ov;      // (read by the texture-evaluating instances only)
     unsigned mask;   // bit i: lobe i of m is part of the BSDF at this vertex (textured lobes drop out where their texture is black)
     DEV bool On(int i) const { return ((mask >> i) & 1u) != 0u; }
     DEV V3 WorldToLocal(const V3 &v) const { return V3(Dot(v, ss), Dot(v, ts), Dot(v, ns)); }
@@ -345,11 +359,15 @@ DEV int NumComponents(const BSDFFrame &fr, int flags) {
     for (int i = 0; i < m->n_bxdfs; ++i) if (fr.On(i) && MatchesFlags(m->bxdf[i], flags)) ++num;
     return num;
 }
-DEV TRDist DistOf(const mi_bxdf &b) { return TRDist{b.p[0], b.p[1], b.p[5] != 0.f}; }
+template <unsigned TM>
+DEV TRDist DistOf(const mi_bxdf &b, const AlphaOv &ov) {
+    if constexpr ((TM & TM_TEXTURED) != 0) return TRDist{ov.onU ? ov.u : b.p[0], ov.onV ? ov.v : b.p[1], b.p[5] != 0.f};
+    return TRDist{b.p[0], b.p[1], b.p[5] != 0.f};
+}
 
 // BxDF::f for lobe i (local wo, wi) -> LobeEval. Mirrors o_bsdf / reflection.cpp per lobe.
 template <unsigned TM>
-DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
+DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const AlphaOv &ov) {
     LobeEval le;
     le.kind = LK_NONE; le.lobe = i | (b.scaled ? 0x200 : 0); le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
     switch (b.type) {
@@ -363,7 +381,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         le.a = (1 - (hi * hi) * (hi * hi) * hi);
         le.b = (1 - (ho * ho) * (ho * ho) * ho);
         le.c = (hc * hc) * (hc * hc) * hc;
-        le.e = DistOf(b).D(wh) / (4 * AbsDot(wi, wh) * maxf(AbsCosTheta(wi), AbsCosTheta(wo)));
+        le.e = DistOf<TM>(b, ov).D(wh) / (4 * AbsDot(wi, wh) * maxf(AbsCosTheta(wi), AbsCosTheta(wo)));
         break;
     } break;
     case MI_BXDF_LAMBERTIAN_REFLECTION:
@@ -390,7 +408,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         if (cosThetaI == 0 || cosThetaO == 0) break;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
-        TRDist d = DistOf(b);
+        TRDist d = DistOf<TM>(b, ov);
         float cosI = Dot(wi, wh);
         le.a = d.D(wh); le.b = d.G(wo, wi);
         const float denom = (4 * cosThetaI * cosThetaO);
@@ -423,7 +441,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
         float F = FrDielectric(Dot(wo, wh), etaA, etaB);
         float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
         float factor = 1 / eta;
-        TRDist d = DistOf(b);
+        TRDist d = DistOf<TM>(b, ov);
         le.kind = LK_MTRANS;
         le.a = F;
         le.b = absf(d.D(wh) * d.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
@@ -480,12 +498,12 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi) {
 }
 
 template <unsigned TM>
-DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
+DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi, const AlphaOv &ov) {
     switch (b.type) {
     case MI_BXDF_FRESNEL_BLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {  // reflection.cpp:470-475
         if (!SameHemisphere(wo, wi)) return 0;
         V3 wh = Normalize(wo + wi);
-        float pdf_wh = DistOf(b).Pdf(wo, wh);
+        float pdf_wh = DistOf<TM>(b, ov).Pdf(wo, wh);
         return .5f * (AbsCosTheta(wi) * kInvPi + pdf_wh / (4 * Dot(wo, wh)));
     } break;
     case MI_BXDF_SPECULAR_REFLECTION: case MI_BXDF_SPECULAR_TRANSMISSION: case MI_BXDF_FRESNEL_SPECULAR: if constexpr (TM_HAS(TM, MI_BXDF_SPECULAR_REFLECTION) || TM_HAS(TM, MI_BXDF_SPECULAR_TRANSMISSION) || TM_HAS(TM, MI_BXDF_FRESNEL_SPECULAR)) { return 0; } break;
@@ -493,7 +511,7 @@ DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
     case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {
         if (!SameHemisphere(wo, wi)) return 0;
         V3 wh = Normalize(wo + wi);
-        return DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
+        return DistOf<TM>(b, ov).Pdf(wo, wh) / (4 * Dot(wo, wh));
     } break;
     case MI_BXDF_MICROFACET_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) {
         if (SameHemisphere(wo, wi)) return 0;
@@ -502,7 +520,7 @@ DEV float LobePdf(const mi_bxdf &b, const V3 &wo, const V3 &wi) {
         V3 wh = Normalize(wo + wi * eta);
         float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
         float dwh_dwi = absf((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
-        return DistOf(b).Pdf(wo, wh) * dwh_dwi;
+        return DistOf<TM>(b, ov).Pdf(wo, wh) * dwh_dwi;
     } break;
     case MI_BXDF_DISNEY_CLEARCOAT: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) {
         if (!SameHemisphere(wo, wi)) return 0;
@@ -540,7 +558,7 @@ DEV void BSDF_f(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, BS
             const mi_bxdf &b = m->bxdf[i];
             if (MatchesFlags(b, flags) &&
                 ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION)))) {
-                LobeEval le = LobeF<TM>(b, i, wo, wi);
+                LobeEval le = LobeF<TM>(b, i, wo, wi, fr.ov);
                 if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
             }
         }
@@ -555,7 +573,7 @@ DEV float BSDF_Pdf(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags)
     float pdf = 0.f;
     int matchingComps = 0;
     for (int i = 0; i < m->n_bxdfs; ++i)
-        if (fr.On(i) && MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf<TM>(m->bxdf[i], wo, wi); }
+        if (fr.On(i) && MatchesFlags(m->bxdf[i], flags)) { ++matchingComps; pdf += LobePdf<TM>(m->bxdf[i], wo, wi, fr.ov); }
     return matchingComps > 0 ? pdf / matchingComps : 0.f;
 }
 
@@ -619,6 +637,7 @@ template <int NL, unsigned TM>
 DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, float u0, float u1, float *pdf, int type,
                        int *sampledType, BSDFEvalT<NL> *ev) {
     const mi_material *m = fr.m;
+    const AlphaOv &ov = fr.ov;
     ev->n = 0;
     int matchingComps = NumComponents(fr, type);
     if (matchingComps == 0) { *pdf = 0; *sampledType = 0; return false; }
@@ -681,31 +700,31 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
             if (wo.z < 0) wi.z *= -1;
         } else {
             const float v0 = minf(2 * (ur0 - .5f), kOneMinusEpsilon);
-            V3 wh = DistOf(b).Sample_wh(wo, v0, ur1);
+            V3 wh = DistOf<TM>(b, ov).Sample_wh(wo, v0, ur1);
             wi = Reflect(wo, wh);
             if (!SameHemisphere(wo, wi)) break;
         }
-        *pdf = LobePdf<TM>(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi, fr.ov);
         break;
     } break;
     case MI_BXDF_LAMBERTIAN_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_LAMBERTIAN_TRANSMISSION)) {
         wi = CosineSampleHemisphere(ur0, ur1);
         if (wo.z > 0) wi.z *= -1;
-        *pdf = LobePdf<TM>(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi, fr.ov);
         break;
     } break;
     case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {
-        V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
+        V3 wh = DistOf<TM>(b, ov).Sample_wh(wo, ur0, ur1);
         wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, wi)) break;
-        *pdf = DistOf(b).Pdf(wo, wh) / (4 * Dot(wo, wh));
+        *pdf = DistOf<TM>(b, ov).Pdf(wo, wh) / (4 * Dot(wo, wh));
         break;
     } break;
     case MI_BXDF_MICROFACET_TRANSMISSION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_TRANSMISSION)) {
-        V3 wh = DistOf(b).Sample_wh(wo, ur0, ur1);
+        V3 wh = DistOf<TM>(b, ov).Sample_wh(wo, ur0, ur1);
         float eta = CosTheta(wo) > 0 ? (b.p[2] / b.p[3]) : (b.p[3] / b.p[2]);
         if (!Refract(wo, wh, eta, &wi)) break;
-        *pdf = LobePdf<TM>(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi, fr.ov);
         break;
     } break;
     case MI_BXDF_DISNEY_CLEARCOAT: if constexpr (TM_HAS(TM, MI_BXDF_DISNEY_CLEARCOAT)) {
@@ -717,13 +736,13 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
         if (!SameHemisphere(wo, wh)) wh = -wh;
         wi = Reflect(wo, wh);
         if (!SameHemisphere(wo, wi)) break;
-        *pdf = LobePdf<TM>(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi, fr.ov);
         break;
     } break;
     default: {
         wi = CosineSampleHemisphere(ur0, ur1);
         if (wo.z < 0) wi.z *= -1;
-        *pdf = LobePdf<TM>(b, wo, wi);
+        *pdf = LobePdf<TM>(b, wo, wi, fr.ov);
         break;
     }
     }
@@ -731,7 +750,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *wiWorld = fr.LocalToWorld(wi);
     if (!isSpecular && matchingComps > 1)
         for (int i = 0; i < m->n_bxdfs; ++i)
-            if (i != bi && fr.On(i) && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi);
+            if (i != bi && fr.On(i) && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi, fr.ov);
     if (matchingComps > 1) *pdf /= matchingComps;
     if (isSpecular) {
         ev->n = 1;
@@ -744,7 +763,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
                 const mi_bxdf &bb = m->bxdf[i];
                 if (MatchesFlags(bb, type) &&
                     ((reflect && (bb.flags & MI_BSDF_REFLECTION)) || (!reflect && (bb.flags & MI_BSDF_TRANSMISSION)))) {
-                    LobeEval le = LobeF<TM>(bb, i, wo, wi);
+                    LobeEval le = LobeF<TM>(bb, i, wo, wi, fr.ov);
                     if ((le.kind & 0xff) != LK_NONE) ev->lobes[ev->n++] = le;
                 }
             }

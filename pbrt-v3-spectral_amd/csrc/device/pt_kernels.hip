@@ -1596,6 +1596,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             BSDFFrame fr;
             fr.m = mat;
             fr.mask = 0xffu;
+            fr.ov.u = fr.ov.v = 0.f; fr.ov.onU = fr.ov.onV = false;
             LobeTexT<NL> lt;
             const LobeTexT<NL> *ltp = nullptr;
             if constexpr ((TM & TM_TEXTURED) != 0) {
@@ -1633,6 +1634,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         td = ComputeDifferentials(isect.p, isect.n, isect.dpdu, tsh.dpdv, cd);
                     }
                     if (mat->bump_tex >= 0) Bump(s, mat->bump_tex, u, v, td, tsh, &isect);   // `if (bumpMap) Bump(bumpMap, si)`
+                    // `rough = roughness->Evaluate(*si); if (remapRoughness) rough = RoughnessToAlpha(rough)` (plastic.cpp:57-62 ...)
+                    if (mat->rough_tex[0] >= 0) {
+                        const float rv = EvalFloatImageTexture(s, mat->rough_tex[0], u, v, td);
+                        fr.ov.u = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;
+                        fr.ov.onU = true;
+                    }
+                    if (mat->rough_tex[1] >= 0) {
+                        if (mat->rough_tex[1] == mat->rough_tex[0]) fr.ov.v = fr.ov.u;
+                        else {
+                            const float rv = EvalFloatImageTexture(s, mat->rough_tex[1], u, v, td);
+                            fr.ov.v = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;
+                        }
+                        fr.ov.onV = true;
+                    }
                     unsigned mask = 0u;
                     for (int i = 0; i < mat->n_bxdfs; ++i) {
                         const mi_lobe_tex ltx = mat->tex[i];

@@ -209,7 +209,7 @@ struct Api {
             compiled = CompileMixMaterial(m1, m2, mp.GetSpectrum("amount", Spectrum(0.5f)), &m, &errs);
         } else
             compiled = CompileMaterial(type, mp, &m, &scene->warnings, &errs);
-        if (compiled && m.bump_tex >= 0) m.textured = 1;   // bump-mapped vertices take the texture-evaluating shading instances
+        if (compiled && (m.bump_tex >= 0 || m.rough_tex[0] >= 0 || m.rough_tex[1] >= 0)) m.textured = 1;   // bump-mapped / roughness-mapped vertices take the texture-evaluating shading instances
         if (!compiled) {
             for (auto &e : errs) Err(e);
             Err("Material \"" + name + "\" replaced by default matte on this path.");

@@ -84,6 +84,31 @@ mi_bxdf MicrofacetTransmission(const Spectrum &T, float ax, float ay, float etaA
     return b;
 }
 
+// A roughness parameter: a constant, or a float image texture evaluated at the hit (mi_material.rough_tex).
+struct RoughSrc {
+    float value = 0.f;
+    int tex = -1;
+    bool given = false;
+};
+RoughSrc Rough(const TextureParams &mp, const std::string &name, float def) {
+    RoughSrc r;
+    r.tex = mp.GetFloatImageTexture(name);
+    if (r.tex >= 0) { r.given = true; return r; }
+    float f;
+    r.given = mp.GetFloatOrNull(name, &f);
+    r.value = r.given ? f : def;
+    return r;
+}
+// the alpha pair of a microfacet lobe from its two roughness sources: constants go into the lobe (through
+// RoughnessToAlpha when the material remaps), textures into the material's rough_tex
+void SetRough(mi_material *m, mi_bxdf *b, const RoughSrc &u, const RoughSrc &v, bool remap) {
+    b->p[0] = u.tex >= 0 ? 0.f : (remap ? RoughnessToAlpha(u.value) : u.value);
+    b->p[1] = v.tex >= 0 ? 0.f : (remap ? RoughnessToAlpha(v.value) : v.value);
+    if (u.tex >= 0) m->rough_tex[0] = u.tex;
+    if (v.tex >= 0) m->rough_tex[1] = v.tex;
+    if ((u.tex >= 0 || v.tex >= 0) && remap) m->rough_flags |= MI_ROUGH_REMAP;
+}
+
 }  // namespace
 
 bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_material *m,
@@ -91,6 +116,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     *m = mi_material{};
     m->eta = 1.f;
     for (int i = 0; i < MI_MAX_BXDFS; ++i) m->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
+    m->rough_tex[0] = m->rough_tex[1] = -1;
     m->bump_tex = mp.GetFloatImageTexture("bumpmap");   // `if (bumpMap) Bump(bumpMap, si)`, first line of every ComputeScatteringFunctions
     if (m->bump_tex >= 0) {
         if (type == "mix" || type == "disney" || type == "metal") { errs->push_back("\"bumpmap\" on a \"" + type + "\" material is outside the hot-path scope"); return false; }
@@ -117,13 +143,14 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(0.25f)), Ks = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
         Spectrum kd = Kd.s.Clamp();
         Spectrum ks = Ks.s.Clamp();
-        float rough = mp.GetFloat("roughness", .1f);
+        const RoughSrc rough = Rough(mp, "roughness", .1f);
         bool remap = mp.FindBool("remaproughness", true);
         if (MayBeNonBlack(Kd, kd)) { Add(m, Lambertian(kd), errs); Bind(m, Kd.tex, Kd.scaled); }
         if (MayBeNonBlack(Ks, ks)) {
-            if (remap) rough = RoughnessToAlpha(rough);
             // FresnelDielectric(1.5f, 1.f): plastic.cpp:59
-            Add(m, MicrofacetReflectionDielectric(ks, rough, rough, 1.5f, 1.f), errs);
+            mi_bxdf b = MicrofacetReflectionDielectric(ks, 0.f, 0.f, 1.5f, 1.f);
+            SetRough(m, &b, rough, rough, remap);
+            Add(m, b, errs);
             Bind(m, Ks.tex, Ks.scaled);
         }
         return true;
@@ -146,14 +173,10 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         for (int i = 0; i < MI_NSPEC; ++i) { copperN.c[i] = kCopperN[i]; copperK.c[i] = kCopperK[i]; }
         Spectrum eta = mp.GetSpectrum("eta", copperN);
         Spectrum k = mp.GetSpectrum("k", copperK);
-        float rough = mp.GetFloat("roughness", .01f);
-        float ur, vr;
-        float uRough = mp.GetFloatOrNull("uroughness", &ur) ? ur : rough;
-        float vRough = mp.GetFloatOrNull("vroughness", &vr) ? vr : rough;
-        if (mp.FindBool("remaproughness", true)) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
+        const RoughSrc rough = Rough(mp, "roughness", .01f), ru = Rough(mp, "uroughness", 0.f), rv = Rough(mp, "vroughness", 0.f);
         mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, Spectrum(1.f));
         b.fresnel = MI_FRESNEL_CONDUCTOR;
-        b.p[0] = uRough; b.p[1] = vRough;
+        SetRough(m, &b, ru.given ? ru : rough, rv.given ? rv : rough, mp.FindBool("remaproughness", true));   // metal.cpp:66-73
         SetS(b, eta);
         for (int i = 0; i < MI_NSPEC; ++i) b.K[i] = k.c[i];
         Add(m, b, errs);
@@ -164,13 +187,11 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(.5f)), Ks = mp.GetSpectrumParam("Ks", Spectrum(.5f));
         Spectrum d = Kd.s.Clamp();
         Spectrum s = Ks.s.Clamp();
-        float roughu = mp.GetFloat("uroughness", .1f);
-        float roughv = mp.GetFloat("vroughness", .1f);
+        const RoughSrc roughu = Rough(mp, "uroughness", .1f), roughv = Rough(mp, "vroughness", .1f);
         if (MayBeNonBlack(Kd, d) || MayBeNonBlack(Ks, s)) {
-            if (mp.FindBool("remaproughness", true)) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
             mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_BLEND, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, d);
             SetS(b, s);
-            b.p[0] = roughu; b.p[1] = roughv;
+            SetRough(m, &b, roughu, roughv, mp.FindBool("remaproughness", true));
             Add(m, b, errs);
             Bind(m, Kd.tex, Kd.scaled, Ks.tex, Ks.scaled, MI_LOBE_IF_R_OR_S);
         }
@@ -196,10 +217,18 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         const SpectrumParam Ks = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
         Spectrum ks = Ks.s.Clamp();
         if (MayBeNonBlack(Ks, ks) && (!r.IsBlack() || !t.IsBlack())) {
-            float rough = mp.GetFloat("roughness", .1f);
-            if (mp.FindBool("remaproughness", true)) rough = RoughnessToAlpha(rough);
-            if (!r.IsBlack()) { Add(m, MicrofacetReflectionDielectric(r * ks, rough, rough, 1.f, eta), errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX); }
-            if (!t.IsBlack()) { Add(m, MicrofacetTransmission(t * ks, rough, rough, 1.f, eta, false), errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX); }
+            const RoughSrc rough = Rough(mp, "roughness", .1f);
+            const bool remap = mp.FindBool("remaproughness", true);
+            if (!r.IsBlack()) {
+                mi_bxdf b = MicrofacetReflectionDielectric(r * ks, 0.f, 0.f, 1.f, eta);
+                SetRough(m, &b, rough, rough, remap);
+                Add(m, b, errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX);
+            }
+            if (!t.IsBlack()) {
+                mi_bxdf b = MicrofacetTransmission(t * ks, 0.f, 0.f, 1.f, eta, false);
+                SetRough(m, &b, rough, rough, remap);
+                Add(m, b, errs); Bind(m, Ks.tex, true, -1, false, MI_LOBE_IF_TEX);
+            }
         }
         return true;
     }
@@ -241,10 +270,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         const SpectrumParam pKd = mp.GetSpectrumParam("Kd", Spectrum(0.25f)), pKs = mp.GetSpectrumParam("Ks", Spectrum(0.25f));
         const SpectrumParam pKr = mp.GetSpectrumParam("Kr", Spectrum(0.f)), pKt = mp.GetSpectrumParam("Kt", Spectrum(0.f));
         const Spectrum Kd = pKd.s, Ks = pKs.s, Kr = pKr.s, Kt = pKt.s;   // (textured: 1, so that op * K below leaves op as the lobe's constant)
-        float roughness = mp.GetFloat("roughness", .1f);
-        float ur, vr;
-        bool hasU = mp.GetFloatOrNull("uroughness", &ur);
-        bool hasV = mp.GetFloatOrNull("vroughness", &vr);
+        const RoughSrc roughness = Rough(mp, "roughness", .1f), ru = Rough(mp, "uroughness", 0.f), rv = Rough(mp, "vroughness", 0.f);
         float e;
         if (!mp.GetFloatOrNull("eta", &e)) e = mp.GetFloat("index", 1.5f);
         Spectrum opacity = mp.GetSpectrum("opacity", Spectrum(1.f));
@@ -261,10 +287,11 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         if (!kd.IsBlack()) { Add(m, Lambertian(kd), errs); Bind(m, pKd.tex, true); }
         Spectrum ks = op * Ks.Clamp();
         if (!ks.IsBlack()) {
-            float roughu = hasU ? ur : roughness;
-            float roughv = hasV ? vr : roughu;
-            if (remap) { roughu = RoughnessToAlpha(roughu); roughv = RoughnessToAlpha(roughv); }
-            Add(m, MicrofacetReflectionDielectric(ks, roughu, roughv, 1.f, e), errs);
+            const RoughSrc roughu = ru.given ? ru : roughness;   // uber.cpp:88-96
+            const RoughSrc roughv = rv.given ? rv : roughu;
+            mi_bxdf b = MicrofacetReflectionDielectric(ks, 0.f, 0.f, 1.f, e);
+            SetRough(m, &b, roughu, roughv, remap);
+            Add(m, b, errs);
             Bind(m, pKs.tex, true);
         }
         Spectrum kr = op * Kr.Clamp();
@@ -364,6 +391,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
     *out = mi_material{};
     for (int i = 0; i < MI_MAX_BXDFS; ++i) out->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     out->bump_tex = -1;
+    out->rough_tex[0] = out->rough_tex[1] = -1;
     out->kind = 9;
     out->eta = m1.eta;
     const Spectrum s1 = amount.Clamp();

@@ -148,7 +148,7 @@ struct TextureParams {
         if (it != tex.floatTex.end()) { *out = it->second; return true; }
         if (tex.floatImageTex.count(name)) {
             if (errors) errors->push_back("Float image texture \"" + name + "\" on parameter \"" + n + "\": this path evaluates float image "
-                                          "textures as \"alpha\" / \"shadowalpha\" masks of triangle meshes only");
+                                          "textures as \"alpha\" / \"shadowalpha\" masks, bump maps and the roughness of plastic / uber / substrate / metal / translucent only");
             return false;
         }
         if (errors) errors->push_back("Couldn't find float texture named \"" + name + "\" for parameter \"" + n + "\"");

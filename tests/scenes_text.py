@@ -261,6 +261,11 @@ def write_texture_files(base_dir):
     with open(os.path.join(base_dir, "tex_c.pfm"), "wb") as f:
         f.write(b"PF\n%d %d\n-1.0\n" % (c.shape[1], c.shape[0]))
         f.write(c[::-1].astype(np.float32).tobytes())
+    # a roughness map: strictly positive everywhere (a zero, used unremapped as an alpha, is a NaN in the reference too)
+    r = 0.04 + 0.5 * (_texture_image(20, 12, 4).astype(np.float32) / 255.0)
+    with open(os.path.join(base_dir, "rough.pfm"), "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (r.shape[1], r.shape[0]))
+        f.write(r[::-1].astype(np.float32).tobytes())
     return a, b, c
 
 
@@ -481,6 +486,67 @@ def bump_scene(res=64, spp=16, depth=4):
     """Material::Bump (material.cpp:47-84) with float image textures: a flat quad without normals, a curved patch with
     vertex normals, a mirrored patch with a textured Kd as well. Uses the files of write_texture_files()."""
     return BUMP_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch())
+
+
+ROUGHNESS_SCENE = """
+LookAt 0 2.4 -7  0 0.8 0  0 1 0
+Camera "perspective" "float fov" [40] %(lens)s
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [18 17 15]
+  Translate 0 5 -1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 0 -1.5  1.5 0 -1.5  1.5 0 1.5  -1.5 0 1.5]
+AttributeEnd
+LightSource "point" "rgb I" [10 10 12] "point from" [-3 3 -5]
+# roughness maps: values in (0, 1), as files (gamma off: they are data), scaled into a useful range
+Texture "r_raw" "float" "imagemap" "string filename" "tex_a.png" "bool gamma" ["false"] "float uscale" [2] "float vscale" [2]
+Texture "r_soft" "float" "scale" "texture tex1" "r_raw" "float tex2" [.5]
+Texture "r_tga" "float" "imagemap" "string filename" "rough.pfm" "bool trilinear" ["true"] "float scale" [.6]
+Texture "r_pfm" "float" "imagemap" "string filename" "tex_c.pfm" "float scale" [.3] "float uscale" [3] "float vscale" [3]
+Texture "colour" "spectrum" "imagemap" "string filename" "tex_c.pfm"
+# plastic: "texture roughness", remapped (the default)
+AttributeBegin
+  Material "plastic" "rgb Kd" [.3 .1 .1] "rgb Ks" [.6 .6 .6] "texture roughness" "r_soft"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# uber: u from a texture, v constant, not remapped; textured Kd as well
+AttributeBegin
+  Material "uber" "texture Kd" "colour" "rgb Ks" [.5 .5 .5] "rgb Kr" [.05 .05 .05] "texture uroughness" "r_tga" "float vroughness" [.05] "bool remaproughness" ["false"]
+  Translate -2 1 0
+  %(patch)s
+AttributeEnd
+# substrate: both axes textured (different maps)
+AttributeBegin
+  Material "substrate" "rgb Kd" [.1 .3 .5] "rgb Ks" [.3 .3 .3] "texture uroughness" "r_tga" "texture vroughness" "r_pfm"
+  Translate 0 1 .5
+  %(patch)s
+AttributeEnd
+# metal: "texture roughness" on a sphere
+AttributeBegin
+  Material "metal" "texture roughness" "r_pfm"
+  Translate 2.1 .8 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+# translucent: both microfacet lobes take the map
+AttributeBegin
+  Material "translucent" "rgb Kd" [.3 .3 .3] "rgb Ks" [.5 .5 .5] "texture roughness" "r_soft"
+  Translate -.5 1.2 -2
+  Rotate 30 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-.8 -.8 0  .8 -.8 0  .8 .8 0  -.8 .8 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+WorldEnd
+"""
+
+
+def roughness_scene(res=64, spp=16, depth=4, lens=False):
+    """Float image textures on "roughness" / "uroughness" / "vroughness" of plastic, uber, substrate, metal and translucent
+    (plastic.cpp:57-62, uber.cpp:88-96, substrate.cpp:55-60, metal.cpp:66-73, translucent.cpp:70-72): remapped and not,
+    one axis or both, "scale"d, trilinear and EWA. Needs write_texture_files()."""
+    return ROUGHNESS_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                  lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
 
 
 INSTANCED_SCENE = """

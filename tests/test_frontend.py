@@ -527,7 +527,8 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
     head = 'Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "a.png"\n'
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
     cases = {
-        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "plastic" "texture roughness" "f"\n' + tri: "Float image texture",
+        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "glass" "texture uroughness" "f"\n' + tri: "Float image texture",
+        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "matte" "texture sigma" "f"\n' + tri: "Float image texture",
         'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
         'Material "disney" "texture color" "t"\n' + tri: "Image texture",
         'Material "glass" "texture Kr" "t" "float uroughness" [.1] "float vroughness" [.1]\n' + tri: "rough",

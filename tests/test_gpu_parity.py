@@ -486,6 +486,29 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
         assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
 
 
+def test_roughness_textures_against_oracle(pt, ob, tmp_path):
+    """Float image textures on the roughness parameters (plastic.cpp:57-62, uber.cpp:88-96, substrate.cpp:55-60,
+    metal.cpp:66-73, translucent.cpp:70-72): the value at the hit, through RoughnessToAlpha unless "remaproughness" is off,
+    is the alpha of the material's microfacet lobes -- one axis or both, with the camera ray's differentials in the lookup."""
+    st.write_texture_files(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.roughness_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == []
+        mats = [s.desc.materials[i] for i in range(s.desc.n_materials)]
+        assert sum(1 for m in mats if m.rough_tex[0] >= 0 or m.rough_tex[1] >= 0) == 5
+        assert any(m.rough_tex[0] >= 0 and m.rough_tex[1] < 0 and not (m.rough_flags & 1) for m in mats)   # uber: u only, not remapped
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "roughness textures lens=%s" % lens)
+    # the maps matter: with constant roughness in their place the picture differs visibly
+    flat = st.roughness_scene(lens=True)
+    for name in ("r_soft", "r_tga", "r_pfm"):
+        flat = flat.replace('"texture roughness" "%s"' % name, '"float roughness" [.1]').replace('"texture uroughness" "%s"' % name, '"float uroughness" [.1]') \
+                   .replace('"texture vroughness" "%s"' % name, '"float vroughness" [.1]')
+    fs = pt.Scene(text=flat, base_dir=str(tmp_path))
+    assert fs.errors == [] and all(fs.desc.materials[i].rough_tex[0] < 0 for i in range(fs.desc.n_materials))
+    ff, _, _, _ = ob.render(fs)
+    assert _rel_l2(ff, ofilm) > 0.02
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with

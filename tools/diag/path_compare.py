@@ -29,7 +29,8 @@ for (x, y, k) in list(bad):
     if shown >= nshow: break
     d = integ.debug_path(x, y, k)
     o = ob.path_log(s, x, y, k)
-    if walk_all and len(d) == len(o) and np.array_equal(d[:, :20].view(np.uint32), o[:, :20].view(np.uint32)): continue
+    if walk_all and len(d) == len(o) and np.array_equal(d[:, :20].view(np.uint32), o[:, :20].view(np.uint32)) \
+            and np.allclose(d[:, 51:82], o[:, 51:82], rtol=1e-4, atol=1e-7, equal_nan=True) and not (np.isinf(d[:, 51:82]).any() or np.isnan(d[:, 51:82]).any() or (d[:, 51:82] < 0).any()): continue
     shown += 1
     print("pixel (%d,%d) k=%d: device %d vertices, oracle %d" % (x, y, k, len(d), len(o)))
     for v in range(min(len(d), len(o))):

@@ -19,6 +19,10 @@ def mk(name, depth, spp):
         _, seed, res = name.split(":")
         st.write_texture_files(tmp); st.write_alpha_png(tmp)
         return pt.Scene(text=st.random_scene(int(seed), res=int(res), spp=spp), base_dir=tmp, max_depth=depth)
+    if name in ("rough", "rough_lens", "inst", "inst_lens"):   # tests/scenes_text.py roughness_scene / instanced_scene
+        st.write_texture_files(tmp); st.write_alpha_png(tmp)
+        gen = st.roughness_scene if name.startswith("rough") else st.instanced_scene
+        return pt.Scene(text=gen(spp=spp, lens=name.endswith("_lens")), base_dir=tmp, max_depth=depth)
     if name.startswith("zoo_"):
         return pt.Scene(text=st.material_zoo(res=96, spp=spp, depth=6, strategy=name[4:]), max_depth=depth)
     if name == "cornell128":
