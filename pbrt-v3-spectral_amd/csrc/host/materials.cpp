@@ -401,11 +401,18 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
     for (int k = 0; k < 2; ++k)
         for (int i = 0; i < src[k]->n_bxdfs; ++i) {
             mi_bxdf b = src[k]->bxdf[i];
-            if (src[k]->textured || src[k]->bump_tex >= 0) { errs->push_back("a \"mix\" of image-textured materials is outside the hot-path scope"); return false; }
+            // (each sub-material runs its own ComputeScatteringFunctions, mixmat.cpp:52-56: its textured lobes keep their
+            // bindings and presence rules; a bump or roughness map would act on one sub-material's copy of the interaction)
+            if (src[k]->bump_tex >= 0 || src[k]->rough_tex[0] >= 0 || src[k]->rough_tex[1] >= 0) {
+                errs->push_back("a \"mix\" of bump-mapped or roughness-mapped materials is outside the hot-path scope");
+                return false;
+            }
             if (b.scaled) { errs->push_back("a \"mix\" of \"mix\" materials (nested ScaledBxDF) is not built on this path"); return false; }
             b.scaled = 1;
             for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j];
             if (!Add(out, b, errs)) return false;
+            out->tex[out->n_bxdfs - 1] = src[k]->tex[i];
+            if (src[k]->tex[i].tex_R >= 0 || src[k]->tex[i].tex_S >= 0) out->textured = 1;
         }
     return true;
 }

@@ -530,6 +530,14 @@ AttributeBegin
   Translate 2.1 .8 0
   Shape "sphere" "float radius" [.8]
 AttributeEnd
+# a "mix" of image-textured materials (mixmat.cpp:46-64): each lobe keeps its texture and its presence rule under ScaledBxDF
+MakeNamedMaterial "mixTexA" "string type" "matte" "texture Kd" "colour"
+MakeNamedMaterial "mixTexB" "string type" "plastic" "rgb Kd" [.1 .1 .1] "texture Ks" "colour" "float roughness" [.1]
+AttributeBegin
+  Material "mix" "string namedmaterial1" "mixTexA" "string namedmaterial2" "mixTexB" "rgb amount" [.6 .4 .3]
+  Translate 1 .5 -2.2
+  Shape "sphere" "float radius" [.5]
+AttributeEnd
 # translucent: both microfacet lobes take the map
 AttributeBegin
   Material "translucent" "rgb Kd" [.3 .3 .3] "rgb Ks" [.5 .5 .5] "texture roughness" "r_soft"

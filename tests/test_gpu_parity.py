@@ -497,6 +497,7 @@ def test_roughness_textures_against_oracle(pt, ob, tmp_path):
         mats = [s.desc.materials[i] for i in range(s.desc.n_materials)]
         assert sum(1 for m in mats if m.rough_tex[0] >= 0 or m.rough_tex[1] >= 0) == 5
         assert any(m.rough_tex[0] >= 0 and m.rough_tex[1] < 0 and not (m.rough_flags & 1) for m in mats)   # uber: u only, not remapped
+        assert any(m.kind == 9 and m.textured and m.n_bxdfs == 3 and m.tex[0].tex_R >= 0 and m.tex[2].tex_R >= 0 for m in mats)   # the textured mix
         film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "roughness textures lens=%s" % lens)
     # the maps matter: with constant roughness in their place the picture differs visibly
     flat = st.roughness_scene(lens=True)
