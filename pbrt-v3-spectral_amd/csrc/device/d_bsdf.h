@@ -269,6 +269,13 @@ constexpr unsigned TM_LIGHTS_ALL = 0x1fu << 24;
 constexpr unsigned TM_LIGHTS_NO_ENV = TM_LIGHTS_ALL & ~(1u << (24 + MI_LIGHT_INFINITE));
 constexpr unsigned TM_DIFFUSE = (1u << MI_BXDF_LAMBERTIAN_REFLECTION) | (1u << MI_BXDF_OREN_NAYAR) | (1u << (16 + MI_FRESNEL_NOOP));
 constexpr unsigned TM_PLASTIC = TM_DIFFUSE | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << (16 + MI_FRESNEL_DIELECTRIC));
+// the lobes "uber" makes (uber.cpp:60-105; "translucent"'s fit as well) and the ones "disney" makes (disney.cpp:474-587)
+constexpr unsigned TM_UBER = TM_PLASTIC | (1u << MI_BXDF_SPECULAR_REFLECTION) | (1u << MI_BXDF_SPECULAR_TRANSMISSION) |
+                             (1u << MI_BXDF_MICROFACET_TRANSMISSION) | (1u << MI_BXDF_LAMBERTIAN_TRANSMISSION);
+constexpr unsigned TM_DISNEY = (1u << MI_BXDF_DISNEY_DIFFUSE) | (1u << MI_BXDF_DISNEY_FAKE_SS) | (1u << MI_BXDF_DISNEY_RETRO) | (1u << MI_BXDF_DISNEY_SHEEN) |
+                               (1u << MI_BXDF_DISNEY_CLEARCOAT) | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << MI_BXDF_MICROFACET_TRANSMISSION) |
+                               (1u << MI_BXDF_LAMBERTIAN_TRANSMISSION) | (1u << MI_BXDF_SPECULAR_TRANSMISSION) | (1u << MI_BXDF_LAMBERTIAN_REFLECTION) |
+                               (1u << (16 + MI_FRESNEL_DISNEY)) | (1u << (16 + MI_FRESNEL_DIELECTRIC)) | (1u << (16 + MI_FRESNEL_NOOP));
 
 template <unsigned TM>
 DEV float LobeValueCore(const LobeEval &le, float R, float Sv, float Kv) {  // R: the lobe's spectrum at the bin (S when bit 8 of le.lobe is set)

@@ -24,7 +24,7 @@ namespace dpt {
 #define PRIM_FLAG_DEGENERATE 2u
 #define PRIM_FLAG_INSTANCE 64u   // a TransformedPrimitive: primTri[3 * prim + 1].w holds the instance number (mi_prim.instance - 1)
 #define PRIM_FLAG_ALPHA 32u   // the triangle's mesh has an "alpha" / "shadowalpha" mask (mi_mesh.alpha_tex)
-#define PRIM_CLASS_SHIFT 2      /* bits 2-4: shading class of the primitive's material (7 = no BSDF) */
+#define PRIM_CLASS_SHIFT 8      /* bits 8-11: shading class of the primitive's material (15 = no BSDF) */
 
 struct DScene {
     const float4 *nodes;

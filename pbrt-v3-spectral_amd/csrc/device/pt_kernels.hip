@@ -111,10 +111,10 @@ enum : int {
 };
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
-// first appearance, the 7th and later share class 6); class 7 holds the vertices without a
+// first appearance, the 15th and later share class 14); class 15 holds the vertices without a
 // BSDF (escaped rays, interface primitives). A wave of k_shade works on one class only.
-constexpr int MAX_CLASSES = 8;
-constexpr int MISS_CLASS = 7;
+constexpr int MAX_CLASSES = 16;
+constexpr int MISS_CLASS = 15;
 
 struct Pool {
     float *f;
@@ -899,7 +899,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
     // append to the class queues: one atomic per class and block
     __shared__ unsigned sCnt[SLOT_CHUNKS][BLOCK / 64][MAX_CLASSES], sBase[MAX_CLASSES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned clsOf = 0, rankLo = 0, rankHi = 0;   // per chunk: 4 bits of (traced, class), 8 bits of rank within the wave and class
+    unsigned long long clsOf = 0;                 // per chunk: 8 bits of (traced, class)
+    unsigned rankLo = 0, rankHi = 0;              // per chunk: 8 bits of rank within the wave and class
     unsigned nodes = 0, tris = 0;
 #pragma unroll 1
     for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
@@ -921,7 +922,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
                 pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
                 if (INST) pool.I(I_HITINST, slot) = h.inst;
             }
-            cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & 7u) : MISS_CLASS;
+            cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & (unsigned)(MAX_CLASSES - 1)) : MISS_CLASS;
         }
         unsigned rank = 0;
         for (int c = 0; c < MAX_CLASSES; ++c) {
@@ -930,7 +931,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
             if (lane == 0) sCnt[ch][wave][c] = (unsigned)__popcll(m);
             if (cls == c) rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
         }
-        clsOf |= (unsigned)((traced ? 8 : 0) | cls) << (4 * ch);
+        clsOf |= (unsigned long long)((traced ? 0x80 : 0) | cls) << (8 * ch);
         if (ch < 4) rankLo |= rank << (8 * ch); else rankHi |= rank << (8 * (ch - 4));
     }
     __syncthreads();
@@ -944,9 +945,9 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
-        const unsigned cc = (clsOf >> (4 * ch)) & 15u;
-        if (!(cc & 8u)) continue;
-        const int cls = (int)(cc & 7u);
+        const unsigned cc = (unsigned)(clsOf >> (8 * ch)) & 255u;
+        if (!(cc & 0x80u)) continue;
+        const int cls = (int)(cc & 0x7fu);
         const unsigned rank = ((ch < 4 ? rankLo >> (8 * ch) : rankHi >> (8 * (ch - 4))) & 255u);
         const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
         pool.shadeQ[(size_t)cls * pool.n + sBase[cls] + sCnt[ch][wave][cls] + rank] = slot;
@@ -2021,6 +2022,7 @@ struct mi_pt {
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
+    unsigned uberClasses = 0, disneyClasses = 0;                 // untextured uber-like (<= 4 lobes) and Disney lobe sets: instances of their own
     unsigned mediumClasses = 0, texturedMedium = 0;              // 3- and 4-lobe classes (uber with Kr / Kt, translucent): 4-lobe instances
     unsigned texturedSmall = 0, texturedLarge = 0;               // classes of image-textured materials (taken out of small / largeClasses)              // subsets of smallClasses run by the lobe-specialised kernels
     int numCUs = 256;
@@ -2385,6 +2387,12 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 if ((pt->largeClasses >> c) & 1u) { pt->texturedLarge |= 1u << c; pt->largeClasses &= ~(1u << c); }
             }
         if (!getenv("MIPT_NO_SPECIALISE"))
+            for (int c = 0; c < MISS_CLASS; ++c) {   // the lobe sets of "uber" and "disney": instances without the rest of the BxDF code
+                if (!((pt->largeClasses >> c) & 1u)) continue;
+                if (classLobes[c] <= 4 && (classTypes[c] & ~TM_UBER) == 0) { pt->uberClasses |= 1u << c; pt->largeClasses &= ~(1u << c); }
+                else if ((classTypes[c] & ~TM_DISNEY) == 0) { pt->disneyClasses |= 1u << c; pt->largeClasses &= ~(1u << c); }
+            }
+        if (!getenv("MIPT_NO_SPECIALISE"))
             for (int c = 0; c < MISS_CLASS; ++c)
                 if (classLobes[c] <= 4) {
                     if ((pt->largeClasses >> c) & 1u) { pt->mediumClasses |= 1u << c; pt->largeClasses &= ~(1u << c); }
@@ -2668,7 +2676,7 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_TEXTURED;
     if (pt->hasInstances) {   // scenes with object instances: the two fully general instances of the kernel, by lobe count
         const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
-        const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge;
+        const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge | pt->uberClasses | pt->disneyClasses;
         if (two) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, two);
         if (more) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, more);
         return;
@@ -2685,6 +2693,8 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
 #undef SHADE_LAUNCH_HOT
 #undef SHADE_LAUNCH
     if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+    if (pt->uberClasses) hipLaunchKernelGGL((k_shade<4, TM_UBER | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->uberClasses);
+    if (pt->disneyClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_DISNEY | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->disneyClasses);
     if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
     if (pt->texturedMedium) hipLaunchKernelGGL((k_shade<4, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedMedium);
     if (pt->largeClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->largeClasses);
