@@ -125,6 +125,7 @@ struct Pool {
     uint32_t *extQ;            // this iteration's path rays: new camera rays from the front (coherent: consecutive
                                // samples of a pixel), continuing paths from the back
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
+    uint32_t *ovfQ;            // rays whose list of postponed quadrics overflowed: 3 queues of n entries (extend / shadow / MIS)
     uint32_t n;
     DEV float &F(int plane, uint32_t slot) const { return f[(size_t)plane * n + slot]; }
     // a slot's 8 quads of one spectrum are one 128-B line: [spectrum][slot][quad] ([slot][spectrum][quad], the
@@ -158,8 +159,9 @@ struct DevCounters {
     DevCursor primCount, contCount;     // entries at the front / back of Pool::extQ
     DevCursor shadeCount[MAX_CLASSES];  // entries in shading queue c
     DevCursor travNext[3];              // work cursors of the persistent traversal kernels (extend/shadow/mis)
+    DevCursor ovfCount[3];              // entries in Pool::ovfQ (extend/shadow/mis)
 };
-constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (5 + MAX_CLASSES + 3);
+constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (5 + MAX_CLASSES + 3 + 3);
 DEV DevStats &Stats(DevCounters *ctr) { return ctr->stats[blockIdx.x & (STAT_STRIPES - 1)]; }
 
 struct WorkDesc {
@@ -851,11 +853,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 // accepted before it); a triangle hit that the traversal found AFTER the last accepted quadric survives only if it is
 // closer than that quadric. (Shadow rays: tMax never changes, the order does not matter.) On overflow the ray is
 // re-traversed by the reference-order routine with inline quadric tests.
-template <bool ANY, bool INST>
+// OVF: the instance of k_resolve_overflow. The resolve kernels proper are compiled without the re-traversal (it cost
+// them 40-56 VGPRs and all but 650 of 12 000 instructions): they hand a ray whose list overflowed to that kernel.
+template <bool ANY, bool INST, bool OVF = false>
 DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
                          Hit *h, bool foundTri, unsigned &nodes, unsigned &tris) {
     const int np = pool.I(I_NPEND, slot);
-    if (np & PEND_OVERFLOW) {
+    if constexpr (OVF) {
         Hit h2;
         h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
         unsigned n2 = 0, t2 = 0;  // statistics were already counted by k_trav
@@ -910,7 +914,11 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
         if (slot < pool.n && (pool.I(I_FLAGS, slot) & F_ALIVE)) {
             traced = true;
             int prim = pool.I(I_HITPRIM, slot);
-            if (pool.I(I_NPEND, slot) != 0) {
+            const int npend = pool.I(I_NPEND, slot);
+            if (npend & PEND_OVERFLOW) {   // k_resolve_overflow commits this one
+                pool.ovfQ[atomicAdd(&ctr->ovfCount[0].v, 1u)] = slot;
+                traced = false;
+            } else if (npend != 0) {
                 const float4 r0 = pool.R(R_RAY0, slot), r1 = pool.R(R_RAY1, slot), hr = pool.R(R_HIT, slot);
                 V3 ro(r0.x, r0.y, r0.z), rd(r1.x, r1.y, r1.z);
                 Hit h;
@@ -965,13 +973,17 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
         const uint32_t slot = pool.shadowQ[qi];
         int flags = pool.I(I_FLAGS, slot);
         bool occluded = pool.I(I_HITPRIM, slot) >= 0;
-        if (!occluded && pool.I(I_NPEND, slot) != 0) {
-            const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
-            V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
-            Hit h;
-            occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
+        const int npend = occluded ? 0 : pool.I(I_NPEND, slot);
+        if (npend & PEND_OVERFLOW) pool.ovfQ[(size_t)pool.n + atomicAdd(&ctr->ovfCount[1].v, 1u)] = slot;   // k_resolve_overflow commits this one
+        else {
+            if (npend != 0) {
+                const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
+                V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+                Hit h;
+                occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
+            }
+            myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
         }
-        myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
     }
     // L += contribution, eight lanes per path: lane (8j + c) of pass `it` adds quad c of entry 8*it + j, so every
     // load and store of the wave is eight whole 128-B lines
@@ -1008,68 +1020,124 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
 }
 
 
+// One MIS ray's commit. OVF = false (k_resolve_mis): a ray whose quadric list overflowed goes to k_resolve_overflow, which
+// runs this again with OVF = true.
+template <bool INST, bool OVF>
+DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, unsigned &zero) {
+    unsigned nodes = 0, tris = 0;
+    int flags = pool.I(I_FLAGS, slot);
+    // the ray and the hit record are fetched only by the few rays that need them: postponed quadrics, or a hit on the
+    // sampled light whose facing has to be tested (most MIS rays hit something else: 48 B of scattered reads saved)
+    V3 ro, rd;
+    Hit h;
+    h.prim = pool.I(I_HITPRIM, slot); h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
+    bool haveRay = false;
+    auto loadRay = [&]() {
+        if (haveRay) return;
+        const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
+        ro = V3(r0.x, r0.y, r0.z); rd = V3(r0.w, r1.x, r1.y);
+        if (h.prim >= 0) { h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w; }
+        haveRay = true;
+    };
+    bool found = h.prim >= 0;
+    const int npend = pool.I(I_NPEND, slot);
+    if (!OVF && (npend & PEND_OVERFLOW)) { pool.ovfQ[2 * (size_t)pool.n + atomicAdd(&ctr->ovfCount[2].v, 1u)] = slot; return; }
+    if (npend != 0) { loadRay(); found = ResolveQuadrics<false, INST, OVF>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
+    bool added = false;
+    if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
+        const bool lZero = (flags & F_L_ZERO) != 0;
+        for (int c = 0; c < NQ; ++c) {
+            const float4 a = pool.Q(Q_LMIS + c, slot);
+            added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+            float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!lZero) l = pool.Q(Q_L + c, slot);
+            l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+            pool.Q(Q_L + c, slot) = l;
+        }
+        flags &= ~F_L_ZERO;
+    }
+    if (found) {
+        const int lightNum = pool.I(I_MISLIGHT, slot);
+        if (s.prims[h.prim].area_light == lightNum) {
+            const mi_light &l = s.lights[lightNum];
+            bool emit = l.two_sided != 0;
+            if (!emit) {
+                loadRay();
+                SurfaceInteraction li;
+                HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
+                emit = Dot(li.n, -rd) > 0;
+            }
+            if (emit) {
+                const bool lZero = (flags & F_L_ZERO) != 0;
+                for (int c = 0; c < NQ; ++c) {
+                    const float4 a = pool.Q(Q_LMIS + c, slot);
+                    added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+                    float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!lZero) l = pool.Q(Q_L + c, slot);
+                    l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+                    pool.Q(Q_L + c, slot) = l;
+                }
+                flags &= ~F_L_ZERO;
+            }
+        }
+    }
+    if (!added && !(flags & F_A_ADDED)) ++zero;
+    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
+}
 template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned zero = 0;
+    if (qi < ctr->misCount.v) ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], zero);
+    CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
+}
+
+// The rays whose list of postponed quadrics overflowed (more than MAX_PEND quadrics met: PEND_OVERFLOW), handed over by
+// the three resolve kernels: re-traversed by the reference-order routine with inline quadric tests, then committed as the
+// resolve kernel would have (mode 0: hit record + shading queue; 1: occlusion + L += the light sample; 2: the MIS commit).
+// A fixed small grid walks the queue; it is empty for all but quadric-heavy scenes.
+constexpr int OVERFLOW_GRID = 512;
+template <bool INST>
+__global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool, DevCounters *ctr, int mode) {
+    const unsigned count = ctr->ovfCount[mode].v;
     unsigned zero = 0, nodes = 0, tris = 0;
-    if (qi < ctr->misCount.v) {
-        const uint32_t slot = pool.misQ[qi];
-        int flags = pool.I(I_FLAGS, slot);
-        // the ray and the hit record are fetched only by the few rays that need them: postponed quadrics, or a hit on the
-        // sampled light whose facing has to be tested (most MIS rays hit something else: 48 B of scattered reads saved)
-        V3 ro, rd;
-        Hit h;
-        h.prim = pool.I(I_HITPRIM, slot); h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
-        bool haveRay = false;
-        auto loadRay = [&]() {
-            if (haveRay) return;
-            const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot), hr = pool.R(R_HIT, slot);
-            ro = V3(r0.x, r0.y, r0.z); rd = V3(r0.w, r1.x, r1.y);
-            if (h.prim >= 0) { h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w; }
-            haveRay = true;
-        };
-        bool found = h.prim >= 0;
-        if (pool.I(I_NPEND, slot) != 0) { loadRay(); found = ResolveQuadrics<false, INST>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
-        bool added = false;
-        if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
-            const bool lZero = (flags & F_L_ZERO) != 0;
-            for (int c = 0; c < NQ; ++c) {
-                const float4 a = pool.Q(Q_LMIS + c, slot);
-                added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!lZero) l = pool.Q(Q_L + c, slot);
-                l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-                pool.Q(Q_L + c, slot) = l;
-            }
-            flags &= ~F_L_ZERO;
-        }
-        if (found) {
-            const int lightNum = pool.I(I_MISLIGHT, slot);
-            if (s.prims[h.prim].area_light == lightNum) {
-                const mi_light &l = s.lights[lightNum];
-                bool emit = l.two_sided != 0;
-                if (!emit) {
-                    loadRay();
-                    SurfaceInteraction li;
-                    HitInteraction(s, h.prim, ro, rd, h.b0, h.b1, h.b2, &li);
-                    emit = Dot(li.n, -rd) > 0;
+    for (unsigned qi = blockIdx.x * BLOCK + threadIdx.x; qi < count; qi += gridDim.x * BLOCK) {
+        const uint32_t slot = pool.ovfQ[(size_t)mode * pool.n + qi];
+        if (mode == 0) {
+            const float4 r0 = pool.R(R_RAY0, slot), r1 = pool.R(R_RAY1, slot);
+            Hit h;
+            h.prim = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
+            const bool found = ResolveQuadrics<false, INST, true>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, &h, false, nodes, tris);
+            const int prim = found ? h.prim : -1;
+            pool.I(I_HITPRIM, slot) = prim;
+            pool.R(R_HIT, slot) = make_float4(h.t, h.b0, h.b1, h.b2);
+            if (INST) pool.I(I_HITINST, slot) = h.inst;
+            const int cls = (prim >= 0) ? (int)((__float_as_uint(s.primTri[3 * prim].w) >> PRIM_CLASS_SHIFT) & (unsigned)(MAX_CLASSES - 1)) : MISS_CLASS;
+            pool.shadeQ[(size_t)cls * pool.n + atomicAdd(&ctr->shadeCount[cls].v, 1u)] = slot;
+        } else if (mode == 1) {
+            const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
+            Hit h;
+            const bool occluded = ResolveQuadrics<true, INST, true>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r0.w, r1.x, r1.y), 1 - kShadowEpsilon, &h, false, nodes, tris);
+            int flags = pool.I(I_FLAGS, slot);
+            bool added = false;
+            if (!occluded) {   // L += the light sample's contribution (k_resolve_shadow, one lane per path here)
+                const bool lZero = (flags & F_L_ZERO) != 0;
+                for (int c = 0; c < NQ; ++c) {
+                    const float4 a = pool.Q(Q_LNEE + c, slot);
+                    added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+                    float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!lZero) l = pool.Q(Q_L + c, slot);
+                    l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
+                    pool.Q(Q_L + c, slot) = l;
                 }
-                if (emit) {
-                    const bool lZero = (flags & F_L_ZERO) != 0;
-                    for (int c = 0; c < NQ; ++c) {
-                        const float4 a = pool.Q(Q_LMIS + c, slot);
-                        added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                        float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!lZero) l = pool.Q(Q_L + c, slot);
-                        l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-                        pool.Q(Q_L + c, slot) = l;
-                    }
-                    flags &= ~F_L_ZERO;
-                }
+                flags &= ~F_L_ZERO;
             }
-        }
-        if (!added && !(flags & F_A_ADDED)) ++zero;
-        pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
+            flags &= ~F_SHADOW;
+            if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }
+            else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
+            pool.I(I_FLAGS, slot) = flags;
+        } else
+            ResolveMisSlot<INST, true>(s, pool, ctr, slot, zero);
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
@@ -2019,6 +2087,7 @@ struct mi_pt {
     std::vector<int> textureTypes;
     bool hasAlphaMasks = false;      // picks the traversal kernels compiled with the alpha-mask test
     bool hasInstances = false;       // ... and with the TransformedPrimitive code (those carry the alpha-mask test too)
+    bool hasQuadrics = false;        // the scene has spheres: the quadric lists of rays can overflow (k_resolve_overflow is launched)
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
@@ -2049,7 +2118,7 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
 }
 
 void FreePool(Pool &p) {
-    hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ);
+    hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ); hipFree(p.ovfQ);
     p = Pool{};   // n = 0, every pointer null: a later render cannot mistake a half-built pool for a usable one
 }
 
@@ -2068,7 +2137,8 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
                     hipMalloc((void **)&t.shadowQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.extQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.misQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
-                    hipMalloc((void **)&t.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)) == hipSuccess;
+                    hipMalloc((void **)&t.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.ovfQ, (size_t)3 * n * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();   // the failed hipMalloc must not poison the next call's hipGetLastError
         FreePool(t);
@@ -2298,7 +2368,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         }
     }
     if (s.bvhWidth == 2 && d->n_instances > 0) {
-        g_err = "object instances are traversed over the two-level BVH records (MIPT_BVH_WIDTH=4), which this scene's tree depth does not allow";
+        g_err = "object instances are traversed over the two-level BVH records (MIPT_BVH_WIDTH=4), which MIPT_BVH_WIDTH=2 or this scene's tree depth rules out";
         mi_pt_destroy(pt);
         return MI_ERR_UNSUPPORTED;
     }
@@ -2450,6 +2520,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 }
                 if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) { flags |= PRIM_FLAG_ALPHA; pt->hasAlphaMasks = true; }
             } else if (p.instance == 0) {
+                pt->hasQuadrics = true;
                 flags |= PRIM_FLAG_SPHERE;
                 shapeIdx = ~p.shape;
             }
@@ -2792,16 +2863,22 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipEventRecord(ev[6], st));
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_extend<true>), chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_extend<false>), chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 0);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 0); }
         HIPCHK(hipEventRecord(ev[2], st));
         LaunchShade(pt, sub, grid);
         HIPCHK(hipEventRecord(ev[3], st));
         LaunchTraversal(pt, sub, 1, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
         HIPCHK(hipEventRecord(ev[4], st));
         LaunchTraversal(pt, sub, 2, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());   // a launch of this iteration that was refused (bad configuration) stops the render here
         havePrev = true; prevFull = true;
@@ -2988,6 +3065,8 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         LaunchTraversal(pt, sub, 0, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_extend<true>), dim3(1), block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_extend<false>), dim3(1), block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 0);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 0); }
         HIPCHK(hipStreamSynchronize(st));
         int bounces = 0, prim = -1, dim = 0;
         float ray0[4], ray1[4], hit[4];
@@ -3000,9 +3079,13 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         LaunchTraversal(pt, sub, 1, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
         LaunchTraversal(pt, sub, 2, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int fl = 0;

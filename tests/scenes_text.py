@@ -488,6 +488,40 @@ def bump_scene(res=64, spp=16, depth=4):
     return BUMP_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch())
 
 
+SPHERE_ROW_SCENE = """
+LookAt 0 1 -9  0 1 0  0 1 0
+Camera "perspective" "float fov" [30]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [30 28 25]
+  Translate 0 6 2
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+LightSource "point" "rgb I" [20 20 25] "point from" [3 3 -8]
+Material "matte" "rgb Kd" [.5 .5 .5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 -8  8 0 -8  8 0 20  -8 0 20]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 0 20  8 0 20  8 9 20  -8 9 20]
+# nine glass and matte spheres in a row along the view axis: a camera ray meets up to nine quadrics, the shadow rays of the
+# wall behind them as many (more than the four a ray's list of postponed quadrics holds)
+%(row)s
+WorldEnd
+"""
+
+
+def sphere_row_scene(res=48, spp=16, depth=12):
+    """Rays that meet more quadrics than the traversal kernel's per-ray list holds (MAX_PEND = 4): a row of spheres
+    along the view axis, glass ones in front (the path goes on through them), partial ones (phimax) among them."""
+    row = []
+    for i in range(9):
+        mat = 'Material "glass" "float index" [1.3]' if i < 6 else 'Material "matte" "rgb Kd" [.2 .6 .3]'
+        extra = ' "float phimax" [300]' if i in (2, 5) else ""
+        row.append('AttributeBegin\n  %s\n  Translate %.2f 1 %.1f\n  Shape "sphere" "float radius" [.7]%s\nAttributeEnd' % (mat, 0.05 * i, -4 + 2.0 * i, extra))
+    return SPHERE_ROW_SCENE % dict(res=res, spp=spp, depth=depth, row="\n".join(row))
+
+
 ROUGHNESS_SCENE = """
 LookAt 0 2.4 -7  0 0.8 0  0 1 0
 Camera "perspective" "float fov" [40] %(lens)s

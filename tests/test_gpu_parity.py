@@ -486,6 +486,24 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
         assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
 
 
+def test_rays_with_more_quadrics_than_the_pending_list_holds(pt, ob):
+    """k_trav postpones the quadrics a ray meets (four per ray); a ray that meets more is handed to k_resolve_overflow, which
+    re-traverses it in the reference's order with inline quadric tests and commits it like the resolve kernel would have:
+    closest-hit, shadow and MIS rays. Exact-mode parity on a row of nine spheres along the view axis, and equal recorded
+    rays along that axis."""
+    s = pt.Scene(text=st.sphere_row_scene())
+    assert s.errors == [] and s.desc.n_spheres == 10
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "sphere row (quadric list overflow)")
+    rng = np.random.default_rng(9)
+    n = 3000
+    o = np.tile(np.array([0, 1, -9], np.float32), (n, 1)) + rng.normal(0, .05, (n, 3)).astype(np.float32)
+    tgt = np.stack([rng.normal(.2, .4, n), rng.normal(1, .4, n), np.full(n, 14.0)], -1).astype(np.float32)
+    rays = np.concatenate([o, tgt - o, np.full((n, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    dh = integ.trace(rays, any_hit=False)
+    oh, _ = ob.trace(s, rays, any_hit=False)
+    assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32)) and np.array_equal(dh[:, 1], oh[:, 1])
+
+
 def test_roughness_textures_against_oracle(pt, ob, tmp_path):
     """Float image textures on the roughness parameters (plastic.cpp:57-62, uber.cpp:88-96, substrate.cpp:55-60,
     metal.cpp:66-73, translucent.cpp:70-72): the value at the hit, through RoughnessToAlpha unless "remaproughness" is off,
