@@ -31,6 +31,9 @@
 #include <vector>
 #include "d_sampling.h"
 #include "d_texture.h"
+#ifdef MIPT_SORT_EXPERIMENT
+#include <hipcub/hipcub.hpp>
+#endif
 
 using namespace dpt;
 
@@ -2715,6 +2718,49 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     return MI_OK;
 }
 
+#ifdef MIPT_SORT_EXPERIMENT
+// Experiment (not part of the product build): how much would the traversal kernels gain from coherent work lists? Sorts a
+// ray queue by (origin cell 8x8x8, direction octant) with hipcub before the traversal launch; MIPT_SORT = bit mask of the
+// modes to sort (1: continuation rays, 2: shadow rays, 4: MIS rays). The sort's own time is not the question here: the
+// traversal kernels' durations in a rocprofv3 kernel trace are.
+__global__ void k_sort_keys(DScene s, Pool pool, const uint32_t *queue, unsigned n, int mode, uint32_t *keys) {
+    const unsigned i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = queue[i];
+    const float4 r0 = pool.R(mode == 0 ? R_RAY0 : (mode == 1 ? R_SH0 : R_MI0), slot), r1 = pool.R(mode == 0 ? R_RAY1 : (mode == 1 ? R_SH1 : R_MI1), slot);
+    const float dx = mode == 0 ? r1.x : r0.w, dy = mode == 0 ? r1.y : r1.x, dz = mode == 0 ? r1.z : r1.y;
+    auto cell = [&](float v, int a) { const float t = (v - s.wbMin[a]) / (s.wbMax[a] - s.wbMin[a]); return (unsigned)min(7, max(0, (int)(t * 8.f))); };
+    const unsigned cx = cell(r0.x, 0), cy = cell(r0.y, 1), cz = cell(r0.z, 2);
+    unsigned m = 0;
+    for (int b = 0; b < 3; ++b) m |= (((cx >> b) & 1u) << (3 * b)) | (((cy >> b) & 1u) << (3 * b + 1)) | (((cz >> b) & 1u) << (3 * b + 2));
+    keys[i] = (m << 3) | (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
+}
+static void SortQueueExperiment(mi_pt *pt, SubRenderer &sub, int mode) {
+    static int mask = getenv("MIPT_SORT") ? atoi(getenv("MIPT_SORT")) : 0;
+    if (!((mask >> mode) & 1)) return;
+    hipStream_t st = sub.stream;
+    static uint32_t *keys = nullptr, *keysOut = nullptr, *valsOut = nullptr;
+    static void *temp = nullptr;
+    static size_t tempBytes = 0;
+    const size_t cap = sub.pool.n;
+    if (!keys) {
+        hipMalloc((void **)&keys, cap * 4); hipMalloc((void **)&keysOut, cap * 4); hipMalloc((void **)&valsOut, cap * 4);
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keys, keysOut, valsOut, valsOut, (int)cap, 0, 12, st);
+        hipMalloc(&temp, tempBytes);
+    }
+    unsigned cnt[2] = {0, 0};
+    uint32_t *queue;
+    if (mode == 0) { hipMemcpyAsync(&cnt[0], &sub.ctr->contCount.v, 4, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); queue = sub.pool.extQ + (sub.pool.n - cnt[0]); }
+    else { hipMemcpyAsync(&cnt[0], mode == 1 ? &sub.ctr->shadowCount.v : &sub.ctr->misCount.v, 4, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); queue = mode == 1 ? sub.pool.shadowQ : sub.pool.misQ; }
+    const unsigned n = cnt[0];
+    if (n < 2) return;
+    hipLaunchKernelGGL(k_sort_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, pt->scene, sub.pool, queue, n, mode, keys);
+    size_t tb = tempBytes;
+    hipcub::DeviceRadixSort::SortPairs(temp, tb, keys, keysOut, queue, valsOut, (int)n, 0, 12, st);
+    hipMemcpyAsync(queue, valsOut, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+}
+#endif
+
 // The launches of one wavefront iteration, shared by RenderSub and the path-dump tool.
 static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid) {
     const DScene &s = pt->scene;
@@ -2860,6 +2906,9 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         if (alive == 0 && drawn >= wd.totalWork) { harvest(set, false); break; }
         if (alive == 0) { harvest(set, false); havePrev = false; set ^= 1; if (++sub.iterations > 100000000ull) { g_err = "render loop did not terminate"; return MI_ERR_HIP; } continue; }
         HIPCHK(hipEventRecord(ev[7], st));
+#ifdef MIPT_SORT_EXPERIMENT
+        SortQueueExperiment(pt, sub, 0);
+#endif
         LaunchTraversal(pt, sub, 0, travGrid);
         HIPCHK(hipEventRecord(ev[6], st));
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_extend<true>), chunkGrid, block, 0, st, s, sub.pool, sub.ctr);
@@ -2869,12 +2918,18 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         HIPCHK(hipEventRecord(ev[2], st));
         LaunchShade(pt, sub, grid);
         HIPCHK(hipEventRecord(ev[3], st));
+#ifdef MIPT_SORT_EXPERIMENT
+        SortQueueExperiment(pt, sub, 1);
+#endif
         LaunchTraversal(pt, sub, 1, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
         HIPCHK(hipEventRecord(ev[4], st));
+#ifdef MIPT_SORT_EXPERIMENT
+        SortQueueExperiment(pt, sub, 2);
+#endif
         LaunchTraversal(pt, sub, 2, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
