@@ -110,7 +110,11 @@ enum : int {
     // much as the rest of k_generate, so they stay implicit until something else is written there:
     F_L_ZERO = 256,     // Q_L holds no value yet; it reads as 0 (0 + x == x)
     F_BETA_ONE = 512,   // Q_BETA holds no value yet; it reads as 1 (1 * x == x)
-    F_DIFF = 1024       // the path ray is still the camera ray: it has ray differentials (RayDifferential::hasDifferentials)
+    F_DIFF = 1024,      // the path ray is still the camera ray: it has ray differentials (RayDifferential::hasDifferentials)
+    // The light sample's contribution of a path whose L is still empty (F_L_ZERO: most first vertices) is written into Q_L
+    // itself instead of Q_LNEE: an unoccluded shadow ray then only clears F_L_ZERO (0 + x == x), an occluded one leaves the
+    // line to read as zero -- k_resolve_shadow moves no spectrum for these. F_NEE_NZ: that contribution has a non-zero bin.
+    F_NEE_IN_L = 2048, F_NEE_NZ = 4096
 };
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
@@ -995,7 +999,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
     for (int it = 0; it < 8; ++it) {
         const int src = it * 8 + (lane >> 3);
         const uint32_t sSlot = (uint32_t)__shfl((int)mySlot, src);
-        const int sAdd = __shfl(doAdd ? 1 : 0, src);
+        const int sAdd = __shfl((doAdd && !(myFlags & F_NEE_IN_L)) ? 1 : 0, src);
         const int sZero = __shfl((myFlags & F_L_ZERO) ? 1 : 0, src);
         bool nz = false;
         if (sAdd) {
@@ -1012,9 +1016,9 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
     }
     if (valid) {
         int flags = myFlags;
-        const bool added = addedBits != 0;
-        if (doAdd) flags &= ~F_L_ZERO;
-        flags &= ~F_SHADOW;
+        const bool added = (flags & F_NEE_IN_L) ? (doAdd && (flags & F_NEE_NZ)) : (addedBits != 0);
+        if (doAdd) flags &= ~F_L_ZERO;   // (F_NEE_IN_L: Q_L holds the contribution already; occluded: it goes on reading as zero)
+        flags &= ~(F_SHADOW | F_NEE_IN_L | F_NEE_NZ);
         if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
         else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
         pool.I(I_FLAGS, mySlot) = flags;
@@ -1123,7 +1127,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool,
             const bool occluded = ResolveQuadrics<true, INST, true>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r0.w, r1.x, r1.y), 1 - kShadowEpsilon, &h, false, nodes, tris);
             int flags = pool.I(I_FLAGS, slot);
             bool added = false;
-            if (!occluded) {   // L += the light sample's contribution (k_resolve_shadow, one lane per path here)
+            if (!occluded && (flags & F_NEE_IN_L)) { added = (flags & F_NEE_NZ) != 0; flags &= ~F_L_ZERO; }
+            else if (!occluded) {   // L += the light sample's contribution (k_resolve_shadow, one lane per path here)
                 const bool lZero = (flags & F_L_ZERO) != 0;
                 for (int c = 0; c < NQ; ++c) {
                     const float4 a = pool.Q(Q_LNEE + c, slot);
@@ -1135,7 +1140,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool,
                 }
                 flags &= ~F_L_ZERO;
             }
-            flags &= ~F_SHADOW;
+            flags &= ~(F_SHADOW | F_NEE_IN_L | F_NEE_NZ);
             if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }
             else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
             pool.I(I_FLAGS, slot) = flags;
@@ -1534,8 +1539,9 @@ DEV float4 LoadBeta(const Pool &pool, int c, uint32_t slot, bool betaOne) {
 struct SpectrumTile {
     float4 q[NQ][BLOCK];
     int slotOf[BLOCK];
-    unsigned char laneOf[BLOCK];
+    unsigned char laneOf[BLOCK], specOf[BLOCK];
 };
+// (`spectrum` may differ from lane to lane: it travels with the path)
 DEV void StoreSpectrumLines(SpectrumTile &t, const Pool &pool, int spectrum, uint32_t slot, bool wrote) {
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1549,13 +1555,14 @@ DEV void StoreSpectrumLines(SpectrumTile &t, const Pool &pool, int spectrum, uin
         const int rw = __popcll(wmask & lt);
         t.slotOf[wbase + rw] = (int)slot;
         t.laneOf[wbase + rw] = (unsigned char)lane;
+        t.specOf[wbase + rw] = (unsigned char)spectrum;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile and the list are written before they are read
     __builtin_amdgcn_wave_barrier();
     const int ra = __popcll(active & lt), g = ra >> 3, c = ra & 7;
     if (g < nGroups)
         for (int e = g; e < nW; e += nGroups)
-            pool.Q(spectrum + c, (uint32_t)t.slotOf[wbase + e]) = t.q[c][wbase + t.laneOf[wbase + e]];
+            pool.Q((int)t.specOf[wbase + e] + c, (uint32_t)t.slotOf[wbase + e]) = t.q[c][wbase + t.laneOf[wbase + e]];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... and read before the tile is reused
     __builtin_amdgcn_wave_barrier();
 }
@@ -1781,7 +1788,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             float weight = 1.f;
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
                             const Divisor lpDiv = MakeDivisor(lightPdf);
-                            bool fNonBlack = false, liNonBlack = false;
+                            bool fNonBlack = false, liNonBlack = false, nzAny = false;
 #pragma unroll 1
                             for (int c = 0; c < NQ; ++c) {
                                 const float4 bt = loadBeta(c);
@@ -1797,13 +1804,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         liNonBlack |= (Li != 0.f);
                                         float Ld = delta ? DivBy(f * Li, lpDiv) : DivBy((f * Li) * weight, lpDiv);
                                         if (!selIsOne) Ld = DivBy(Ld, selDiv);
-                                        Set4(out, k, Get4(bt, k) * Ld);
+                                        const float contrib = Get4(bt, k) * Ld;
+                                        nzAny |= (contrib != 0.f);
+                                        Set4(out, k, contrib);
                                     }
                                 }
                                 tile.q[c][threadIdx.x] = out;
                             }
-                            StoreSpectrumLines(tile, pool, Q_LNEE, slot, true);
-                            if (fNonBlack && liNonBlack) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
+                            // only a contribution whose shadow ray will be traced is ever read; into Q_L itself while the
+                            // path's L is still empty (F_NEE_IN_L)
+                            const bool traced = fNonBlack && liNonBlack;
+                            StoreSpectrumLines(tile, pool, lZero ? Q_L : Q_LNEE, slot, traced);
+                            if (traced && lZero) newFlags |= F_NEE_IN_L | (nzAny ? F_NEE_NZ : 0);
+                            if (traced) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
                                 pool.R(R_SH0, slot) = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.d.x);
                                 pool.R(R_SH1, slot) = make_float4(sr.d.y, sr.d.z, 0.f, 0.f);
@@ -1946,7 +1959,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (finished) {
                 // ReportValue(pathLength, bounces): `bounces` at the break of path.cpp's loop
                 pathLen = (unsigned)bounces;
-                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS)) | F_FINISHED;
+                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_NEE_IN_L | F_NEE_NZ)) | F_FINISHED;
             } else {
                 newFlags |= F_ALIVE;
                 pool.I(I_BOUNCES, slot) = bounces + 1;

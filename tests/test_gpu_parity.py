@@ -214,10 +214,14 @@ def test_cornell_glass_sphere(pt, ob):
     _parity(pt, ob, s, "cornell glass 128x128 16spp", exact=False, rel_tol=2e-3, counter_tol=1e-3)
 
 
-@pytest.mark.parametrize("text", [st.furnace_point(), st.furnace_area(), st.furnace_uber()])
-def test_furnace_scenes_on_gpu(pt, text):
-    """The reference's known answers (tests/analytic_scenes.cpp) on the device itself."""
-    s = pt.Scene(text=text)
+@pytest.mark.parametrize("sampler", ["halton", "sobol", "random"])
+@pytest.mark.parametrize("text", [st.furnace_point(), st.furnace_point(n_lights=4), st.furnace_area(), st.furnace_uber()])
+def test_furnace_scenes_on_gpu(pt, text, sampler):
+    """The reference's known answers on the device itself: the scenes of tests/analytic_scenes.cpp:71-203 under the
+    samplers of its matrix (:250-267) that this path builds -- radiance 1 everywhere, to the reference's 2 %."""
+    assert 'Sampler "halton"' in text
+    s = pt.Scene(text=text.replace('Sampler "halton"', 'Sampler "%s"' % sampler))
+    assert s.errors == []
     integ = pt.CreatePathIntegrator(s)
     film, weight = integ.Render()
     assert abs(float((film / weight[..., None]).mean()) - 1.0) < 0.02
