@@ -37,14 +37,25 @@
 
 using namespace dpt;
 
-namespace {
+// The library is built from this file four times in parallel (Makefile): MIPT_PART 0 holds everything but the shading
+// kernel's instances (host code, the other kernels), parts 1-3 hold a third of the k_shade instances each (they are 95 % of
+// the compile time). Without MIPT_PART (tools/isa_stats.py, tools/build_variants.sh) everything is one translation unit.
+#ifdef MIPT_PART
+#define MIPT_HAS_MAIN (MIPT_PART == 0)
+#else
+#define MIPT_HAS_MAIN 1
+#endif
 
-thread_local std::string g_err;
+namespace dptk {   // (named: k_shade's instances are shared between the parts, so the types in its signature need linkage)
+
+static thread_local std::string g_err;
 
 // Four sub-renderer streams want four hardware queues of their own; the HIP runtime maps
 // streams onto GPU_MAX_HW_QUEUES (default 4, shared with the null stream) when it
 // initialises, which happens at the first HIP call -- after this library is loaded.
-struct QueueEnv { QueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queueEnv;
+#if MIPT_HAS_MAIN
+static struct QueueEnv { QueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queueEnv;
+#endif
 #define HIPCHK(x)                                                                         \
     do {                                                                                  \
         hipError_t e_ = (x);                                                              \
@@ -1170,6 +1181,7 @@ DEV void CameraRay(const DScene &s, float pFilmX, float pFilmY, float lensU, flo
     *out = XfRay(cam.camera_to_world, ray);
 }
 
+#if MIPT_HAS_MAIN
 // FilmTile::AddSample + MergeFilmTile (film.h:123-163, film.cpp:124-142) as float atomics
 // into the resident film [pixel][32] (31 bins + filter-weight sum = one 128-B row), then the refill of the
 // freed slots with new camera samples, then the extend work list.
@@ -1484,6 +1496,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     CountAdd(&Stats(ctr).cameraRays, cam);
     CountAdd(&Stats(ctr).badSamples, bad);
 }
+
+#endif   // MIPT_HAS_MAIN
 
 // Transform::operator()(const SurfaceInteraction&), transform.cpp:262-297, with an instance's InstanceToWorld: the fields the
 // path reads (SurfaceInteraction) and the ones textures and bump mapping read besides (TriShading).
@@ -1983,6 +1997,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     CountAdd(&Stats(ctr).zeroRadiancePaths, zeroNow);
 }
 
+#if MIPT_HAS_MAIN
 // ------------------------------------------------------------------ spatial light distribution (create time)
 __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcInt, uint32_t nVox) {
     const uint32_t vox = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2069,9 +2084,34 @@ __global__ void k_film_split(const float *film32, float *filmSum, float *weightS
     if (b < 31) { if (filmSum) filmSum[pix * 31 + b] = v; }
     else if (weightSum) weightSum[pix] = v;
 }
+#endif   // MIPT_HAS_MAIN
 
-}  // namespace
+// The k_shade instances LaunchShade uses, in three groups of about equal compile time.
+constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_TEXTURED;
+#define MIPT_SHADE_GROUP_1(X) X(MI_MAX_BXDFS, TM_ALL) X(4, TM_GENERIC) X(2, TM_GENERIC) \
+    X(2, TM_DIFFUSE | TM_LIGHTS_ALL) X(2, TM_DIFFUSE | TM_LIGHTS_NO_ENV) X(2, TM_DIFFUSE | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_DIFFUSE | TM_LIGHTS_NO_ENV | TM_SAMPLERS)
+#define MIPT_SHADE_GROUP_2(X) X(MI_MAX_BXDFS, TM_FULL) X(2, TM_ALL) X(2, TM_FULL) \
+    X(2, TM_PLASTIC | TM_LIGHTS_ALL) X(2, TM_PLASTIC | TM_LIGHTS_NO_ENV) X(2, TM_PLASTIC | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_PLASTIC | TM_LIGHTS_NO_ENV | TM_SAMPLERS)
+#define MIPT_SHADE_GROUP_3(X) X(MI_MAX_BXDFS, TM_GENERIC) X(4, TM_FULL) X(4, TM_UBER | TM_LIGHTS_ALL | TM_SAMPLERS) X(MI_MAX_BXDFS, TM_DISNEY | TM_LIGHTS_ALL | TM_SAMPLERS) \
+    X(2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS)
+#define MIPT_SHADE_DEFINE(NL_, TM_) template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
+#define MIPT_SHADE_EXTERN(NL_, TM_) extern template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
+#ifdef MIPT_PART
+#if MIPT_PART == 0
+MIPT_SHADE_GROUP_1(MIPT_SHADE_EXTERN) MIPT_SHADE_GROUP_2(MIPT_SHADE_EXTERN) MIPT_SHADE_GROUP_3(MIPT_SHADE_EXTERN)
+#elif MIPT_PART == 1
+MIPT_SHADE_GROUP_1(MIPT_SHADE_DEFINE)
+#elif MIPT_PART == 2
+MIPT_SHADE_GROUP_2(MIPT_SHADE_DEFINE)
+#else
+MIPT_SHADE_GROUP_3(MIPT_SHADE_DEFINE)
+#endif
+#endif
 
+}  // namespace dptk
+using namespace dptk;
+
+#if MIPT_HAS_MAIN
 // =============================================================================
 // C ABI
 // =============================================================================
@@ -2803,7 +2843,6 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
     const dim3 shadeGrid(grid.x + MAX_CLASSES);
-    constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_TEXTURED;
     if (pt->hasInstances) {   // scenes with object instances: the two fully general instances of the kernel, by lobe count
         const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
         const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge | pt->uberClasses | pt->disneyClasses;
@@ -3207,3 +3246,4 @@ void mi_pt_destroy(mi_pt *pt) {
 }
 
 }  // extern "C"
+#endif   // MIPT_HAS_MAIN
