@@ -250,14 +250,18 @@ struct Hit {
 // wave tests leaves together). Quadric primitives are postponed: recorded in encounter
 // order and tested after the triangles against the final tMax (closest hit is order
 // independent), so the interval-arithmetic sphere code runs at full lane utilisation.
-struct TravLds {
+// (TMIN = false: the any-hit kernel keeps no entry distances -- a shadow ray's tMax never shrinks, so an entry pushed in
+// front of it stays in front of it -- which takes the stack from 36 to 24 KB per block: five blocks per CU instead of four)
+template <bool TMIN>
+struct TravLdsT {
     int node[STACK_LDS][BLOCK];
     int meta[STACK_LDS][BLOCK];
-    float tmin[STACK_LDS][BLOCK];
+    float tmin[TMIN ? STACK_LDS : 1][BLOCK];
 };
 // The block's traversal stack lives in one LDS object reached by name (no generic pointers).
-DEV TravLds &TravStack() {
-    __shared__ TravLds stack;
+template <bool TMIN>
+DEV TravLdsT<TMIN> &TravStack() {
+    __shared__ TravLdsT<TMIN> stack;
     return stack;
 }
 struct TravSpill {
@@ -302,10 +306,11 @@ DEV bool BoxTest(const RayCtx &r, float mnx, float mny, float mnz, float mxx, fl
 struct TravState {
     int cur, sp;
 };
+template <bool TMIN = true>
 DEV void StackPush(TravSpill &sp, int lane, int &n, int node, int meta, float tmin) {
-    TravLds &lds = TravStack();
+    TravLdsT<TMIN> &lds = TravStack<TMIN>();
     if (n >= STACK_LDS + STACK_SPILL) return;   // (cannot happen: mi_pt_create bounds the depth of the tree it uploads)
-    if (n < STACK_LDS) { lds.node[n][lane] = node; lds.meta[n][lane] = meta; lds.tmin[n][lane] = tmin; }
+    if (n < STACK_LDS) { lds.node[n][lane] = node; lds.meta[n][lane] = meta; if (TMIN) lds.tmin[n][lane] = tmin; }
     else {
         // keep the LDS and the scratch path apart: merged into one store through a selected
         // generic pointer, hipcc 7.2 emits an illegal address-space test for gfx950
@@ -314,10 +319,11 @@ DEV void StackPush(TravSpill &sp, int lane, int &n, int node, int meta, float tm
     }
     ++n;
 }
+template <bool TMIN = true>
 DEV void StackPop(TravSpill &sp, int lane, int &n, int *node, int *meta, float *tmin) {
-    TravLds &lds = TravStack();
+    TravLdsT<TMIN> &lds = TravStack<TMIN>();
     --n;
-    if (n < STACK_LDS) { *node = lds.node[n][lane]; *meta = lds.meta[n][lane]; *tmin = lds.tmin[n][lane]; }
+    if (n < STACK_LDS) { *node = lds.node[n][lane]; *meta = lds.meta[n][lane]; *tmin = TMIN ? lds.tmin[n][lane] : 0.f; }
     else {
         int nd = sp.node[n - STACK_LDS], mt = sp.meta[n - STACK_LDS];
         float tm = sp.tmin[n - STACK_LDS];
@@ -336,7 +342,7 @@ DEV void StackPop(TravSpill &sp, int lane, int &n, int *node, int *meta, float *
 // is monotone), and the entry-distance re-validation at pop time is the only tMax-dependent part of the test. So the lane
 // enters the same leaves in the same order against the same tMax as the BVH2 traversal -- closest hits, equal-t ties and
 // the count of primitive tests are unchanged -- with half the dependent node fetches per ray.
-template <int W>
+template <int W, bool TMIN = true>
 DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, float tMax, TravSpill &spill, int lane, int &sp,
                   int *tkChild, int *tkMeta, unsigned &nodeCount) {
     if constexpr (W == 2) {
@@ -358,7 +364,7 @@ DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, f
         const float tS = negAxis ? tL : tR;
         if (hitF) {
             *tkChild = chF; *tkMeta = mtF;
-            if (hitS) StackPush(spill, lane, sp, chS, mtS, tS);
+            if (hitS) StackPush<TMIN>(spill, lane, sp, chS, mtS, tS);
             return true;
         }
         if (hitS) { *tkChild = chS; *tkMeta = mtS; return true; }
@@ -392,7 +398,7 @@ DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, f
                     const int lk = cand == 0 ? l0 : (cand == 1 ? l1 : (cand == 2 ? l2 : l3));
                     const int ct = cand == 0 ? cnt0 : (cand == 1 ? cnt1 : (cand == 2 ? cnt2 : cnt3));
                     const float tt = cand == 0 ? t0 : (cand == 1 ? t1 : (cand == 2 ? t2 : t3));
-                    StackPush(spill, lane, sp, lk, ct, tt);
+                    StackPush<TMIN>(spill, lane, sp, lk, ct, tt);
                 }
                 cand = sl;
             }
@@ -558,6 +564,9 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 #ifndef MIPT_TRAV_WAVES_PER_EU
 #define MIPT_TRAV_WAVES_PER_EU 4
 #endif
+#ifndef MIPT_TRAV_WAVES_PER_EU_ANY
+#define MIPT_TRAV_WAVES_PER_EU_ANY 5   // the any-hit kernel (without the alpha-mask code): 96 VGPRs and a 24-KB stack allow five blocks per CU
+#endif
 // ALPHA: the scene has meshes with alpha masks (the mask test is compiled into this instance only)
 // INST: the scene has object instances (TransformedPrimitive, primitive.cpp:78-99). A lane that meets an instance in a world
 // leaf pushes ONE return entry (the rest of that leaf and the world ray's tMax; meta < 0 marks it), swaps its ray for
@@ -565,7 +574,8 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 // the pool and resumes the leaf -- with the instance ray's tMax if something was hit inside (`r.tMax = ray.tMax`). The
 // sequence of box tests, primitive tests and tMax updates per ray is the reference's recursion unrolled.
 template <int MODE, bool ALPHA, int W, bool INST = false>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_TRAV_WAVES_PER_EU, MIPT_TRAV_WAVES_PER_EU))) k_trav(DScene s, Pool pool, DevCounters *ctr) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 1 && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU, (MODE == 1 && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU)))
+k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool ANY = (MODE == 1);
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
@@ -664,7 +674,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             bool needPop = false, got = false, finished = false;
             int tkChild = 0, tkMeta = 0;
             if (walking) {
-                got = OpenNode<W>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
+                got = OpenNode<W, !ANY>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
                 needPop = !got;
                 st.cur = -1;
             }
@@ -763,7 +773,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (INST && (pf & PRIM_FLAG_INSTANCE)) {
                     // TransformedPrimitive::Intersect[P]: the ray in the instance's space, then the object's BVH from its root
                     const int k = __float_as_int(primTri[3 * prim + 1].w);
-                    StackPush(spill, lane, st.sp, leafOff, -(leafCnt + 1), tMax);
+                    StackPush<!ANY>(spill, lane, st.sp, leafOff, -(leafCnt + 1), tMax);
                     const Ray ir = XfRay(s.instances[k].w2i, Ray(V3(r.ox, r.oy, r.oz), V3(r.dx, r.dy, r.dz), tMax));
                     InitRayCtx(r, ir.o.x, ir.o.y, ir.o.z, ir.d.x, ir.d.y, ir.d.z);
                     triRay = MakeTriRay(ir.d);
@@ -817,20 +827,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (needPop) {  // a popped node is entered only if still in front of tMax
                 while (!got && st.sp > 0) {
                     float t;
-                    StackPop(spill, lane, st.sp, &tkChild, &tkMeta, &t);
+                    StackPop<!ANY>(spill, lane, st.sp, &tkChild, &tkMeta, &t);
                     if (INST && tkMeta < 0) {   // back from the instance: the world ray again, and the rest of the leaf
                         const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
                         const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
                         if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
                         else InitRayCtx(r, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
                         triRay = MakeTriRay(V3(r.dx, r.dy, r.dz));
-                        if (!hitInCur) tMax = t;   // (a hit inside: r.tMax = ray.tMax)
+                        if (!hitInCur) tMax = ANY ? 1 - kShadowEpsilon : t;   // (a hit inside: r.tMax = ray.tMax; any-hit: no entry distances are kept)
                         curInst = -1;
                         tkMeta = -tkMeta - 1;      // primitives left in the world leaf
                         got = tkMeta > 0;
                         continue;
                     }
-                    got = t < tMax;
+                    got = ANY || t < tMax;
                 }
                 finished = !got;
             }
@@ -2816,6 +2826,7 @@ static void SortQueueExperiment(mi_pt *pt, SubRenderer &sub, int mode) {
 
 // The launches of one wavefront iteration, shared by RenderSub and the path-dump tool.
 static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid) {
+    if (mode == 1 && !pt->hasAlphaMasks && !pt->hasInstances && travGrid.x == (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU) travGrid.x = (unsigned)pt->numCUs * MIPT_TRAV_WAVES_PER_EU_ANY;   // (a full-size launch: one more block per CU)
     const DScene &s = pt->scene;
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
