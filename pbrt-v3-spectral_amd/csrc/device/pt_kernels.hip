@@ -248,8 +248,9 @@ struct Hit {
 //     same order against the same tMax: equal-t ties resolve identically.
 // SIMT schedule: "while-while" (walk interior nodes until the lane holds a leaf, then the
 // wave tests leaves together). Quadric primitives are postponed: recorded in encounter
-// order and tested after the triangles against the final tMax (closest hit is order
-// independent), so the interval-arithmetic sphere code runs at full lane utilisation.
+// order with the ray's tMax of that moment and replayed after the triangles in the
+// reference's order (ResolveQuadrics), so the interval-arithmetic sphere code runs at full
+// lane utilisation.
 // (TMIN = false: the any-hit kernel keeps no entry distances -- a shadow ray's tMax never shrinks, so an entry pushed in
 // front of it stays in front of it -- which takes the stack from 36 to 24 KB per block: five blocks per CU instead of four)
 template <bool TMIN>
@@ -657,9 +658,10 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
             continue;  // every fetched slot was dead: fetch again
         }
         // ---- step the lanes until enough of them have run dry. Every pass opens one
-        // interior node in each lane that holds one; lanes that reached a leaf wait, and
-        // one primitive per waiting lane is tested once TRI_BATCH lanes wait (or nobody is
-        // left walking), so both the box code and the triangle code run on well-filled waves.
+        // interior node in each lane that holds one; lanes that reached a leaf wait, and once
+        // TRI_BATCH lanes wait (or nobody is left walking) their leaves are tested -- triangles-only
+        // leaves by the whole wave (cooperative test below), the others one primitive per waiting
+        // lane -- so both the box code and the triangle code run on well-filled waves.
         // Per lane the sequence of node visits, pops and primitive tests is unchanged.
         while (true) {
             const bool walking = has && st.cur >= 0;
