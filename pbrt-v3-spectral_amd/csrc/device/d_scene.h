@@ -46,6 +46,7 @@ struct DScene {
     const mi_sphere *spheres;
     const mi_material *materials;
     const mi_light *lights;
+    const float4 *lightBounds;   // [2 * nLights]: dilated world bounds of an area light's shape (see F_MIS_DARK, pt_kernels.hip)
     uint32_t nNodes, nPrims, nLights, nMaterials;
     uint32_t classMask;  // shading classes present in the scene (bit c), see pt_kernels.hip
     // light distribution: distribution d at func[d*nLights], cdf[d*(nLights+1)], funcInt[d]

@@ -125,8 +125,28 @@ enum : int {
     // The light sample's contribution of a path whose L is still empty (F_L_ZERO: most first vertices) is written into Q_L
     // itself instead of Q_LNEE: an unoccluded shadow ray then only clears F_L_ZERO (0 + x == x), an occluded one leaves the
     // line to read as zero -- k_resolve_shadow moves no spectrum for these. F_NEE_NZ: that contribution has a non-zero bin.
-    F_NEE_IN_L = 2048, F_NEE_NZ = 4096
+    F_NEE_IN_L = 2048, F_NEE_NZ = 4096,
+    // The BSDF-sampled (MIS) ray is traced, but it cannot reach the sampled area light (it misses the dilated bounds of the
+    // light's shape: Sphere::Pdf gives every direction the cone's pdf, sphere.cpp:294-310, so the estimate goes on for rays
+    // that point away from the sphere), so its contribution was neither formed nor stored in Q_LMIS.
+    F_MIS_DARK = 8192
 };
+// Conservative: false only if the ray o + t d, t >= 0, stays outside the box.
+DEV bool RayMayHitBox(const V3 &o, const V3 &d, const float4 &bmin, const float4 &bmax) {
+    float t0 = 0.f, t1 = kInfinity;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {bmin.x, bmin.y, bmin.z}, hi[3] = {bmax.x, bmax.y, bmax.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] == 0.f) { if (oo[a] < lo[a] || oo[a] > hi[a]) return false; continue; }
+        const float inv = 1.f / dd[a];
+        float ta = (lo[a] - oo[a]) * inv, tb = (hi[a] - oo[a]) * inv;
+        if (ta > tb) { const float tt = ta; ta = tb; tb = tt; }
+        tb *= 1.0001f;   // (rounding of the products: widen the exit)
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+    }
+    return !(t0 > t1);
+}
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
 // first appearance, the 15th and later share class 14); class 15 holds the vertices without a
@@ -1088,7 +1108,7 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
     }
     if (found) {
         const int lightNum = pool.I(I_MISLIGHT, slot);
-        if (s.prims[h.prim].area_light == lightNum) {
+        if (s.prims[h.prim].area_light == lightNum && !(flags & F_MIS_DARK)) {   // (dark: cannot happen, the bounds are conservative)
             const mi_light &l = s.lights[lightNum];
             bool emit = l.two_sided != 0;
             if (!emit) {
@@ -1112,7 +1132,7 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
         }
     }
     if (!added && !(flags & F_A_ADDED)) ++zero;
-    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED);
+    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED | F_MIS_DARK);
 }
 template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
@@ -1872,10 +1892,23 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 if (isEnvLight && go) envLe = InfiniteLe(s, light, wi);   // light.Le(ray) when the ray escapes
                                 const Divisor spDiv = MakeDivisor(sPdf);
                                 bool fNonBlack = false;
+                                // a ray that cannot reach the sampled area light is traced all the same (the reference
+                                // traces it), but its contribution is never read: F_MIS_DARK
+                                const Ray mr = SpawnRay(isect, wi);
+                                const bool dark = go && !isEnvLight && !RayMayHitBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1]);
+                                if (dark) {
+#pragma unroll 1
+                                    for (int c = 0; c < NQ; ++c) {   // (only: is f black? -- that decides whether the ray exists)
+                                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
+#pragma unroll
+                                        for (int k = 0; k < 4; ++k)
+                                            if (4 * c + k < MI_NSPEC) fNonBlack |= (Get4(fq, k) * absdot != 0.f);
+                                    }
+                                }
                                 // (when the light's pdf for wi is 0 the estimate ends here, integrator.cpp:186-187:
                                 // nothing reads the spectrum then, so it is not formed)
 #pragma unroll 1
-                                for (int c = 0; go && c < NQ; ++c) {
+                                for (int c = 0; go && !dark && c < NQ; ++c) {
                                     const float4 bt = loadBeta(c);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
                                     const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
@@ -1895,9 +1928,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     }
                                     tile.q[c][threadIdx.x] = out;
                                 }
-                                StoreSpectrumLines(tile, pool, Q_LMIS, slot, go);   // whole 128-B lines, as for the light sample
+                                StoreSpectrumLines(tile, pool, Q_LMIS, slot, go && !dark);   // whole 128-B lines, as for the light sample
                                 if (fNonBlack && go) {
-                                    Ray mr = SpawnRay(isect, wi);
+                                    if (dark) newFlags |= F_MIS_DARK;
                                     pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
                                     pool.R(R_MI1, slot) = make_float4(mr.d.y, mr.d.z, 0.f, 0.f);
                                     pool.I(I_MISLIGHT, slot) = lightNum;
@@ -1985,7 +2018,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (finished) {
                 // ReportValue(pathLength, bounces): `bounces` at the break of path.cpp's loop
                 pathLen = (unsigned)bounces;
-                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_NEE_IN_L | F_NEE_NZ)) | F_FINISHED;
+                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_NEE_IN_L | F_NEE_NZ | F_MIS_DARK)) | F_FINISHED;
             } else {
                 newFlags |= F_ALIVE;
                 pool.I(I_BOUNCES, slot) = bounces + 1;
@@ -2620,6 +2653,40 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     UP(d->spheres, d->n_spheres, s.spheres);
     UP(d->materials, d->n_materials, s.materials);
     UP(d->lights, d->n_lights, s.lights);
+    {   // dilated world bounds of the area lights' shapes (F_MIS_DARK)
+        std::vector<float4> lb((size_t)std::max<uint32_t>(d->n_lights, 1) * 2, float4{-INFINITY, -INFINITY, -INFINITY, 0});
+        for (uint32_t i = 0; i < d->n_lights; ++i) {
+            const mi_light &l = d->lights[i];
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            auto add = [&](float x, float y, float z) { const float p[3] = {x, y, z}; for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } };
+            bool have = false;
+            if (l.type == MI_LIGHT_DIFFUSE_AREA && l.shape >= 0 && (uint32_t)l.shape < d->n_tris) {
+                const int32_t *v = &d->tri_indices[3 * l.shape];
+                for (int k = 0; k < 3; ++k) add(d->P[3 * v[k]], d->P[3 * v[k] + 1], d->P[3 * v[k] + 2]);
+                have = true;
+            } else if (l.type == MI_LIGHT_DIFFUSE_AREA && l.shape < 0 && (uint32_t)(~l.shape) < d->n_spheres) {
+                const mi_sphere &sp = d->spheres[~l.shape];   // Sphere::ObjectBound through ObjectToWorld (shape.cpp:50)
+                for (int c = 0; c < 8; ++c) {
+                    const float x = (c & 1) ? sp.radius : -sp.radius, y = (c & 2) ? sp.radius : -sp.radius, z = (c & 4) ? sp.z_max : sp.z_min;
+                    const float *m = sp.o2w;
+                    const float w = m[12] * x + m[13] * y + m[14] * z + m[15];
+                    add((m[0] * x + m[1] * y + m[2] * z + m[3]) / w, (m[4] * x + m[5] * y + m[6] * z + m[7]) / w, (m[8] * x + m[9] * y + m[10] * z + m[11]) / w);
+                }
+                have = true;
+            }
+            if (have) {
+                float scale = 0;
+                for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::abs(mn[a]), std::abs(mx[a])) + (mx[a] - mn[a]));
+                const float e = 1e-3f * scale;
+                lb[2 * i] = float4{mn[0] - e, mn[1] - e, mn[2] - e, 0};
+                lb[2 * i + 1] = float4{mx[0] + e, mx[1] + e, mx[2] + e, 0};
+            } else {   // not an area light: everything may hit
+                lb[2 * i] = float4{-INFINITY, -INFINITY, -INFINITY, 0};
+                lb[2 * i + 1] = float4{INFINITY, INFINITY, INFINITY, 0};
+            }
+        }
+        UP(lb.data(), lb.size(), s.lightBounds);
+    }
     UP(d->sampler.primes, d->sampler.n_dims, s.primes);
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
     UP(d->sampler.perms, d->sampler.n_perms, s.perms);
