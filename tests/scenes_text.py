@@ -706,6 +706,11 @@ def random_scene(seed, res=32, spp=8):
     out.append('AttributeBegin\n  AreaLightSource "diffuse" "rgb L" %s %s\n  Translate %.2f %.2f %.2f\n'
                '  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]\nAttributeEnd'
                % (rgb(5, 20), '"bool twosided" ["true"]' if rng.random() < .3 else "", r(-2, 2), r(4, 6), r(-2, 2)))
+    if rng.random() < .35:   # a quadric area light, possibly stretched and partial (every direction has a pdf: sphere.cpp:294-310)
+        out.append('AttributeBegin\n  AreaLightSource "diffuse" "rgb L" %s\n  Translate %.2f %.2f %.2f\n  Scale %.2f %.2f %.2f\n'
+                   '  Shape "sphere" "float radius" [%.2f]%s\nAttributeEnd'
+                   % (rgb(4, 15), r(-3, 3), r(2.5, 5), r(-3, 2), r(.6, 1.5), r(.6, 1.5), r(.6, 1.5), r(.2, .6),
+                      ' "float zmax" [%.2f]' % r(.05, .15) if rng.random() < .3 else ""))
     if rng.random() < .6:
         out.append('LightSource "point" "rgb I" %s "point from" [%.2f %.2f %.2f]' % (rgb(3, 15), r(-4, 4), r(2, 5), r(-5, 0)))
     if rng.random() < .4:
