@@ -29,7 +29,10 @@ for (x, y, k) in list(bad):
     if shown >= nshow: break
     d = integ.debug_path(x, y, k)
     o = ob.path_log(s, x, y, k)
-    if walk_all and len(d) == len(o) and np.array_equal(d[:, :20].view(np.uint32), o[:, :20].view(np.uint32)) \
+    dg, og = d[:, :20].copy(), o[:, :20].copy()
+    if len(d) == len(o):   # a path's last vertex spawns no ray that anything reads: what the two sides leave there differs
+        dg[-1, 12:15] = og[-1, 12:15] = 0; dg[-1, 16:20] = og[-1, 16:20] = 0
+    if walk_all and len(d) == len(o) and np.array_equal(dg.view(np.uint32), og.view(np.uint32)) \
             and np.allclose(d[:, 51:82], o[:, 51:82], rtol=1e-4, atol=1e-7, equal_nan=True) and not (np.isinf(d[:, 51:82]).any() or np.isnan(d[:, 51:82]).any() or (d[:, 51:82] < 0).any()): continue
     shown += 1
     print("pixel (%d,%d) k=%d: device %d vertices, oracle %d" % (x, y, k, len(d), len(o)))
