@@ -5,7 +5,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[1].split("::")[-1] if "anonymous" in row["Kernel_Name"] else row["Kernel_Name"][:30]
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("dptk::", "")
+            if k.startswith("void "): k = k[5:]
+            k = k.split("(")[0]   # k_trav<0, false, 4, false>
             a = agg[k][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"]); a[1] += 1
 for k in sorted(agg):
