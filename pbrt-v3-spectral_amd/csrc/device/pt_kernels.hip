@@ -1977,12 +1977,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         }
                         tile.q[c][threadIdx.x] = bt;
                     }
-                    StoreSpectrumLines(tile, pool, Q_BETA, slot, true);
-                    betaWritten = true;
+                    // (the new throughput is stored below, once it is known that a later vertex will read it)
+                    bool killed = false;
                     if (fNonBlack) {
-                        Ray nr = SpawnRay(isect, wi);
                         // Russian roulette, path.cpp:176-184
-                        bool killed = false;
                         if (maxRR < s.rrThreshold && bounces > 3) {
                             float q = maxf(.05f, 1 - maxRR);
                             if (Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot) < q) killed = true;
@@ -1990,16 +1988,25 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 const Divisor inv = MakeDivisor(1 - q);
 #pragma unroll 1
                                 for (int c = 0; c < NQ; ++c) {
-                                    float4 bt = tile.q[c][threadIdx.x];   // (the new beta, still parked in the tile)
+                                    float4 bt = tile.q[c][threadIdx.x];   // (the new beta, parked in the tile)
 #pragma unroll
                                     for (int k = 0; k < 4; ++k)
                                         if (4 * c + k < MI_NSPEC) Set4(bt, k, DivBy(Get4(bt, k), inv));
-                                    pool.Q(Q_BETA + c, slot) = bt;
+                                    tile.q[c][threadIdx.x] = bt;
                                 }
                             }
                         }
+                    }
+                    // the next vertex reads the throughput if it is shaded (bounces + 1 < maxDepth) or may show emitted
+                    // light (after a specular bounce, path.cpp:91-101); a path that ends here, or whose last ray only
+                    // has to be traced, leaves none behind
+                    const bool needBeta = fNonBlack && !killed && (bounces + 1 < s.maxDepth || (sflags & MI_BSDF_SPECULAR));
+                    StoreSpectrumLines(tile, pool, Q_BETA, slot, needBeta);
+                    if (needBeta) betaWritten = true;
+                    if (fNonBlack) {
                         if (killed) finished = true;
                         else {
+                            const Ray nr = SpawnRay(isect, wi);
                             pool.R(R_RAY0, slot) = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.tMax);
                             pool.R(R_RAY1, slot) = make_float4(nr.d.x, nr.d.y, nr.d.z, etaScale);
                             if (sflags & MI_BSDF_SPECULAR) newFlags |= F_SPECULAR;
