@@ -1260,7 +1260,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     __shared__ float sFilter[256];  // the 16x16 filter table, one LDS copy per block
     __shared__ unsigned sWant[SLOT_CHUNKS][BLOCK / 64], sPrim[SLOT_CHUNKS][BLOCK / 64], sCont[SLOT_CHUNKS][BLOCK / 64];
     __shared__ unsigned long long sWorkBase;
-    __shared__ unsigned sPrimBase, sContBase;
+    __shared__ unsigned sPrimBase, sContBase, sTotWant;
     sFilter[threadIdx.x] = s.filterTable[threadIdx.x];
     __syncthreads();
     unsigned bad = 0, cam = 0;
@@ -1454,15 +1454,34 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
             for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sWant[ch][w]; sWant[ch][w] = tot; tot += n; }
         sWorkBase = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : ~0ull;
+        sTotWant = tot;
     }
     __syncthreads();
     // ---------------------------------------------------------------- pass 2: refill
-    bool anyAlive = false;
+    // The free slots are a third of the block's slots, spread over all chunks: they are listed (in slot order, so work item
+    // base + i still goes to the i-th free slot) and refilled by all lanes together -- the camera sample (index of the
+    // Halton / Sobol' sample, five dimensions, the camera ray) runs on full waves.
+    unsigned short *sFree = (unsigned short *)sL;                 // (pass 1's rows are dead now)
+    unsigned char *sGot = (unsigned char *)(sL + SLOT_CHUNKS * BLOCK / 2);
 #pragma unroll 1
     for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
-        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
-        const bool want = (wantBits >> ch) & 1u, restart = (restartBits >> ch) & 1u;
+        const bool want = (wantBits >> ch) & 1u;
         const unsigned long long wm = __ballot(want);
+        if (want) sFree[sWant[ch][wave] + (unsigned)__popcll(wm & ltMask)] = (unsigned short)(ch * BLOCK + threadIdx.x);
+        sGot[ch * BLOCK + threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const unsigned totWant = sTotWant;
+    const unsigned nRounds = (nBands > 1) ? SLOT_CHUNKS : 0;   // spectralpath: the restarting slots, chunk by chunk as before
+    bool anyAlive = false;
+#pragma unroll 1
+    for (unsigned it = 0; it < nRounds + (totWant + BLOCK - 1) / BLOCK; ++it) {
+        const bool restartRound = it < nRounds;
+        unsigned e = 0;
+        bool want = false, restart = false;
+        if (restartRound) { e = it * BLOCK + threadIdx.x; restart = (restartBits >> it) & 1u; }
+        else { const unsigned i = (it - nRounds) * BLOCK + threadIdx.x; want = i < totWant; if (want) e = sFree[i]; }
+        const uint32_t slot = blockIdx.x * SLOT_CHUNKS * BLOCK + e;
         bool got = false;
         int px = 0, py = 0, band = 0;
         long long sampleNum = 0;
@@ -1474,7 +1493,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             got = true;
         }
         if (want) {
-            const unsigned long long w = sWorkBase + sWant[ch][wave] + (unsigned long long)__popcll(wm & ltMask);
+            const unsigned long long w = sWorkBase + (unsigned long long)((it - nRounds) * BLOCK + threadIdx.x);
             if (w < wd.totalWork) {
                 // work order: runs of wd.run consecutive samples of a pixel, pixel by pixel through the shard's tiles, then
                 // the next run (so the lanes of a wave hold neighbouring samples of a few pixels: the most coherent camera
@@ -1521,8 +1540,14 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             }
             pool.I(I_BOUNCES, slot) = 0;
             pool.I(I_FLAGS, slot) = F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF;   // L = 0, beta = 1, not stored
-            gotBits |= 1u << ch;
+            sGot[e] = 1;
         } else if (want) pool.I(I_FLAGS, slot) = 0;   // stays free (its finished path has been flushed)
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+        const bool got = sGot[ch * BLOCK + threadIdx.x] != 0;
+        if (got) gotBits |= 1u << ch;
         const bool isCont = ((contBits >> ch) & 1u) != 0;
         anyAlive |= got || isCont;
         // the extend work list: new camera rays first (lanes of a traversal wave then hold neighbouring samples)
