@@ -3033,8 +3033,9 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
     wd.sampleBegin = rp->sample_begin;
     wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
-    int runCap = 16;   // (same-box A/B: 16 gives the shortest frame; longer runs shave k_generate further but put one pixel's
-                       // paths into whole waves of the other kernels, which costs them 2-5 %)
+    int runCap = 64;   // (same-box A/B at the end of round 2: 16 -> 64 takes 4 % off k_generate and 1 % off the camera-ray
+                       // traversal, the other kernels unchanged -- 3596 -> 3620 Mray/s; 128 ... 1024 measure the same as 64.
+                       // Earlier in the round longer runs cost the shading kernels 2-5 % and 16 was the optimum.)
     if (const char *e = getenv("MIPT_WORK_RUN")) runCap = std::max(1, atoi(e));
     wd.run = 1;
     while (2 * wd.run <= runCap && wd.spp % (2 * wd.run) == 0) wd.run *= 2;
