@@ -3044,7 +3044,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
     // Default pool: half of the samples to render (round 2: a 1/8 shard of the killeroo frame takes 0.1196 s with the
-    // quarter's 16M slots, 0.1169 s with 32M), at most 32M slots in total (22 GB of path state)
+    // quarter's 16M slots, 0.1169 s with 32M), at most 96M slots in total (below)
     // and at least 4M (8M per sub-renderer when several share the GPU): bigger pools mean fewer, better-filled
     // launches, but the last iterations of a render drain the pool at low occupancy, which a small job (one
     // shard of a multi-GPU frame) feels. Measured on the 1024-spp killeroo frame and its shards
@@ -3055,7 +3055,11 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     if (poolN == 0) {
         const unsigned long long quarter = wd.totalWork * (unsigned long long)subCount / 2;
         const unsigned long long floorN = subCount > 1 ? (8ull << 20) * (unsigned long long)subCount : (1ull << 22);
-        poolN = (uint32_t)std::min<unsigned long long>(1ull << 25, std::max<unsigned long long>(floorN, quarter));   // (`quarter`: half, since round 2)
+        // (`quarter`: half, since round 2.) The cap: 96M slots = 77 GB of path state of the 288 GB. With the kernels of the end
+        // of round 2 bigger pools pay again (fewer, longer launches: the persistent traversal kernels lose less to their
+        // tails, k_shade and k_generate no longer slow down): killeroo 1024 spp 3740 Mray/s at 32M, 3880 at 64M, 3912 at
+        // 96M, 3931 at 128M; the 10M-triangle scene +0.4 %, cornell-glass -0.3 % at 64M.
+        poolN = (uint32_t)std::min<unsigned long long>(3ull << 25, std::max<unsigned long long>(floorN, quarter));
     }
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
