@@ -3043,7 +3043,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     for (double &t : sub.t) t = 0;
     sub.result = DevCounters{};
     if (wd.totalWork == 0) return MI_OK;
-    // Default pool: half of the samples to render (round 2: a 1/8 shard of the killeroo frame takes 0.1196 s with the
+    // Default pool: one slot per sample to render, up to the cap (earlier in round 2, at half: a 1/8 shard took 0.1196 s with the
     // quarter's 16M slots, 0.1169 s with 32M), at most 96M slots in total (below)
     // and at least 4M (8M per sub-renderer when several share the GPU): bigger pools mean fewer, better-filled
     // launches, but the last iterations of a render drain the pool at low occupancy, which a small job (one
@@ -3053,7 +3053,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     // (the path state outgrows the TLB reach), no gain for the full frame.
     uint32_t poolN = rp->path_pool;
     if (poolN == 0) {
-        const unsigned long long quarter = wd.totalWork * (unsigned long long)subCount / 2;
+        const unsigned long long quarter = wd.totalWork * (unsigned long long)subCount;   // (all of them: a 1/8 shard of the killeroo frame takes 0.1071 s on 32M slots, 0.1046 s on 64M)
         const unsigned long long floorN = subCount > 1 ? (8ull << 20) * (unsigned long long)subCount : (1ull << 22);
         // (`quarter`: half, since round 2.) The cap: 96M slots = 77 GB of path state of the 288 GB. With the kernels of the end
         // of round 2 bigger pools pay again (fewer, longer launches: the persistent traversal kernels lose less to their
