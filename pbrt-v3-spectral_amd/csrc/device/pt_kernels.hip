@@ -3065,6 +3065,12 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
     int rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
+    // the default size is a preference, not a requirement: on a device that cannot hold it the render goes on with half,
+    // a quarter, ... (an explicit mi_render_params.path_pool is taken at its word and fails)
+    while (rc == MI_ERR_NOMEM && rp->path_pool == 0 && poolN > (1u << 22)) {
+        poolN = poolN / 2 / BLOCK * BLOCK;
+        rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
+    }
     if (rc != MI_OK) return rc;
     HIPCHK(hipMemsetAsync(sub.pool.i + (size_t)I_FLAGS * poolN, 0, (size_t)poolN * sizeof(int), st));
     HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));

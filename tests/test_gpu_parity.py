@@ -490,6 +490,22 @@ def test_texture_lookups_bit_for_bit(pt, ob, tmp_path):
         assert np.allclose(dev, ref, rtol=2e-5, atol=1e-7), (tex, np.abs(dev - ref).max())
 
 
+def test_a_pool_that_cannot_be_allocated_is_an_error_and_leaves_the_renderer_usable(pt, ob):
+    """mi_render_params.path_pool is taken at its word: a pool the device cannot hold fails with an error code (no launch on
+    half-built buffers), and the next render with the default pool is the oracle's."""
+    big = pt.Scene(CORNELL, spp=1 << 20, xres=64, yres=64)   # 4.3e9 samples: the pool is not clamped by the work
+    integ = pt.CreatePathIntegrator(big)
+    with pytest.raises(RuntimeError, match="hipMalloc|pool"):
+        integ.Render(path_pool=(1 << 31) - 256)   # ~1.7 TB of path state
+    film, weight = integ.Render(spp=4)
+    s = pt.Scene(CORNELL, spp=4, xres=64, yres=64)
+    with ob.exact_libm():
+        ofilm, oweight, oc, _ = ob.render(s)
+    assert _rel_l2(film, ofilm) < 1e-6 and np.array_equal(weight, oweight)
+    c, o = integ.counters.as_dict(), oc.as_dict()
+    assert all(c[k] == o[k] for k in ("camera_rays", "regular_rays", "shadow_rays", "total_paths"))
+
+
 def test_rays_with_more_quadrics_than_the_pending_list_holds(pt, ob):
     """k_trav postpones the quadrics a ray meets (four per ray); a ray that meets more is handed to k_resolve_overflow, which
     re-traverses it in the reference's order with inline quadric tests and commits it like the resolve kernel would have:
