@@ -269,6 +269,10 @@ constexpr unsigned TM_LIGHTS_ALL = 0x1fu << 24;
 constexpr unsigned TM_LIGHTS_NO_ENV = TM_LIGHTS_ALL & ~(1u << (24 + MI_LIGHT_INFINITE));
 constexpr unsigned TM_DIFFUSE = (1u << MI_BXDF_LAMBERTIAN_REFLECTION) | (1u << MI_BXDF_OREN_NAYAR) | (1u << (16 + MI_FRESNEL_NOOP));
 constexpr unsigned TM_PLASTIC = TM_DIFFUSE | (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << (16 + MI_FRESNEL_DIELECTRIC));
+// the lobes "glass" and "mirror" make (glass.cpp:60-92, mirror.cpp:46-56): specular and rough dielectric interfaces
+constexpr unsigned TM_GLASS = (1u << MI_BXDF_SPECULAR_REFLECTION) | (1u << MI_BXDF_SPECULAR_TRANSMISSION) | (1u << MI_BXDF_FRESNEL_SPECULAR) |
+                              (1u << MI_BXDF_MICROFACET_REFLECTION) | (1u << MI_BXDF_MICROFACET_TRANSMISSION) |
+                              (1u << (16 + MI_FRESNEL_DIELECTRIC)) | (1u << (16 + MI_FRESNEL_NOOP));
 // the lobes "uber" makes (uber.cpp:60-105; "translucent"'s fit as well) and the ones "disney" makes (disney.cpp:474-587)
 constexpr unsigned TM_UBER = TM_PLASTIC | (1u << MI_BXDF_SPECULAR_REFLECTION) | (1u << MI_BXDF_SPECULAR_TRANSMISSION) |
                              (1u << MI_BXDF_MICROFACET_TRANSMISSION) | (1u << MI_BXDF_LAMBERTIAN_TRANSMISSION);

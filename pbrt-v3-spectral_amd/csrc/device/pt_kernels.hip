@@ -2198,7 +2198,7 @@ constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_
     X(2, TM_DIFFUSE | TM_LIGHTS_ALL) X(2, TM_DIFFUSE | TM_LIGHTS_NO_ENV) X(2, TM_DIFFUSE | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_DIFFUSE | TM_LIGHTS_NO_ENV | TM_SAMPLERS)
 #define MIPT_SHADE_GROUP_2(X) X(MI_MAX_BXDFS, TM_FULL) X(2, TM_ALL) X(2, TM_FULL) \
     X(2, TM_PLASTIC | TM_LIGHTS_ALL) X(2, TM_PLASTIC | TM_LIGHTS_NO_ENV) X(2, TM_PLASTIC | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_PLASTIC | TM_LIGHTS_NO_ENV | TM_SAMPLERS)
-#define MIPT_SHADE_GROUP_3(X) X(MI_MAX_BXDFS, TM_GENERIC) X(4, TM_FULL) X(4, TM_UBER | TM_LIGHTS_ALL | TM_SAMPLERS) X(MI_MAX_BXDFS, TM_DISNEY | TM_LIGHTS_ALL | TM_SAMPLERS) \
+#define MIPT_SHADE_GROUP_3(X) X(MI_MAX_BXDFS, TM_GENERIC) X(4, TM_FULL) X(2, TM_GLASS | TM_LIGHTS_ALL | TM_SAMPLERS) X(4, TM_UBER | TM_LIGHTS_ALL | TM_SAMPLERS) X(MI_MAX_BXDFS, TM_DISNEY | TM_LIGHTS_ALL | TM_SAMPLERS) \
     X(2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS)
 #define MIPT_SHADE_DEFINE(NL_, TM_) template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
 #define MIPT_SHADE_EXTERN(NL_, TM_) extern template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
@@ -2253,6 +2253,7 @@ struct mi_pt {
     bool hasInfiniteLight = false;   // picks the kernels compiled with the environment-light code
     unsigned diffuseClasses = 0, plasticClasses = 0;
     unsigned texturedDiffuse = 0, texturedPlastic = 0;           // textured classes that fit the diffuse / plastic lobe masks
+    unsigned glassClasses = 0;                                   // untextured glass / mirror lobe sets (<= 2 lobes)
     unsigned uberClasses = 0, disneyClasses = 0;                 // untextured uber-like (<= 4 lobes) and Disney lobe sets: instances of their own
     unsigned mediumClasses = 0, texturedMedium = 0;              // 3- and 4-lobe classes (uber with Kr / Kt, translucent): 4-lobe instances
     unsigned texturedSmall = 0, texturedLarge = 0;               // classes of image-textured materials (taken out of small / largeClasses)              // subsets of smallClasses run by the lobe-specialised kernels
@@ -2606,9 +2607,13 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             if ((classTypes[c] & ~TM_DIFFUSE) == 0) pt->diffuseClasses |= 1u << c;
             else if ((classTypes[c] & ~TM_PLASTIC) == 0) pt->plasticClasses |= 1u << c;
         }
-        if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = 0;
+        for (int c = 0; c < MISS_CLASS; ++c)
+            if (((pt->smallClasses >> c) & 1u) && !((pt->diffuseClasses | pt->plasticClasses) >> c & 1u) && !(classTypes[c] & TM_TEXTURED) &&
+                (classTypes[c] & ~TM_GLASS) == 0)
+                pt->glassClasses |= 1u << c;
+        if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = pt->glassClasses = 0;
         if (getenv("MIPT_ALL_LIGHTS")) pt->hasInfiniteLight = true;
-        pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses);
+        pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses | pt->glassClasses);
         for (int c = 0; c < MISS_CLASS; ++c)
             if (classTypes[c] & TM_TEXTURED) {
                 if (((pt->smallClasses >> c) & 1u) && !getenv("MIPT_NO_SPECIALISE")) {
@@ -2985,7 +2990,7 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     hipStream_t st = sub.stream;
     const dim3 shadeGrid(grid.x + MAX_CLASSES);
     if (pt->hasInstances) {   // scenes with object instances: the two fully general instances of the kernel, by lobe count
-        const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
+        const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->glassClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
         const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge | pt->uberClasses | pt->disneyClasses;
         if (two) hipLaunchKernelGGL((k_shade<2, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, two);
         if (more) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_ALL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, more);
@@ -3003,6 +3008,7 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
 #undef SHADE_LAUNCH_HOT
 #undef SHADE_LAUNCH
     if (pt->smallClasses) hipLaunchKernelGGL((k_shade<2, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->smallClasses);
+    if (pt->glassClasses) hipLaunchKernelGGL((k_shade<2, TM_GLASS | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->glassClasses);
     if (pt->uberClasses) hipLaunchKernelGGL((k_shade<4, TM_UBER | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->uberClasses);
     if (pt->disneyClasses) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_DISNEY | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->disneyClasses);
     if (pt->mediumClasses) hipLaunchKernelGGL((k_shade<4, TM_GENERIC>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->mediumClasses);
