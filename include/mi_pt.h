@@ -400,6 +400,20 @@ const char *mi_pt_last_error(void);
  * semantics (prim = 0/-1 only). Host pointers. */
 int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hits);
 
+/* The same question answered by the kernels a render launches (mi_pt_trace runs a plain per-ray routine, k_trace): ray i is
+ * loaded into slot i of a path pool and a work list as the pipeline leaves it, traversed by the persistent wavefront kernel
+ * of its class (batched state machine, cooperative leaf test, postponed quadrics, instance return entries) and committed by
+ * that class's resolve step. Restates BVHAccel::Intersect / IntersectP (src/accelerators/bvh.cpp:662-738).
+ *   mode 0: path rays -- k_trav<0>, k_resolve_extend, k_resolve_overflow; closest hit, tMax as given.
+ *   mode 1: NEE shadow rays -- k_trav<1>, k_resolve_shadow, k_resolve_overflow; any hit (prim = 0 / -1); d is the
+ *           unnormalised vector to the light sample and tMax must be 1 - 0.0001f (Interaction::SpawnRayTo).
+ *   mode 2: BSDF-sampled MIS rays -- k_trav<2>, then the quadric step of k_resolve_mis (the same device function; that
+ *           kernel consumes the hit in place); closest hit, tMax must be +infinity (Interaction::SpawnRay).
+ * hits: as mi_pt_trace. extra (may be NULL): n x 4 words {b2 (float), instance of the hit (int32 bits, -1 = none),
+ * I_NPEND as the traversal kernel left it (int32 bits: count of postponed quadrics | 0x100 on overflow),
+ * I_HITPRIM as the traversal kernel left it, before the quadric step (int32 bits)}. Host pointers; n <= 2^24. */
+int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra);
+
 /* Parity tool for image textures: MIPMap<RGBSpectrum>::Lookup(st, dstdx, dstdy) (src/core/mipmap.h:281-319) of texture
  * `tex` for n queries on the device. queries: 6 floats each (s, t, dsdx, dtdx, dsdy, dtdy) in texture space, i.e. after
  * the UVMapping2D; rgb: 3 floats per query. */

@@ -221,6 +221,7 @@ def hip_lib():
         lib.mi_pt_destroy.argtypes = [C.c_void_p]
         lib.mi_pt_last_error.restype = C.c_char_p
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+        lib.mi_pt_trace_wavefront.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_texture_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_light_distribution.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
         lib.mi_pt_debug_path.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -378,6 +379,18 @@ class PathIntegrator:
             raise RuntimeError("mi_pt_trace failed: %s" % hip_lib().mi_pt_last_error().decode())
         return hits
 
+    def trace_wavefront(self, rays, mode=0):
+        """The rays through the render's own kernels (mi_pt_trace_wavefront): mode 0 path rays (k_trav<0> + resolve),
+        1 shadow rays (tMax = 1 - 0.0001f), 2 MIS rays (tMax = inf). Returns (hits [n, 4] as trace(), extra [n, 4] int32 view:
+        b2 bits, hit instance, raw I_NPEND, raw I_HITPRIM)."""
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        hits = np.zeros((n, 4), np.float32)
+        extra = np.zeros((n, 4), np.float32)
+        rc = hip_lib().mi_pt_trace_wavefront(self._h, _fptr(rays), n, int(mode), _fptr(hits), _fptr(extra))
+        if rc != 0:
+            raise RuntimeError("mi_pt_trace_wavefront failed: %s" % hip_lib().mi_pt_last_error().decode())
+        return hits, extra.view(np.int32)
 
     def light_distribution(self):
         """The spatial light-selection tables built at create: (func [nz, ny, nx, n_lights], funcInt [nz, ny, nx])."""

@@ -2181,6 +2181,79 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, ui
     o[3] = (prim >= 0 && !anyHit) ? h.b1 : 0.f;
 }
 
+// ------------------------------------------------------------------ recorded rays through the render's own kernels (mi_pt_trace_wavefront)
+// Loads ray i into slot i of the pool exactly as k_generate / k_shade leave a path ray (mode 0), an NEE shadow ray (1) or a
+// BSDF-sampled MIS ray (2), and lists it in that mode's work list. The shadow mode's flags make k_resolve_shadow's commit
+// readable without a spectrum: the light sample "already sits in L" (F_NEE_IN_L), so an unoccluded ray only clears F_L_ZERO.
+__global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ctr, const float *rays, uint32_t n, int mode) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) {
+        if (mode == 0) { ctr->primCount.v = n; ctr->contCount.v = 0; }
+        else if (mode == 1) ctr->shadowCount.v = n;
+        else ctr->misCount.v = n;
+    }
+    if (i >= pool.n) return;
+    int flags = 0;
+    if (i < n) {
+        const float *r = rays + (size_t)i * 7;
+        if (mode == 0) {
+            pool.R(R_RAY0, i) = make_float4(r[0], r[1], r[2], r[6]);
+            pool.R(R_RAY1, i) = make_float4(r[3], r[4], r[5], 1.f);
+            pool.extQ[i] = i;
+            flags = F_ALIVE;
+        } else {
+            pool.R(mode == 1 ? R_SH0 : R_MI0, i) = make_float4(r[0], r[1], r[2], r[3]);
+            pool.R(mode == 1 ? R_SH1 : R_MI1, i) = make_float4(r[4], r[5], 0.f, 0.f);
+            (mode == 1 ? pool.shadowQ : pool.misQ)[i] = i;
+            flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_NEE_IN_L | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
+        }
+        pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
+        pool.I(I_NPEND, i) = 0;
+        pool.I(I_HITINST, i) = -1;
+        pool.I(I_MISLIGHT, i) = 0;
+    }
+    pool.I(I_FLAGS, i) = flags;
+}
+// what k_trav left in the planes, before the resolve step
+__global__ void __launch_bounds__(BLOCK) k_trace_raw(Pool pool, uint32_t n, float *extra) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    extra[4 * (size_t)i + 2] = __int_as_float(pool.I(I_NPEND, i));
+    extra[4 * (size_t)i + 3] = __int_as_float(pool.I(I_HITPRIM, i));
+}
+// The committed answer. Mode 0: the planes as k_resolve_extend / k_resolve_overflow left them. Mode 1: k_resolve_shadow's
+// verdict (see k_trace_load). Mode 2: k_resolve_mis consumes its hit in place (ResolveMisSlot), so the quadric step is run
+// here with the same device function and arguments it uses.
+template <bool INST>
+__global__ void __launch_bounds__(BLOCK) k_trace_read(DScene s, Pool pool, uint32_t n, int mode, float *hits, float *extra) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int prim = pool.I(I_HITPRIM, i), inst = -1;
+    float4 hr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 0) { hr = pool.R(R_HIT, i); if (INST) inst = pool.I(I_HITINST, i); }
+    else if (mode == 1) prim = (pool.I(I_FLAGS, i) & F_L_ZERO) ? 0 : -1;
+    else {
+        const float4 r0 = pool.R(R_MI0, i), r1 = pool.R(R_MI1, i);
+        const V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+        hr = pool.R(R_HIT, i);
+        Hit h;
+        h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
+        bool found = prim >= 0;
+        unsigned nodes = 0, tris = 0;
+        const int npend = pool.I(I_NPEND, i);
+        if (npend & PEND_OVERFLOW) found = ResolveQuadrics<false, INST, true>(s, pool, i, ro, rd, kInfinity, &h, found, nodes, tris);
+        else if (npend != 0) found = ResolveQuadrics<false, INST, false>(s, pool, i, ro, rd, kInfinity, &h, found, nodes, tris);
+        prim = found ? h.prim : -1;
+        hr = make_float4(h.t, h.b0, h.b1, h.b2);
+        inst = h.inst;
+    }
+    const bool rec = prim >= 0 && mode != 1;
+    float *o = hits + (size_t)i * 4;
+    o[0] = __int_as_float(prim);
+    o[1] = rec ? hr.x : 0.f; o[2] = rec ? hr.y : 0.f; o[3] = rec ? hr.z : 0.f;
+    if (extra) { extra[4 * (size_t)i] = rec ? hr.w : 0.f; extra[4 * (size_t)i + 1] = __int_as_float(rec ? inst : -1); }
+}
+
 __global__ void k_film_split(const float *film32, float *filmSum, float *weightSum, size_t nPix) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPix * 32) return;
@@ -3383,6 +3456,54 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hits, dh.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra) {
+    if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { g_err = "mi_pt_trace_wavefront: mode must be 0 (path rays), 1 (shadow rays) or 2 (MIS rays)"; return MI_ERR_INVALID; }
+    if (n == 0) return MI_OK;
+    if (n > (1u << 24)) { g_err = "mi_pt_trace_wavefront: at most 16M rays per call"; return MI_ERR_INVALID; }
+    // the kernels fix what the render fixes: a shadow ray ends at 1 - ShadowEpsilon (Interaction::SpawnRayTo), a BSDF-sampled
+    // ray never ends (SpawnRay)
+    for (uint32_t i = 0; i < n && mode != 0; ++i) {
+        const float tMax = rays[(size_t)i * 7 + 6];
+        if (mode == 1 ? tMax != 1 - kShadowEpsilon : !std::isinf(tMax) || tMax < 0) {
+            g_err = mode == 1 ? "mi_pt_trace_wavefront: shadow rays (mode 1) carry tMax = 1 - 0.0001f" : "mi_pt_trace_wavefront: MIS rays (mode 2) carry tMax = +infinity";
+            return MI_ERR_INVALID;
+        }
+    }
+    HIPCHK(hipSetDevice(pt->device));
+    SubRenderer &sub = pt->subs[0];
+    hipStream_t st = sub.stream;
+    const DScene &s = pt->scene;
+    const uint32_t poolN = (n + SLOT_CHUNKS * BLOCK - 1) / (SLOT_CHUNKS * BLOCK) * (SLOT_CHUNKS * BLOCK);
+    int rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
+    if (rc != MI_OK) return rc;
+    struct PoolGuard { SubRenderer &sub; ~PoolGuard() { FreePool(sub.pool); sub.poolQuadPlanes = 0; } } guard{sub};   // the next render sizes its own
+    DevBuf dr, dh, dx;
+    HIPCHK(dr.alloc((size_t)n * 7 * sizeof(float)));
+    HIPCHK(dh.alloc((size_t)n * 4 * sizeof(float)));
+    HIPCHK(dx.alloc((size_t)n * 4 * sizeof(float)));
+    HIPCHK(hipMemcpy(dr.p, rays, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(sub.ctr, 0, sizeof(DevCounters), st));
+    const dim3 grid(poolN / BLOCK), block(BLOCK);
+    const dim3 chunkGrid(grid.x / SLOT_CHUNKS);
+    const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
+    hipLaunchKernelGGL(k_trace_load, grid, block, 0, st, sub.pool, sub.ctr, dr.as<float>(), n, mode);
+    LaunchTraversal(pt, sub, mode, travGrid);
+    hipLaunchKernelGGL(k_trace_raw, grid, block, 0, st, sub.pool, n, dx.as<float>());
+    const bool inst = pt->hasInstances;
+#define MIPT_BY_INST(K, G, ...) do { if (inst) hipLaunchKernelGGL((K<true>), G, block, 0, st, __VA_ARGS__); else hipLaunchKernelGGL((K<false>), G, block, 0, st, __VA_ARGS__); } while (0)
+    if (mode == 0) MIPT_BY_INST(k_resolve_extend, chunkGrid, s, sub.pool, sub.ctr);
+    else if (mode == 1) MIPT_BY_INST(k_resolve_shadow, grid, s, sub.pool, sub.ctr);
+    if (mode != 2 && pt->hasQuadrics) MIPT_BY_INST(k_resolve_overflow, dim3(OVERFLOW_GRID), s, sub.pool, sub.ctr, mode);
+    MIPT_BY_INST(k_trace_read, grid, s, sub.pool, n, mode, dh.as<float>(), dx.as<float>());
+#undef MIPT_BY_INST
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hits, dh.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (extra) HIPCHK(hipMemcpy(extra, dx.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -67,6 +67,17 @@ def test_gpu_traversal_matches_the_golden_rays_bit_exactly(pt):
     integ = pt.CreatePathIntegrator(pt.Scene(KILLEROO, spp=1))
     assert np.array_equal(integ.trace(z["rays"], any_hit=False).view(np.int32), z["closest"])
     assert np.array_equal(integ.trace(z["rays"], any_hit=True).view(np.int32)[:, 0], z["anyhit"])
+    _wavefront_against_fixture(integ, z)
+
+
+def _wavefront_against_fixture(integ, z):
+    """The same recorded rays through the kernels the render launches: k_trav<0> + resolve against the fixture bit for bit;
+    the unbounded (k_trav<2>) and shadow-form (k_trav<1>) variants of the rays against k_trace, which the fixture pins."""
+    import trace_check as tc
+    closest_dev, occluded_dev = tc.device_answers(integ)
+    rays = np.ascontiguousarray(z["rays"], np.float32)
+    closest = lambda r: z["closest"].view(np.float32) if np.array_equal(r, rays, equal_nan=True) else closest_dev(r)
+    tc.check_wavefront(integ, rays, closest, occluded_dev)
 
 
 def _check_against_fixture(film, weight, z, spp, tol, frac_over, max_over, exact_max=2e-4):
@@ -161,6 +172,7 @@ def _full_frame_against_tiles(pt, s, z, counters, exact, tol, frac_over, max_ove
     if "rays" in z:   # recorded rays: hit primitive, t and barycentrics bitwise, closest-hit and any-hit
         assert np.array_equal(integ.trace(z["rays"], any_hit=False).view(np.int32), z["closest"])
         assert np.array_equal(integ.trace(z["rays"], any_hit=True).view(np.int32)[:, 0], z["anyhit"])
+        _wavefront_against_fixture(integ, z)
     full, wfull = integ.Render()
     c = integ.counters.as_dict()
     assert c["camera_rays"] == w * h * spp and c["bad_samples"] == 0

@@ -26,6 +26,7 @@ import pytest
 
 from conftest import KILLEROO, CORNELL, ROOT
 import scenes_text as st
+import trace_check as tc
 
 pytestmark = pytest.mark.gpu
 
@@ -102,7 +103,8 @@ def _parity(pt, ob, s, name, exact=True, rel_tol=None, counter_tol=None, weights
 
 def test_traversal_kernel_matches_oracle_bit_exactly(pt, ob):
     """BVH2 traversal on recorded rays: same primitive, same t and barycentrics (bitwise),
-    closest-hit and any-hit, coherent camera rays and incoherent random rays."""
+    closest-hit and any-hit, coherent camera rays and incoherent random rays -- answered by the per-ray routine of
+    mi_pt_trace (k_trace) AND by the kernels the render launches (mi_pt_trace_wavefront: k_trav<0>, <1>, <2> + resolve)."""
     s = pt.Scene(KILLEROO, spp=1)
     integ = pt.CreatePathIntegrator(s)
     rng = np.random.default_rng(5)
@@ -118,7 +120,59 @@ def test_traversal_kernel_matches_oracle_bit_exactly(pt, ob):
             want, _ = ob.trace(s, rays, any_hit=any_hit)
             got = integ.trace(rays, any_hit=any_hit)
             assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        hits, extra = tc.check_wavefront(integ, rays, *tc.oracle_answers(ob, s))
+        # the sphere light is a postponed quadric for the rays that meet it (I_NPEND as k_trav left it)
+        assert ((extra[:, 2] & 0xff) > 0).any() and ((extra[:, 2] & 0x100) == 0).all()
     assert (ob.trace(s, cam)[0].view(np.int32)[:, 0] >= 0).mean() > 0.5
+
+
+def _stacked_sheets_scene(pt, seed=11):
+    """Triangles that tie: a 6 x 6 sheet of quads, each present four times in ONE mesh -- twice at z = 5 exactly (coplanar
+    duplicates: equal t, the tie goes by leaf order) and once each an ulp or two in front of and behind it (two hits of one
+    leaf inside the tMax-dependent rejection of triangle.cpp:262-266). Equal centroids end in one leaf (bvh.cpp:289-300)."""
+    rng = np.random.default_rng(seed)
+    P, idx = [], []
+    ulp = float(np.spacing(np.float32(5)))
+    for cy in range(6):
+        for cx in range(6):
+            x0, y0 = -3 + cx, -3 + cy
+            for dz in (0.0, 0.0, ulp * int(rng.integers(1, 3)), -ulp * int(rng.integers(1, 3))):
+                b = len(P)
+                P += [(x0, y0, 5 + dz), (x0 + 1, y0, 5 + dz), (x0 + 1, y0 + 1, 5 + dz), (x0, y0 + 1, 5 + dz)]
+                idx += [b, b + 1, b + 2, b, b + 2, b + 3]
+    body = ('Shape "trianglemesh" "integer indices" [%s] "point P" [%s]\n'
+            % (" ".join(map(str, idx)), " ".join(repr(float(np.float32(v))) for p in P for v in p)))
+    return pt.Scene(text=st._HEAD % dict(res=8, spp=1, depth=1, extra="") + 'LightSource "point" "rgb I" [1 1 1]\n' + body + "WorldEnd\n")
+
+
+@pytest.mark.parametrize("env", [{}, {"MIPT_BVH_WIDTH": "2"}, {"MIPT_NO_COOP_LEAVES": "1"}])
+def test_ties_and_near_ties_inside_a_leaf(pt, ob, monkeypatch, env):
+    """BVHAccel::Intersect's sequential leaf loop (bvh.cpp:676-682) decides ties by order and lets a second hit through only
+    if Triangle::Intersect's tScaled test passes against the tMax the first one left: k_trav tests a leaf's triangles
+    side by side (cooperative test) and replays that sequence. Bit-equal hit records against the oracle for the
+    two-level records, the BVH2 records (W = 2) and the one-primitive-per-pass leaf path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = _stacked_sheets_scene(pt)
+    assert s.errors == [] and s.stats["n_triangles"] == 6 * 6 * 4 * 2
+    leaves = [int(s.desc.nodes[i].n_prims) for i in range(s.desc.n_nodes) if s.desc.nodes[i].n_prims > 0]
+    assert max(leaves) >= 4   # (several copies of a triangle share a leaf)
+    integ = pt.CreatePathIntegrator(s)
+    rng = np.random.default_rng(17)
+    n = 60000
+    o = np.stack([rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), np.where(rng.random(n) < .5, rng.uniform(-2, 4.5, n), rng.uniform(5.5, 9, n))], -1).astype(np.float32)
+    tgt = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), np.full(n, 5.0)], -1).astype(np.float32)
+    d = tgt - o
+    norm = rng.random(n) < .5
+    d[norm] = (d[norm] / np.linalg.norm(d[norm].astype(np.float64), axis=1)[:, None]).astype(np.float32)
+    tmax = np.where(rng.random(n) < .7, np.inf, rng.uniform(.5, 12, n)).astype(np.float32)
+    rays = np.concatenate([o, d, tmax[:, None]], axis=1).astype(np.float32)
+    closest, occluded = tc.oracle_answers(ob, s)
+    want = closest(rays)
+    assert np.array_equal(integ.trace(rays).view(np.int32), want.view(np.int32))
+    hits, extra = tc.check_wavefront(integ, rays, closest, occluded)
+    prim = hits.view(np.int32)[:, 0]
+    assert (prim >= 0).mean() > .5 and len(np.unique(prim[prim >= 0])) > 100   # (the winners are spread over the copies)
 
 
 def test_killeroo_full_size_low_spp_against_oracle(pt, ob):
@@ -445,6 +499,8 @@ def test_alpha_masks_against_oracle(pt, ob, tmp_path):
             assert np.array_equal(dh[:, 0].view(np.int32) >= 0, oh[:, 0].view(np.int32) >= 0)
         else:
             assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32))
+    tc.check_wavefront(integ, rays, *tc.oracle_answers(ob, s), prim_only=True)   # k_trav<*, ALPHA = true>
+    tc.check_wavefront(integ, rays, *tc.device_answers(integ))                    # ... and bit for bit what k_trace answers
 
 
 def test_bump_mapping_against_oracle(pt, ob, tmp_path):
@@ -522,6 +578,9 @@ def test_rays_with_more_quadrics_than_the_pending_list_holds(pt, ob):
     dh = integ.trace(rays, any_hit=False)
     oh, _ = ob.trace(s, rays, any_hit=False)
     assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32)) and np.array_equal(dh[:, 1], oh[:, 1])
+    hits, extra = tc.check_wavefront(integ, rays, *tc.oracle_answers(ob, s), prim_only=True)   # k_trav + k_resolve_overflow
+    tc.check_wavefront(integ, rays, *tc.device_answers(integ))
+    assert ((extra[:, 2] & 0x100) != 0).sum() > 100   # (rays whose quadric list did overflow)
 
 
 def test_roughness_textures_against_oracle(pt, ob, tmp_path):
@@ -573,6 +632,9 @@ def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
             assert np.array_equal(dh[:, 0].view(np.int32), oh[:, 0].view(np.int32))
             assert np.array_equal(dh[:, 1], oh[:, 1])
             closest = dh[:, 0].view(np.int32).copy()
+    hits, extra = tc.check_wavefront(integ, rays, *tc.oracle_answers(ob, s), prim_only=True)   # k_trav<*, true, 4, INST = true>: return entries
+    tc.check_wavefront(integ, rays, *tc.device_answers(integ))
+    assert (extra[:, 1] >= 0).sum() > 200 and (extra[:, 1] < s.desc.n_instances).all()   # I_HITINST
     members = set()   # the primitives under the objects' roots (a first child follows its parent in the array)
     for k in range(s.desc.n_instances):
         todo = [int(s.desc.instances[k].root)]

@@ -115,6 +115,29 @@ def _device_trace(pt):
     return of
 
 
+def _device_trace_wavefront(pt):
+    """Every ray query answered by the kernels a render launches (mi_pt_trace_wavefront): closest hits by k_trav<0> +
+    k_resolve_extend; occlusion by k_trav<1> + k_resolve_shadow when the rays are NEE shadow rays (tMax = 1 - ShadowEpsilon,
+    what SpawnRayTo makes), otherwise -- any other tMax -- as "k_trav<0> found a closest hit"."""
+    import trace_check as tc
+
+    def of(s):
+        integ = pt.CreatePathIntegrator(s)
+
+        def trace(rays, any_hit):
+            rays = np.ascontiguousarray(rays, np.float32)
+            if any_hit and (rays[:, 6] == tc.SHADOW_TMAX).all():
+                return integ.trace_wavefront(rays, mode=1)[0]
+            hits = integ.trace_wavefront(rays, mode=0)[0]
+            if any_hit:
+                out = np.zeros((len(rays), 4), np.int32)
+                out[:, 0] = np.where(hits.view(np.int32)[:, 0] >= 0, 0, -1)
+                return out.view(np.float32)
+            return hits
+        return trace
+    return of
+
+
 def test_sphere_solid_angle(pt, ob):
     """Sphere.SolidAngle: 4 pi from inside (area sampling branch of Sphere::Sample), and cone sampling from outside
     agreeing with uniform-sphere hit counting to 1e-3 -- with the reference's transform, points and sample count."""
@@ -285,3 +308,12 @@ def test_full_sphere_reintersect(pt, ob):
 @pytest.mark.gpu
 def test_full_sphere_reintersect_on_device(pt, ob):
     _full_sphere_reintersect(pt, ob, _device_trace(pt), 100, 10000)
+
+
+@pytest.mark.gpu
+def test_shape_pins_through_the_wavefront_kernels(pt, ob):
+    """Sphere.SolidAngle, Triangle.Reintersect and FullSphere.Reintersect once more, every Intersect / IntersectP answered
+    by the persistent traversal kernels and resolve steps of the render (not by k_trace's per-ray routine)."""
+    _sphere_solid_angle(pt, ob, _device_trace_wavefront(pt))
+    _triangle_reintersect(pt, ob, _device_trace_wavefront(pt), 100, 2000)
+    _full_sphere_reintersect(pt, ob, _device_trace_wavefront(pt), 40, 2000)
