@@ -39,12 +39,21 @@ DEV bool isnanf_(float a) { return a != a; }
 // They are deliberately not inlined: each expands to several hundred instructions, and the shading kernels
 // are bound by instruction fetch (their code does not fit the instruction cache), not by call overhead.
 #define DEV_CALL __device__ __noinline__
+#ifdef MIPT_EXP_FLOATLIBM   // (timing experiment: ocml's float routines, inlined)
+DEV float sinF(float x) { return ::sinf(x); }
+DEV float cosF(float x) { return ::cosf(x); }
+DEV float acosF(float x) { return ::acosf(x); }
+DEV float atan2F(float y, float x) { return ::atan2f(y, x); }
+DEV float logF(float x) { return ::logf(x); }
+DEV float powF(float x, float y) { return ::powf(x, y); }
+#else
 static DEV_CALL float sinF(float x) { return (float)sin((double)x); }
 static DEV_CALL float cosF(float x) { return (float)cos((double)x); }
 static DEV_CALL float acosF(float x) { return (float)acos((double)x); }
 static DEV_CALL float atan2F(float y, float x) { return (float)atan2((double)y, (double)x); }
 static DEV_CALL float logF(float x) { return (float)log((double)x); }
 static DEV_CALL float powF(float x, float y) { return (float)pow((double)x, (double)y); }
+#endif
 
 // x / d for many x and one d: one IEEE reciprocal, then per quotient a multiply and two
 // fused corrections (q = x*r; rem = fma(-q, d, x); q += rem*r). With r the correctly

@@ -145,6 +145,13 @@ struct PathSampler {
 // samplers (TM_SAMPLERS, d_bsdf.h)
 template <bool HALTON_ONLY = false>
 DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelPlane, const int *__restrict__ samplePlane, uint32_t slot) {
+#ifdef MIPT_EXP_FASTRNG
+    if constexpr (HALTON_ONLY) {   // (timing experiment: a hash instead of the scrambled radical inverse)
+        uint32_t h = (uint32_t)ps.index * 2654435761u + (uint32_t)(ps.dim++) * 0x9E3779B9u;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+        return minf((float)h * 0x1p-32f, kOneMinusEpsilon);
+    }
+#endif
     if constexpr (HALTON_ONLY) return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim++);
     if (s.samplerType == MI_SAMPLER_RANDOM) {
         const int pixelWord = pixelPlane[slot];

@@ -198,7 +198,19 @@ struct DevCounters {
     DevCursor shadeCount[MAX_CLASSES];  // entries in shading queue c
     DevCursor travNext[3];              // work cursors of the persistent traversal kernels (extend/shadow/mis)
     DevCursor ovfCount[3];              // entries in Pool::ovfQ (extend/shadow/mis)
+#ifdef MIPT_EXP_STAMPS
+    unsigned long long phase[24];       // diagnostic build: wave-cycles of k_shade between its stamps (s_memtime), summed over waves
+    unsigned long long phaseWaves;
+#endif
 };
+#ifdef MIPT_EXP_STAMPS
+// In-kernel stamps (MI355X_MICROARCH.md, "in-kernel stamps"): one wave-uniform s_memtime per phase boundary, the difference
+// to the previous stamp added to phase[k]. Diagnostic build only (tools/shade_experiments.sh stamps).
+#define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (stampOn && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&ctr->phase[k], t_ - stampLast); stampLast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 constexpr size_t ITER_CLEAR_BYTES = sizeof(DevCursor) * (5 + MAX_CLASSES + 3 + 3);
 DEV DevStats &Stats(DevCounters *ctr) { return ctr->stats[blockIdx.x & (STAT_STRIPES - 1)]; }
 
@@ -1610,6 +1622,20 @@ DEV void ShadingToWorld(const mi_instance &in, TriShading *ts) {
 // Build the SurfaceInteraction of a recorded hit.
 DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, float b0, float b1, float b2, SurfaceInteraction *si) {
     const mi_prim p = s.prims[prim];
+#ifdef MIPT_EXP_FLATTRI
+    if (p.shape >= 0) {   // (timing experiment: the interaction from the pre-gathered leaf record, no indexed N / UV gather)
+        const float4 a = s.primTri[3 * prim], b = s.primTri[3 * prim + 1], c = s.primTri[3 * prim + 2];
+        const V3 p0(a.x, a.y, a.z), p1(b.x, b.y, b.z), p2(c.x, c.y, c.z);
+        si->p = b0 * p0 + b1 * p1 + b2 * p2;
+        si->pError = gammaf(7) * V3(absf(b0 * p0.x) + absf(b1 * p1.x) + absf(b2 * p2.x), absf(b0 * p0.y) + absf(b1 * p1.y) + absf(b2 * p2.y), absf(b0 * p0.z) + absf(b1 * p1.z) + absf(b2 * p2.z));
+        si->wo = Normalize(-rd);
+        V3 n = Normalize(Cross(p0 - p2, p1 - p2)), du, dv;
+        CoordinateSystem(n, &du, &dv);
+        n = Faceforward(n, si->wo);
+        si->n = n; si->shN = n; si->dpdu = du; si->shDpdu = du;
+        return;
+    }
+#endif
     if (p.shape >= 0) TriInteraction(s, p.shape, b0, b1, b2, rd, si);
     else { float t; SphereInteraction(s.spheres[~p.shape], ro, rd, kInfinity, si, &t); }
 }
@@ -1670,6 +1696,18 @@ DEV void StoreSpectrumLines(SpectrumTile &t, const Pool &pool, int spectrum, uin
 #ifndef MIPT_SHADE_WAVES_PER_EU
 #define MIPT_SHADE_WAVES_PER_EU 4
 #endif
+// Timing experiments (tools/shade_experiments.sh; the films of these builds are wrong, only k_shade's time is read):
+// MIPT_EXP_NOSPEC evaluates one quad of every spectral pass instead of eight, MIPT_EXP_NOSTORE leaves the spectra unstored.
+#ifdef MIPT_EXP_NOSPEC
+constexpr int EXP_NQ = 1;
+#else
+constexpr int EXP_NQ = NQ;
+#endif
+#ifdef MIPT_EXP_NOSTORE
+#define EXP_STORE(x) false
+#else
+#define EXP_STORE(x) (x)
+#endif
 
 template <int NL, unsigned TM>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT_SHADE_WAVES_PER_EU, 8))) k_shade(DScene s, Pool pool, DevCounters *ctr, unsigned classes) {
@@ -1685,6 +1723,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     const uint32_t qi = blk * BLOCK + threadIdx.x;
     constexpr bool HALTON_ONLY = (TM & TM_SAMPLERS) == 0;
     __shared__ SpectrumTile tile;
+#ifdef MIPT_EXP_STAMPS
+    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+    const bool stampOn = (blockIdx.x % 61u) == 0u;   // (one block in 61 reports: the atomics of every wave would be the kernel)
+#endif
     unsigned totalPaths = 0, pathLen = 0, zeroNow = 0;
     bool wantShadow = false, wantMis = false;
     uint32_t slot = 0;
@@ -1702,6 +1744,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         const bool emitCheck = bounces == 0 || (flags & F_SPECULAR);
         const bool needIsect = found && (bounces < s.maxDepth || emitCheck);
         const bool needRay = needIsect || (!found && emitCheck && TM_LIGHT(TM, MI_LIGHT_INFINITE) && s.nInfiniteLights > 0);
+        STAMP(1);
         float4 ray0 = make_float4(0.f, 0.f, 0.f, 0.f), ray1 = make_float4(0.f, 0.f, 1.f, 1.f);
         if (needRay) { ray0 = pool.R(R_RAY0, slot); ray1 = pool.R(R_RAY1, slot); }
         V3 ro(ray0.x, ray0.y, ray0.z), rd(ray1.x, ray1.y, ray1.z);
@@ -1716,6 +1759,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (inst >= 0) { const Ray ir = XfRay(s.instances[inst].w2i, Ray(ro, rd, kInfinity)); roS = ir.o; rdS = ir.d; }
         }
         if (needIsect) { const float4 hr = pool.R(R_HIT, slot); HitInteraction(s, prim, roS, rdS, hr.y, hr.z, hr.w, &isect); }
+        STAMP(2);
         SurfaceInteraction isectObj;
         if constexpr ((TM & TM_INSTANCES) != 0) {
             if (inst >= 0) { isectObj = isect; InteractionToWorld(s.instances[inst], &isect); }
@@ -1763,6 +1807,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             }
         }
         if (!found || bounces >= s.maxDepth) finished = true;
+        STAMP(3);
         int newFlags = 0;
         if (!finished && s.prims[prim].material < 0) {  // interface without BSDF: continue through it, path.cpp:108-113
             Ray r = SpawnRay(isect, rd);
@@ -1862,6 +1907,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             ps.dim = pool.I(I_DIM, slot);
             const int *__restrict__ pixelPlane = pool.i + (size_t)I_PIXEL * pool.n, *__restrict__ samplePlane = pool.i + (size_t)I_SAMPLE * pool.n;
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
+        STAMP(4);
             // ---- direct lighting: UniformSampleOneLight + EstimateDirect, integrator.cpp:85-215
             if (NumComponents(fr, nonSpec) > 0) {
                 ++totalPaths;
@@ -1874,23 +1920,26 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     if (selPdf != 0) {
                         const float uL0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uL1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                         const float uS0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uS1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
+        STAMP(5);
                         const mi_light &light = s.lights[lightNum];
                         const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
                         const Divisor selDiv = MakeDivisor(selPdf);
                         const LightSample ls = SampleLi<TM>(s, light, isect, uL0, uL1);
+        STAMP(6);
                         const float lightPdf = ls.pdf;
                         if (lightPdf > 0 && !ls.black) {
                             BSDFEvalT<NL> ev;
                             BSDF_f<NL, TM>(fr, isect.wo, ls.wi, nonSpec, &ev);
                             const float absdot = AbsDot(ls.wi, isect.shN);
                             const float scatteringPdf = BSDF_Pdf<TM>(fr, isect.wo, ls.wi, nonSpec);
+        STAMP(7);
                             const bool delta = IsDeltaLight(light);
                             float weight = 1.f;
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
                             const Divisor lpDiv = MakeDivisor(lightPdf);
                             bool fNonBlack = false, liNonBlack = false, nzAny = false;
 #pragma unroll 1
-                            for (int c = 0; c < NQ; ++c) {
+                            for (int c = 0; c < EXP_NQ; ++c) {
                                 const float4 bt = loadBeta(c);
                                 float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
                                 const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), Lq = LiQuad<TM>(s, light, ls, c);
@@ -1914,7 +1963,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             // only a contribution whose shadow ray will be traced is ever read; into Q_L itself while the
                             // path's L is still empty (F_NEE_IN_L)
                             const bool traced = fNonBlack && liNonBlack;
-                            StoreSpectrumLines(tile, pool, lZero ? Q_L : Q_LNEE, slot, traced);
+        STAMP(8);
+                            StoreSpectrumLines(tile, pool, lZero ? Q_L : Q_LNEE, slot, EXP_STORE(traced));
                             if (traced && lZero) newFlags |= F_NEE_IN_L | (nzAny ? F_NEE_NZ : 0);
                             if (traced) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
@@ -1922,6 +1972,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 pool.R(R_SH1, slot) = make_float4(sr.d.y, sr.d.z, 0.f, 0.f);
                                 newFlags |= F_SHADOW;
                             }
+        STAMP(9);
                         }
                         if (!IsDeltaLight(light)) {  // BSDF sampling with MIS, integrator.cpp:167-213
                             V3 wi;
@@ -1929,6 +1980,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             int sampledType = 0;
                             BSDFEvalT<NL> ev;
                             const bool ok = BSDF_Sample_f<NL, TM>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
+        STAMP(10);
                             if (ok && sPdf > 0) {
                                 const float absdot = AbsDot(wi, isect.shN);
                                 // Pdf_Li has no side effect: evaluate it before knowing whether f is black
@@ -1950,9 +2002,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // traces it), but its contribution is never read: F_MIS_DARK
                                 const Ray mr = SpawnRay(isect, wi);
                                 const bool dark = go && !isEnvLight && !RayMayHitBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1]);
+        STAMP(11);
                                 if (dark) {
 #pragma unroll 1
-                                    for (int c = 0; c < NQ; ++c) {   // (only: is f black? -- that decides whether the ray exists)
+                                    for (int c = 0; c < EXP_NQ; ++c) {   // (only: is f black? -- that decides whether the ray exists)
                                         const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
 #pragma unroll
                                         for (int k = 0; k < 4; ++k)
@@ -1962,7 +2015,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // (when the light's pdf for wi is 0 the estimate ends here, integrator.cpp:186-187:
                                 // nothing reads the spectrum then, so it is not formed)
 #pragma unroll 1
-                                for (int c = 0; go && !dark && c < NQ; ++c) {
+                                for (int c = 0; go && !dark && c < EXP_NQ; ++c) {
                                     const float4 bt = loadBeta(c);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
                                     const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
@@ -1982,7 +2035,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     }
                                     tile.q[c][threadIdx.x] = out;
                                 }
-                                StoreSpectrumLines(tile, pool, Q_LMIS, slot, go && !dark);   // whole 128-B lines, as for the light sample
+                                StoreSpectrumLines(tile, pool, Q_LMIS, slot, EXP_STORE(go && !dark));   // whole 128-B lines, as for the light sample
+        STAMP(12);
                                 if (fNonBlack && go) {
                                     if (dark) newFlags |= F_MIS_DARK;
                                     pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
@@ -2003,6 +2057,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 const float u0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), u1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                 BSDFEvalT<NL> ev;
                 const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
+        STAMP(13);
                 bool fNonBlack = false;
                 if (ok && pdf != 0.f) {
                     const float absdot = AbsDot(wi, isect.shN);
@@ -2014,7 +2069,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     const Divisor pdfDiv = MakeDivisor(pdf);
                     float maxRR = 0;
 #pragma unroll 1
-                    for (int c = 0; c < NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
+                    for (int c = 0; c < EXP_NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
                         float4 bt = loadBeta(c);
                         const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
 #pragma unroll
@@ -2033,6 +2088,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     }
                     // (the new throughput is stored below, once it is known that a later vertex will read it)
                     bool killed = false;
+        STAMP(14);
                     if (fNonBlack) {
                         // Russian roulette, path.cpp:176-184
                         if (maxRR < s.rrThreshold && bounces > 3) {
@@ -2055,7 +2111,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     // light (after a specular bounce, path.cpp:91-101); a path that ends here, or whose last ray only
                     // has to be traced, leaves none behind
                     const bool needBeta = fNonBlack && !killed && (bounces + 1 < s.maxDepth || (sflags & MI_BSDF_SPECULAR));
-                    StoreSpectrumLines(tile, pool, Q_BETA, slot, needBeta);
+                    StoreSpectrumLines(tile, pool, Q_BETA, slot, EXP_STORE(needBeta));
+        STAMP(15);
                     if (needBeta) betaWritten = true;
                     if (fNonBlack) {
                         if (killed) finished = true;
@@ -2069,6 +2126,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 }
                 if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
             }
+        STAMP(16);
             pool.I(I_DIM, slot) = ps.dim;
             if (!HALTON_ONLY && s.samplerType == MI_SAMPLER_RANDOM) {   // the stream moves on with the path
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)ps.index;
@@ -2093,6 +2151,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             pool.I(I_FLAGS, slot) = newFlags;
         }
     }
+    STAMP(17);
     __shared__ unsigned sShadow[5], sMis[5];
     const unsigned posS = BlockReserve(&ctr->shadowCount.v, wantShadow, sShadow);
     const unsigned posM = BlockReserve(&ctr->misCount.v, wantMis, sMis);
@@ -2101,6 +2160,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     CountAdd(&Stats(ctr).totalPaths, totalPaths);
     CountAdd(&Stats(ctr).pathLengthSum, pathLen);
     CountAdd(&Stats(ctr).zeroRadiancePaths, zeroNow);
+    STAMP(18);
+#ifdef MIPT_EXP_STAMPS
+    if (stampOn && (threadIdx.x & 63) == 0) atomicAdd(&ctr->phaseWaves, 1ull);
+#endif
 }
 
 #if MIPT_HAS_MAIN
@@ -2275,6 +2338,8 @@ constexpr unsigned TM_FULL = TM_ALL & ~TM_INSTANCES, TM_GENERIC = TM_FULL & ~TM_
     X(2, TM_DIFFUSE | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS) X(2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS)
 #define MIPT_SHADE_DEFINE(NL_, TM_) template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
 #define MIPT_SHADE_EXTERN(NL_, TM_) extern template __global__ void k_shade<NL_, (TM_)>(DScene, Pool, DevCounters *, unsigned);
+// MIPT_HOT_ONLY (tools/shade_experiments.sh): a one-translation-unit build with the matte and plastic Halton instances
+// alone -- what the killeroo / Cornell-without-glass frames launch -- for quick same-box A/B runs of k_shade experiments.
 #ifdef MIPT_PART
 #if MIPT_PART == 0
 MIPT_SHADE_GROUP_1(MIPT_SHADE_EXTERN) MIPT_SHADE_GROUP_2(MIPT_SHADE_EXTERN) MIPT_SHADE_GROUP_3(MIPT_SHADE_EXTERN)
@@ -3062,6 +3127,11 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
     const dim3 shadeGrid(grid.x + MAX_CLASSES);
+#ifdef MIPT_HOT_ONLY
+    if (pt->diffuseClasses) hipLaunchKernelGGL((k_shade<2, TM_DIFFUSE | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->diffuseClasses);
+    if (pt->plasticClasses) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_LIGHTS_NO_ENV>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->plasticClasses);
+    return;
+#else
     if (pt->hasInstances) {   // scenes with object instances: the two fully general instances of the kernel, by lobe count
         const unsigned two = pt->diffuseClasses | pt->plasticClasses | pt->glassClasses | pt->smallClasses | pt->texturedDiffuse | pt->texturedPlastic | pt->texturedSmall;
         const unsigned more = pt->mediumClasses | pt->texturedMedium | pt->largeClasses | pt->texturedLarge | pt->uberClasses | pt->disneyClasses;
@@ -3091,6 +3161,7 @@ static void LaunchShade(mi_pt *pt, SubRenderer &sub, dim3 grid) {
     if (pt->texturedPlastic) hipLaunchKernelGGL((k_shade<2, TM_PLASTIC | TM_TEXTURED | TM_LIGHTS_ALL | TM_SAMPLERS>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedPlastic);
     if (pt->texturedSmall) hipLaunchKernelGGL((k_shade<2, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedSmall);
     if (pt->texturedLarge) hipLaunchKernelGGL((k_shade<MI_MAX_BXDFS, TM_FULL>), shadeGrid, block, 0, st, s, sub.pool, sub.ctr, pt->texturedLarge);
+#endif   // MIPT_HOT_ONLY
 }
 
 // One sub-renderer = one path pool with its queues and counters on its own HIP stream.
@@ -3227,6 +3298,15 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(&sub.result, sub.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost));
+#ifdef MIPT_EXP_STAMPS
+    {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 24; ++k) tot += sub.result.phase[k];
+        fprintf(stderr, "k_shade stamps: %llu waves, %.0f cycles per wave;", sub.result.phaseWaves, (double)tot / (double)std::max(1ull, sub.result.phaseWaves));
+        for (int k = 0; k < 19; ++k) fprintf(stderr, " [%d] %.1f%%", k, 100.0 * (double)sub.result.phase[k] / (double)std::max(1ull, tot));
+        fprintf(stderr, "\n");
+    }
+#endif
     return MI_OK;
 }
 

@@ -230,3 +230,58 @@ def test_gpu_procedural_10M_triangles_256spp_full_frame(pt, tmp_path):
     s = _procedural_scene(pt, tmp_path, z)
     assert s.stats["n_triangles"] == 10_000_002 and s.film_size == (700, 700)
     _full_frame_against_tiles(pt, s, z, counters, exact, 1e-4, 2e-3, 0.05)
+
+
+@pytest.mark.gpu
+def test_gpu_procedural_10M_triangles_2048spp_in_8_shards(pt, tmp_path):
+    """BASELINE configs[4]'s workload on the one device of the box: the 10 000 002-triangle scene, 700x700, 2048 spp, the
+    film's tiles in the 8 shards that config gives to 8 GPUs, rendered one after another through the product's step function
+    (ShardedFrame.step: the shard into the resident device film, then the film reduce -- which has nothing to add up without
+    a process group) and summed. Camera rays exact; the shard films tile the frame and add up to the one-pass frame;
+    the oracle's tiles (every 64th of the full frame: they lie in shard 0 of 8) at the configs[3] bars, both libm modes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ptdist", os.path.join(ROOT, "pbrt-v3-spectral_amd", "distributed.py"))
+    ptdist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ptdist)
+    z, counters, exact = _load("procedural_10M_2048spp_tiles.npz")
+    spp = int(z["spp"])
+    assert spp == 2048
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden as mg
+    s = pt.Scene(mg.procedural_scene(str(tmp_path)), spp=spp)
+    assert s.stats["n_triangles"] == 10_000_002 == int(z["n_triangles"]) and s.film_size == (700, 700) and s.spp == spp
+    integ = pt.CreatePathIntegrator(s)
+    w, h = s.film_size
+    # the fixture's own shard (0 of 64): counters and film against the oracle
+    f0, w0 = integ.Render(shard_index=0, shard_count=int(z["shard_count"]))
+    c0 = integ.counters.as_dict()
+    assert c0["camera_rays"] == exact["camera_rays"] == counters["camera_rays"] and c0["bad_samples"] == 0
+    for k in COUNTER_KEYS:
+        assert abs(c0[k] - exact[k]) <= 2, (k, c0[k], exact[k])
+        assert abs(c0[k] - counters[k]) <= 1e-4 * counters[k] + 3, (k, c0[k], counters[k])
+    ys, xs = z["ys"].astype(int), z["xs"].astype(int)
+    zz = {"film": z["film"], "film_exact": z["film_exact"], "weight": z["weight"]}
+    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, 1e-4, 2e-3, 0.05)
+    # the 8 shards of configs[4] through ShardedFrame.step
+    film32 = ptdist.device_film_tensor(integ)
+    acc = np.zeros((h, w, 32), np.float32)
+    owners = np.zeros((h, w), np.int32)
+    cams = 0
+    for r in range(8):
+        frame = ptdist.ShardedFrame(lambda si, sc: integ.Render(shard_index=si, shard_count=sc, download=False), film32, r, 8)
+        frame.step()
+        assert frame.steps == 1 and frame.render_s > 0
+        part = film32.cpu().numpy()
+        cams += integ.counters.camera_rays
+        assert integ.counters.bad_samples == 0
+        owners += (part[..., 31] > 0)
+        acc += part
+    assert cams == w * h * spp
+    assert owners.min() >= 1 and (owners > 1).mean() < 0.2   # every pixel rendered; only tile-border pixels by two shards
+    full, wfull = integ.Render()
+    assert integ.counters.camera_rays == w * h * spp
+    assert np.array_equal(acc[..., 31], wfull)
+    assert _rel_l2(acc[..., :31], full) < 1e-6
+    inner = (w0[ys, xs] == spp) & (acc[ys, xs, 31] == spp)   # (pixels no border-exact sample reaches: six in seven at 2048 spp)
+    assert inner.mean() > 0.8
+    assert _rel_l2(acc[ys, xs][inner][:, :31], z["film_exact"][inner]) < 1e-6 * (spp / 256.0) ** 0.5

@@ -18,6 +18,8 @@ they pin the oracle itself against regressions.
   procedural_10M_256spp.npz   BASELINE configs[3] stand-in at full size (tools/make_procedural_scene.py, 10 000 002
                               triangles, 700x700, 256 spp): the films of every 64th 16x16 tile (shard 0 of 64) and 8192
                               recorded rays (camera rays + random rays through the scene) with their hits
+  procedural_10M_2048spp_tiles.npz  BASELINE configs[4]'s workload (the same scene at 2048 spp, which that config shards over
+                              8 GPUs): every 64th tile of the full frame
 
 Every film fixture holds the oracle's result twice: `film` / `counters` with the host's libm as the reference binary calls
 it (glibc), and `film_exact` / `counters_exact` with correctly rounded libm calls (oracle/o_math.h mode 1), the arithmetic
@@ -112,11 +114,13 @@ def tile_fixture(path, s, shard_count, rays=None):
           (os.path.basename(path), len(ys), d["camera_rays"], film[ys, xs].mean() / spp, secs, rel, d["regular_rays"] - dx["regular_rays"]))
 
 
-def procedural_fixture(path):
+def procedural_fixture(path, spp=None):
+    """spp = None: configs[3] (256 spp, with recorded rays). spp = 2048: configs[4]'s workload -- the same scene file with the
+    sample count overridden, the tiles of shard 0 of 64 (which lie inside shards 0 of 8, 2 and 4: 64 = 8 x 8)."""
     import tempfile
-    s = pt.Scene(procedural_scene(tempfile.mkdtemp()))
+    s = pt.Scene(procedural_scene(tempfile.mkdtemp()), **({"spp": spp} if spp else {}))
     assert s.stats["n_triangles"] == PROCEDURAL["tris"] + 2, s.stats
-    tile_fixture(path, s, PROCEDURAL["shard_count"], rays=procedural_rays(s))
+    tile_fixture(path, s, PROCEDURAL["shard_count"], rays=procedural_rays(s) if spp is None else None)
 
 
 def ray_fixture(path):
@@ -165,6 +169,7 @@ if __name__ == "__main__":
         "killeroo_1024spp_tiles": lambda p: tile_fixture(p, pt.Scene(KILLEROO, spp=1024), 64),
         "cornell_4096spp_tiles": lambda p: tile_fixture(p, pt.Scene(CORNELL, spp=4096), 64),
         "procedural_10M_256spp": procedural_fixture,
+        "procedural_10M_2048spp_tiles": lambda p: procedural_fixture(p, spp=2048),
     }
     for name, job in jobs.items():
         if only is None or only == name:
