@@ -641,6 +641,116 @@ DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c, const Lob
     return make_float4(f[0], f[1], f[2], f[3]);
 }
 
+// ---- straight-line spectral evaluation (the hot shading instances: matte, plastic, glass / mirror lobe sets)
+// EvalQuad / LobeValueCore / DivBy decide per lane and per bin -- which kind of lobe, whether the fast quotient applies,
+// whether bin 31 exists -- and every such decision is an exec-mask branch: the light-sample loop of the plastic instance was
+// 815 instructions per quad, 380 of them branch scaffolding (s_and_saveexec / s_cbranch_execz / s_or), in a kernel bound by
+// instruction issue (SQ counters: VALU + SALU issue fill the four waves' slots). Here the same values come out of code
+// without a per-lane branch:
+//  * every lobe kind these instances can meet is ((R*a)*b)*c [/ d] with factors that may be absent; an absent factor is 1
+//    (x * 1.f == x exactly), LK_MTRANS's (1 - a) * R is R * (1 - a) (IEEE multiplication commutes); whether ANY lane of the
+//    wave needs the b / c factor or the division is a wave-uniform (scalar) branch;
+//  * DivBy's quotient candidate is formed for every operand without testing it; instead the largest and smallest magnitude
+//    seen in the quad are tracked as integers (two instructions per quotient) and ONE wave-uniform test per quad decides
+//    whether any lane left DivBy's fast range -- then the quad is redone by the branching code (EvalQuad / DivBy), which
+//    is the definition of the result. (An exact zero stays on the fast path: 0 * r is the quotient 0 / d.)
+#define TM_SIMPLE_KINDS(tm) (!TM_FRESNEL(tm, MI_FRESNEL_CONDUCTOR) && !TM_FRESNEL(tm, MI_FRESNEL_DISNEY) && !TM_HAS(tm, MI_BXDF_FRESNEL_BLEND) && \
+                             !TM_HAS(tm, MI_BXDF_DISNEY_CLEARCOAT) && !TM_HAS(tm, MI_BXDF_DISNEY_DIFFUSE) && !TM_HAS(tm, MI_BXDF_DISNEY_RETRO) && (((tm) & (TM_TEXTURED | TM_SCALED)) == 0u))
+struct DivTrack {
+    unsigned mx, mn;   // over the quotient candidates q1 != 0 formed so far: max of bits(|q1|), min of bits(|q1|) - 1
+    DEV void Reset(bool allDivisorsFast) { mx = allDivisorsFast ? 0u : 0xffffffffu; mn = 0xffffffffu; }
+    // DivBy's `aq > 1e-30f && aq < 1e30f` for all of them (bits of 1e-30f: 0x0da24260, of 1e30f: 0x7149f2ca)
+    DEV bool Bad() const { return mx >= 0x7149f2cau || mn < 0x0da24260u; }
+};
+DEV float DivFast(float x, float d, float r, DivTrack &t) {
+    const float q = x * r;
+    const float rem = __builtin_fmaf(-q, d, x);
+    const float q1 = __builtin_fmaf(rem, r, q);
+    const unsigned u = __float_as_uint(q1) & 0x7fffffffu;
+    t.mx = max(t.mx, u);
+    t.mn = min(t.mn, u - 1u);   // (u == 0: wraps to the top, leaves the minimum alone)
+    return q1;
+}
+// The lobe list of one evaluation in canonical form, per lane: f[bin] = sum over slots of ((R*A)*B)*C / d. A slot the lane does
+// not use has A = 0 (its term is +0: f + 0 == f), a slot without division d = r = 1 (DivBy(v, 1) == v). TM says at compile
+// time which factors can occur at all (matte lobes have neither c nor d).
+#define TM_HAS_DIV_KINDS(tm) (TM_HAS(tm, MI_BXDF_MICROFACET_REFLECTION) || TM_SPECULAR(tm))
+#define TM_HAS_C_FACTOR(tm) (TM_HAS(tm, MI_BXDF_MICROFACET_REFLECTION))
+template <int NL>
+struct SimpleLobes {
+    float A[NL], B[NL], C[NL], d[NL], r[NL];
+    unsigned off[NL];                              // byte offset of the slot's spectrum (R, or S for bit 8 of LobeEval::lobe) from bx
+    bool anyOn[NL], anyB[NL], anyC[NL], anyDiv[NL];   // wave-uniform: some lane needs the slot / the factor / the division
+    bool divisorsFast;                             // per lane: every divisor of the list is in DivBy's fast range
+};
+template <int NL, unsigned TM>
+DEV SimpleLobes<NL> MakeSimpleLobes(const BSDFEvalT<NL> &ev) {
+    SimpleLobes<NL> sl;
+    sl.divisorsFast = true;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const LobeEval &le = ev.lobes[i];
+        const bool on = i < ev.n;
+        const int kind = on ? (le.kind & 0xff) : LK_NONE;
+        const bool hasB = kind == LK_MUL2 || kind == LK_MUL3 || kind == LK_MUL3_DIV || kind == LK_MUL2_DIV || kind == LK_MTRANS;
+        const bool hasC = TM_HAS_C_FACTOR(TM) && (kind == LK_MUL3 || kind == LK_MUL3_DIV);
+        const bool div = TM_HAS_DIV_KINDS(TM) && (kind == LK_MUL3_DIV || kind == LK_MUL1_DIV || kind == LK_MUL2_DIV);
+        sl.A[i] = !on ? 0.f : ((kind == LK_MTRANS) ? (1.f - le.a) : le.a);
+        sl.B[i] = hasB ? le.b : 1.f;
+        sl.C[i] = hasC ? le.c : 1.f;
+        sl.d[i] = div ? le.d : 1.f;
+        sl.r[i] = div ? le.r : 1.f;
+        if (div && !(le.kind & LK_FASTDIV)) sl.divisorsFast = false;
+        const int li = on ? (le.lobe & 0xff) : 0;
+        sl.off[i] = (unsigned)li * (unsigned)sizeof(mi_bxdf) + ((on && (le.lobe & 0x100)) ? (unsigned)offsetof(mi_bxdf, S) : (unsigned)offsetof(mi_bxdf, R));
+        sl.anyOn[i] = __any(on);
+        sl.anyB[i] = __any(hasB); sl.anyC[i] = __any(hasC); sl.anyDiv[i] = __any(div);
+    }
+    return sl;
+}
+DEV Divisor DivisorOf(float d, float r) {
+    Divisor v;
+    v.d = d; v.r = r;
+    const float a = absf(d);
+    v.fast = (a > 1e-18f) && (a < 1e18f);
+    return v;
+}
+// Quad c of f = sum of the lobes (EvalQuad's value). EXACT: the defining form, every quotient by DivBy (taken when the
+// fast form's range test fails somewhere in the quad).
+template <int NL, unsigned TM, bool EXACT>
+DEV float4 SimpleEvalQuad(const SimpleLobes<NL> &sl, const mi_bxdf *bx, int c, DivTrack &t) {
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        if (!sl.anyOn[i]) continue;   // (wave-uniform)
+        const float4 R = LoadSpec4(reinterpret_cast<const float *>(reinterpret_cast<const char *>(bx) + sl.off[i]), c);
+        float v[4] = {R.x * sl.A[i], R.y * sl.A[i], R.z * sl.A[i], R.w * sl.A[i]};
+        if (sl.anyB[i]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= sl.B[i];
+        }
+        if (TM_HAS_C_FACTOR(TM) && sl.anyC[i]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= sl.C[i];
+        }
+        if (TM_HAS_DIV_KINDS(TM) && sl.anyDiv[i]) {
+            if constexpr (EXACT) {
+                const Divisor dv = DivisorOf(sl.d[i], sl.r[i]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (sl.d[i] == 1.f && sl.r[i] == 1.f) ? v[k] : DivBy(v[k], dv);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = DivFast(v[k], sl.d[i], sl.r[i], t);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] += v[k];
+    }
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+// `acc |= bits(|x|)`: acc != 0 afterwards iff some x was != 0 (a NaN counts, as in `x != 0.f`)
+DEV void OrNonZero(unsigned &acc, float x) { acc |= __float_as_uint(x) & 0x7fffffffu; }
+
 // BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a
 // black f (including the early-outs that leave *pdf untouched). On success the value is
 // described by *ev (one specular LobeEval, or the lobe list for the sampled direction).

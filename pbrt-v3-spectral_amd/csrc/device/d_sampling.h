@@ -131,6 +131,61 @@ DEV float SampleDimensionFrom2(const DScene &s, uint64_t index, int dim) {
     return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, index, dim);
 }
 
+// N consecutive dimensions (>= 2) of ONE sample index, their digit loops side by side: a path vertex draws five (light
+// choice, light sample, BSDF sample) and then two (next direction) dimensions of the same index, and one after the other
+// every digit of every dimension waits for its own permutation lookup (~32 dependent lookups for five dimensions; in step,
+// the seven of the longest chain). Per dimension the operations and their order are ScrambledRadicalInverseBase's, so the
+// values are the same bits.
+template <int N>
+DEV void ScrambledDimensionsFused(const int32_t *__restrict__ primes, const int32_t *__restrict__ primeSums, const uint16_t *__restrict__ perms,
+                                  const uint64_t *__restrict__ primeMagic, uint64_t index, int dim, float (&u)[N]) {
+    if (index >> 32) {   // (beyond 138k spp: the 64-bit head of the digit loop, one dimension at a time)
+#pragma unroll
+        for (int k = 0; k < N; ++k) u[k] = ScrambledDimension(primes, primeSums, perms, primeMagic, index, dim + k);
+        return;
+    }
+    uint32_t a[N], base[N];
+    uint64_t magic[N], rev[N];
+    float invBase[N], invBaseN[N], perm0[N];
+    const uint16_t *perm[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        base[k] = (uint32_t)primes[dim + k];
+        magic[k] = primeMagic[dim + k];
+        perm[k] = perms + primeSums[dim + k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        perm0[k] = (float)perm[k][0];
+        invBase[k] = 1.f / (float)(int)base[k];
+        invBaseN[k] = 1;
+        rev[k] = 0;
+        a[k] = (uint32_t)index;
+    }
+    while (true) {
+        bool any = false;
+        uint32_t next[N], digit[N];
+        unsigned pv[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            next[k] = DivMagic(a[k], magic[k]);
+            digit[k] = a[k] - next[k] * base[k];
+            pv[k] = perm[k][digit[k]];   // (a chain that has run out reads perm[0]: unused)
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (a[k]) {
+                rev[k] = rev[k] * base[k] + pv[k];
+                invBaseN[k] *= invBase[k];
+                a[k] = next[k];
+                any = true;
+            }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) u[k] = minf(invBaseN[k] * ((float)rev[k] + invBase[k] * perm0[k] / (1 - invBase[k])), kOneMinusEpsilon);
+}
+
 // A path's view of its sampler: the sample's index (HALTON / SOBOL) or the state of its PCG32 stream (RANDOM), and the next
 // dimension. Get1D = Sampler::Get1D for dimensions >= 5 (sampler.cpp:178-195, random.cpp:44-48). The stream's increment
 // is recomputed from the slot's pixel and sample number when a RANDOM draw happens (`pixelWord`, `sampleNum`: planes

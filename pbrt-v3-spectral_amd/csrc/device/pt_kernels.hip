@@ -29,6 +29,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <type_traits>
 #include "d_sampling.h"
 #include "d_texture.h"
 #ifdef MIPT_SORT_EXPERIMENT
@@ -259,6 +260,27 @@ DEV unsigned BlockReserve(unsigned *counter, bool pred, unsigned *scratch) {
     unsigned base = scratch[4];
     for (int w = 0; w < wave; ++w) base += scratch[w];
     return base + (unsigned)__popcll(mask & ((1ull << lane) - 1));
+}
+
+// Two reservations behind ONE pair of barriers, their atomics issued by two different waves (k_shade ends in an append to the
+// shadow queue and one to the MIS queue; one after the other they cost two atomic round trips and four barriers).
+// `scratch`: 10 words of LDS.
+DEV void BlockReserve2(unsigned *counterA, bool predA, unsigned *counterB, bool predB, unsigned *scratch, unsigned *posA, unsigned *posB) {
+    const unsigned long long mA = __ballot(predA), mB = __ballot(predB);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { scratch[wave] = (unsigned)__popcll(mA); scratch[5 + wave] = (unsigned)__popcll(mB); }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        unsigned *sc = scratch + (threadIdx.x ? 5 : 0);
+        const unsigned tot = sc[0] + sc[1] + sc[2] + sc[3];
+        sc[4] = tot ? atomicAdd(threadIdx.x ? counterB : counterA, tot) : 0;
+    }
+    __syncthreads();
+    unsigned a = scratch[4], b = scratch[9];
+    for (int w = 0; w < wave; ++w) { a += scratch[w]; b += scratch[5 + w]; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    *posA = a + (unsigned)__popcll(mA & lt);
+    *posB = b + (unsigned)__popcll(mB & lt);
 }
 
 // ------------------------------------------------------------------ traversal
@@ -1722,6 +1744,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     }
     const uint32_t qi = blk * BLOCK + threadIdx.x;
     constexpr bool HALTON_ONLY = (TM & TM_SAMPLERS) == 0;
+#ifdef MIPT_NO_SIMPLE_SPECTRA
+    constexpr bool SIMPLE_SPECTRA = false;
+#else
+    constexpr bool SIMPLE_SPECTRA = NL <= 2 && TM_SIMPLE_KINDS(TM);   // the straight-line spectral passes (d_bsdf.h, SimpleLobes)
+#endif
+#ifdef MIPT_FUSED_HALTON
+    constexpr bool FUSED_HALTON = HALTON_ONLY;
+#else
+    constexpr bool FUSED_HALTON = false;   // (measured: the side-by-side digit loops cost 29 more scratch instructions and 7 % of the kernel)
+#endif
     __shared__ SpectrumTile tile;
 #ifdef MIPT_EXP_STAMPS
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
@@ -1915,11 +1947,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (s.nLights > 0) {
                     const uint32_t di = LightDistribIndex(s, isect.p);
                     float selPdf;
+                    // the five dimensions of the estimate (light choice, light sample, BSDF sample): with the Halton sampler
+                    // -- values are a pure function of (index, dimension) -- their digit loops run side by side
+                    float u5[5];
+                    if constexpr (FUSED_HALTON) { ScrambledDimensionsFused<5>(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim, u5); ps.dim += 1; }
+                    else u5[0] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                     const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
-                                                        s.ldFuncInt[di], (int)s.nLights, Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), &selPdf);
+                                                        s.ldFuncInt[di], (int)s.nLights, u5[0], &selPdf);
                     if (selPdf != 0) {
-                        const float uL0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uL1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
-                        const float uS0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), uS1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
+                        if constexpr (FUSED_HALTON) ps.dim += 4;
+                        else { for (int k = 1; k < 5; ++k) u5[k] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); }
+                        const float uL0 = u5[1], uL1 = u5[2], uS0 = u5[3], uS1 = u5[4];
         STAMP(5);
                         const mi_light &light = s.lights[lightNum];
                         const bool selIsOne = (selPdf == 1.f);  // x / 1 == x: skip the division
@@ -1938,11 +1976,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
                             const Divisor lpDiv = MakeDivisor(lightPdf);
                             bool fNonBlack = false, liNonBlack = false, nzAny = false;
-#pragma unroll 1
-                            for (int c = 0; c < EXP_NQ; ++c) {
+                            auto neeQuad = [&](int c, const float4 &fq, const float4 &Lq) {
                                 const float4 bt = loadBeta(c);
                                 float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-                                const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), Lq = LiQuad<TM>(s, light, ls, c);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const int b = 4 * c + k;
@@ -1959,6 +1995,50 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     }
                                 }
                                 tile.q[c][threadIdx.x] = out;
+                            };
+                            if constexpr (SIMPLE_SPECTRA) {
+                                // straight-line form (d_bsdf.h, SimpleLobes); a quad in which a quotient leaves DivBy's fast range is redone with DivBy
+                                const SimpleLobes<NL> sl = MakeSimpleLobes<NL, TM>(ev);
+                                const mi_bxdf *bx = mat->bxdf;
+                                const bool allSelOne = __all(selIsOne);
+                                const bool divFast = sl.divisorsFast && lpDiv.fast && (selIsOne || selDiv.fast);
+                                unsigned accF = 0u, accLi = 0u, accNz = 0u;
+                                auto quad = [&](int c, auto exactTag) {
+                                    constexpr bool EXACT = decltype(exactTag)::value;
+                                    DivTrack trk;
+                                    trk.Reset(divFast);
+                                    const float4 bt = loadBeta(c);
+                                    float4 fq = SimpleEvalQuad<NL, TM, EXACT>(sl, bx, c, trk), Lq = LiQuad<TM>(s, light, ls, c);
+                                    if (c == NQ - 1) { fq.w = 0.f; Lq.w = 0.f; }   // bin 31 does not exist
+                                    unsigned aF = 0u, aLi = 0u, aNz = 0u;
+                                    float o[4];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        const float f = Get4(fq, k) * absdot;
+                                        const float Li = Get4(Lq, k);
+                                        OrNonZero(aF, f); OrNonZero(aLi, Li);
+                                        const float x = (f * Li) * weight;   // (weight == 1 for a delta light: x * 1 == x)
+                                        float Ld;
+                                        if constexpr (EXACT) { Ld = DivBy(x, lpDiv); if (!selIsOne) Ld = DivBy(Ld, selDiv); }
+                                        else {
+                                            Ld = DivFast(x, lpDiv.d, lpDiv.r, trk);
+                                            if (!allSelOne) { const float Ld2 = DivFast(Ld, selDiv.d, selDiv.r, trk); Ld = selIsOne ? Ld : Ld2; }
+                                        }
+                                        o[k] = Get4(bt, k) * Ld;
+                                        OrNonZero(aNz, o[k]);
+                                    }
+                                    if (!EXACT && __any(trk.Bad())) return false;
+                                    tile.q[c][threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
+                                    accF |= aF; accLi |= aLi; accNz |= aNz;
+                                    return true;
+                                };
+#pragma unroll 1
+                                for (int c = 0; c < EXP_NQ; ++c)
+                                    if (!quad(c, std::false_type{})) quad(c, std::true_type{});
+                                fNonBlack |= accF != 0u; liNonBlack |= accLi != 0u; nzAny |= accNz != 0u;
+                            } else {
+#pragma unroll 1
+                                for (int c = 0; c < EXP_NQ; ++c) neeQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), LiQuad<TM>(s, light, ls, c));
                             }
                             // only a contribution whose shadow ray will be traced is ever read; into Q_L itself while the
                             // path's L is still empty (F_NEE_IN_L)
@@ -2003,24 +2083,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 const Ray mr = SpawnRay(isect, wi);
                                 const bool dark = go && !isEnvLight && !RayMayHitBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1]);
         STAMP(11);
-                                if (dark) {
-#pragma unroll 1
-                                    for (int c = 0; c < EXP_NQ; ++c) {   // (only: is f black? -- that decides whether the ray exists)
-                                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
+                                auto darkQuad = [&](int c, const float4 &fq) {   // (only: is f black? -- that decides whether the ray exists)
 #pragma unroll
-                                        for (int k = 0; k < 4; ++k)
-                                            if (4 * c + k < MI_NSPEC) fNonBlack |= (Get4(fq, k) * absdot != 0.f);
-                                    }
-                                }
+                                    for (int k = 0; k < 4; ++k)
+                                        if (4 * c + k < MI_NSPEC) fNonBlack |= (Get4(fq, k) * absdot != 0.f);
+                                };
                                 // (when the light's pdf for wi is 0 the estimate ends here, integrator.cpp:186-187:
                                 // nothing reads the spectrum then, so it is not formed)
-#pragma unroll 1
-                                for (int c = 0; go && !dark && c < EXP_NQ; ++c) {
+                                auto misQuad = [&](int c, const float4 &fq, const float4 &Lq) {
                                     const float4 bt = loadBeta(c);
                                     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-                                    const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
-                                    float4 Lq = make_float4(0.f, 0.f, 0.f, 0.f);
-                                    if (!isEnvLight) Lq = LoadSpec4(light.L, c);
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
                                         const int b = 4 * c + k;
@@ -2034,6 +2106,75 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         }
                                     }
                                     tile.q[c][threadIdx.x] = out;
+                                };
+                                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if constexpr (SIMPLE_SPECTRA) {
+                                    const SimpleLobes<NL> sl = MakeSimpleLobes<NL, TM>(ev);
+                                    const mi_bxdf *bx = mat->bxdf;
+                                    const bool allSelOne = __all(selIsOne);
+                                    const bool divFast = sl.divisorsFast && spDiv.fast && (selIsOne || selDiv.fast);
+                                    unsigned accF = 0u;
+                                    if (dark) {
+                                        auto quad = [&](int c, auto exactTag) {
+                                            constexpr bool EXACT = decltype(exactTag)::value;
+                                            DivTrack trk;
+                                            trk.Reset(sl.divisorsFast);
+                                            float4 fq = SimpleEvalQuad<NL, TM, EXACT>(sl, bx, c, trk);
+                                            if (c == NQ - 1) fq.w = 0.f;
+                                            unsigned aF = 0u;
+#pragma unroll
+                                            for (int k = 0; k < 4; ++k) OrNonZero(aF, Get4(fq, k) * absdot);
+                                            if (!EXACT && __any(trk.Bad())) return false;
+                                            accF |= aF;
+                                            return true;
+                                        };
+#pragma unroll 1
+                                        for (int c = 0; c < EXP_NQ; ++c)
+                                            if (!quad(c, std::false_type{})) quad(c, std::true_type{});
+                                    }
+                                    if (go && !dark) {
+                                        auto quad = [&](int c, auto exactTag) {
+                                            constexpr bool EXACT = decltype(exactTag)::value;
+                                            DivTrack trk;
+                                            trk.Reset(divFast);
+                                            const float4 bt = loadBeta(c);
+                                            float4 fq = SimpleEvalQuad<NL, TM, EXACT>(sl, bx, c, trk), Lq = isEnvLight ? zero4 : LoadSpec4(light.L, c);
+                                            if (c == NQ - 1) { fq.w = 0.f; Lq.w = 0.f; }
+                                            unsigned aF = 0u;
+                                            float o[4];
+#pragma unroll
+                                            for (int k = 0; k < 4; ++k) {
+                                                const float f = Get4(fq, k) * absdot;
+                                                OrNonZero(aF, f);
+                                                const float LiB = isEnvLight ? ((4 * c + k < MI_NSPEC) ? IllumBin(s, envLe, min(4 * c + k, MI_NSPEC - 1)) : 0.f) : Get4(Lq, k);
+                                                const float x = (f * LiB) * weight;
+                                                float Ld;
+                                                if constexpr (EXACT) { Ld = DivBy(x, spDiv); if (!selIsOne) Ld = DivBy(Ld, selDiv); }
+                                                else {
+                                                    Ld = DivFast(x, spDiv.d, spDiv.r, trk);
+                                                    if (!allSelOne) { const float Ld2 = DivFast(Ld, selDiv.d, selDiv.r, trk); Ld = selIsOne ? Ld : Ld2; }
+                                                }
+                                                o[k] = Get4(bt, k) * Ld;
+                                            }
+                                            if (!EXACT && __any(trk.Bad())) return false;
+                                            tile.q[c][threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
+                                            accF |= aF;
+                                            return true;
+                                        };
+#pragma unroll 1
+                                        for (int c = 0; c < EXP_NQ; ++c)
+                                            if (!quad(c, std::false_type{})) quad(c, std::true_type{});
+                                    }
+                                    fNonBlack |= accF != 0u;
+                                } else {
+                                    if (dark) {
+#pragma unroll 1
+                                        for (int c = 0; c < EXP_NQ; ++c) darkQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp));
+                                    }
+                                    if (go && !dark) {
+#pragma unroll 1
+                                        for (int c = 0; c < EXP_NQ; ++c) misQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), isEnvLight ? zero4 : LoadSpec4(light.L, c));
+                                    }
                                 }
                                 StoreSpectrumLines(tile, pool, Q_LMIS, slot, EXP_STORE(go && !dark));   // whole 128-B lines, as for the light sample
         STAMP(12);
@@ -2054,7 +2195,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 V3 wo = -rd, wi;
                 float pdf = 0;
                 int sflags = 0;
-                const float u0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot), u1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
+                float u2[2];
+                if constexpr (FUSED_HALTON) { ScrambledDimensionsFused<2>(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim, u2); ps.dim += 2; }
+                else { u2[0] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); u2[1] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); }
+                const float u0 = u2[0], u1 = u2[1];
                 BSDFEvalT<NL> ev;
                 const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
         STAMP(13);
@@ -2068,10 +2212,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     }
                     const Divisor pdfDiv = MakeDivisor(pdf);
                     float maxRR = 0;
-#pragma unroll 1
-                    for (int c = 0; c < EXP_NQ; ++c) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
+                    auto contQuad = [&](int c, const float4 &fq) {  // beta *= f * |wi.ns| / pdf (only meaningful when f is not black)
                         float4 bt = loadBeta(c);
-                        const float4 fq = EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
@@ -2085,6 +2227,46 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             }
                         }
                         tile.q[c][threadIdx.x] = bt;
+                    };
+                    if constexpr (SIMPLE_SPECTRA) {
+                        const SimpleLobes<NL> sl = MakeSimpleLobes<NL, TM>(ev);
+                        const mi_bxdf *bx = mat->bxdf;
+                        const bool divFast = sl.divisorsFast && pdfDiv.fast;
+                        unsigned accF = 0u;
+                        auto quad = [&](int c, auto exactTag) {
+                            constexpr bool EXACT = decltype(exactTag)::value;
+                            DivTrack trk;
+                            trk.Reset(divFast);
+                            const float4 bt = loadBeta(c);
+                            float4 fq = SimpleEvalQuad<NL, TM, EXACT>(sl, bx, c, trk);
+                            if (c == NQ - 1) fq.w = 0.f;
+                            unsigned aF = 0u;
+                            float o[4], mr = maxRR;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float f = Get4(fq, k);
+                                OrNonZero(aF, f);
+                                const float x = f * absdot;
+                                o[k] = Get4(bt, k) * (EXACT ? DivBy(x, pdfDiv) : DivFast(x, pdfDiv.d, pdfDiv.r, trk));
+                                const float rr = o[k] * etaScale;
+                                if (k == 0) mr = (c == 0) ? rr : maxf(mr, rr);
+                                else if (k < 3) mr = maxf(mr, rr);
+                                else mr = (c == NQ - 1) ? mr : maxf(mr, rr);
+                            }
+                            if (c == NQ - 1) o[3] = bt.w;   // (the pad word keeps what it held)
+                            if (!EXACT && __any(trk.Bad())) return false;
+                            tile.q[c][threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
+                            accF |= aF;
+                            maxRR = mr;
+                            return true;
+                        };
+#pragma unroll 1
+                        for (int c = 0; c < EXP_NQ; ++c)
+                            if (!quad(c, std::false_type{})) quad(c, std::true_type{});
+                        fNonBlack |= accF != 0u;
+                    } else {
+#pragma unroll 1
+                        for (int c = 0; c < EXP_NQ; ++c) contQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp));
                     }
                     // (the new throughput is stored below, once it is known that a later vertex will read it)
                     bool killed = false;
@@ -2152,9 +2334,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         }
     }
     STAMP(17);
-    __shared__ unsigned sShadow[5], sMis[5];
-    const unsigned posS = BlockReserve(&ctr->shadowCount.v, wantShadow, sShadow);
-    const unsigned posM = BlockReserve(&ctr->misCount.v, wantMis, sMis);
+    __shared__ unsigned sAppend[10];
+    unsigned posS, posM;
+    BlockReserve2(&ctr->shadowCount.v, wantShadow, &ctr->misCount.v, wantMis, sAppend, &posS, &posM);
     if (wantShadow) pool.shadowQ[posS] = slot;
     if (wantMis) pool.misQ[posM] = slot;
     CountAdd(&Stats(ctr).totalPaths, totalPaths);

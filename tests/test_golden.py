@@ -80,7 +80,7 @@ def _wavefront_against_fixture(integ, z):
     tc.check_wavefront(integ, rays, closest, occluded_dev)
 
 
-def _check_against_fixture(film, weight, z, spp, tol, frac_over, max_over, exact_max=2e-4):
+def _check_against_fixture(film, weight, z, spp, tol, frac_over, max_over, exact_max=2e-4, exact_rel=None):
     """film / weight: the device's result on the fixture's pixels. Exact-libm oracle: image relative L2 < 1e-6 (x sqrt(spp / 256)
     beyond 256 spp: the film is a float sum of spp terms per pixel whose order differs -- atomics on the device, sample order
     in the reference) and every pixel within 2e-4 of the mean radiance; glibc-libm oracle: BASELINE's target --
@@ -90,7 +90,7 @@ def _check_against_fixture(film, weight, z, spp, tol, frac_over, max_over, exact
     gx = z["film_exact"]
     mean = gx.mean() / spp
     px = np.sqrt(((film.astype(np.float64) - gx) ** 2).mean(axis=-1)) / spp
-    assert _rel_l2(film, gx) < 1e-6 * max(1.0, (spp / 256.0) ** 0.5), _rel_l2(film, gx)
+    assert _rel_l2(film, gx) < (exact_rel or 1e-6 * max(1.0, (spp / 256.0) ** 0.5)), _rel_l2(film, gx)
     assert px.max() < exact_max * mean, px.max() / mean
     gold = z["film"]
     pg = np.sqrt(((film.astype(np.float64) - gold) ** 2).mean(axis=-1)) / spp
@@ -261,7 +261,13 @@ def test_gpu_procedural_10M_triangles_2048spp_in_8_shards(pt, tmp_path):
         assert abs(c0[k] - counters[k]) <= 1e-4 * counters[k] + 3, (k, c0[k], counters[k])
     ys, xs = z["ys"].astype(int), z["xs"].astype(int)
     zz = {"film": z["film"], "film_exact": z["film_exact"], "weight": z["weight"]}
-    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, 1e-4, 2e-3, 0.05)
+    # Exact-mode film bar at 2048 spp: 2e-5 (measured 8.6e-6, spread over all pixels, per-pixel maximum 1.6e-5). It is the
+    # REFERENCE's accumulation, not a path: FilmTile::AddSample adds a pixel's samples one after the other in float, and where
+    # they are (nearly) the same value -- a pixel on an emitter -- every add rounds the same way: the sum drifts by N ulp / 2
+    # (1.6e-5 at 2048 equal samples), linear in N; the device adds a pixel's samples in groups of 64 first and stays within
+    # 7e-7 of the exact sum. The device's own passes agree to 2.3e-7 whatever their structure (tools/diag/spp_scaling.py:
+    # one 2048-spp pass, eight 256-spp passes, other pool sizes); with random sample values both orders agree to 7e-7.
+    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, 1e-4, 2e-3, 0.05, exact_rel=2e-5)
     # the 8 shards of configs[4] through ShardedFrame.step
     film32 = ptdist.device_film_tensor(integ)
     acc = np.zeros((h, w, 32), np.float32)
@@ -284,4 +290,4 @@ def test_gpu_procedural_10M_triangles_2048spp_in_8_shards(pt, tmp_path):
     assert _rel_l2(acc[..., :31], full) < 1e-6
     inner = (w0[ys, xs] == spp) & (acc[ys, xs, 31] == spp)   # (pixels no border-exact sample reaches: six in seven at 2048 spp)
     assert inner.mean() > 0.8
-    assert _rel_l2(acc[ys, xs][inner][:, :31], z["film_exact"][inner]) < 1e-6 * (spp / 256.0) ** 0.5
+    assert _rel_l2(acc[ys, xs][inner][:, :31], z["film_exact"][inner]) < 2e-5   # (the reference's sequential float sums: above)
