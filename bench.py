@@ -95,13 +95,19 @@ def main():
     # The scene is parsed and its BVH built ONCE per job: rank 0 loads the .pbrt text and saves the flat scene as a binary
     # file, the other ranks read the arrays back (mi_scene_save_cache / mi_scene_load_cache) -- eight ranks parsing
     # 200 MB of text and building the same 10M-triangle BVH side by side is what the reference's single process never does.
-    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mipt_scene_%s_%s.bin" % (os.environ.get("MASTER_PORT", "solo"), os.getpid() if world == 1 else "job"))
+    # The cache and the generated scene text live in a directory of this job's own (mkdtemp: mode 0700, an unguessable name --
+    # never a predictable path in a shared /tmp that another user could have planted), whose name rank 0 hands to the others.
+    import shutil
+    import tempfile
+    job_dir = tempfile.mkdtemp(prefix="mipt_job_") if rank == 0 else None
+    job_dir = ptdist.broadcast_string(job_dir)
+    cache = os.path.join(job_dir, "scene.bin")
     t_load = time.perf_counter()
     if rank == 0:
         if a.procedural_tris > 0:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import make_procedural_scene as mps
-            a.scene = os.path.join(os.environ.get("TMPDIR", "/tmp"), "procedural_%d_%s.pbrt" % (a.procedural_tris, os.environ.get("MASTER_PORT", "solo")))
+            a.scene = os.path.join(job_dir, "procedural_%d.pbrt" % a.procedural_tris)
             with open(a.scene, "w") as fh:
                 mps.write_scene(fh, a.procedural_tris, 700, total_spp, 7, 5)
         scene = pt.Scene(a.scene, spp=total_spp)
@@ -112,11 +118,8 @@ def main():
         scene = pt.Scene(cache=cache)
     t_load = time.perf_counter() - t_load
     ptdist.barrier()
-    if rank == 0 and world > 1:
-        try:
-            os.remove(cache)
-        except OSError:
-            pass
+    if rank == 0:
+        shutil.rmtree(job_dir, ignore_errors=True)
     integ = pt.CreatePathIntegrator(scene, local_rank)
     w, h = scene.film_size
     film32 = ptdist.device_film_tensor(integ)   # [H, W, 32] view of the renderer's resident film: reduced in place
@@ -259,7 +262,8 @@ def main():
             "config": {"workload": "%s %dx%d, %d spp per step (one full frame), film tiles sharded over %d GPU(s)"
                                    % (workload, w, h, total_spp, world),
                        "triangles": int(scene.stats["n_triangles"]), "scene_load_s": round(t_load, 2),
-                       "spp": total_spp, "resolution": [w, h], "max_depth": int(scene.desc.integrator.max_depth)},
+                       "spp": total_spp, "resolution": [w, h], "max_depth": int(scene.desc.integrator.max_depth),
+                       "path_pool_slots": integ.pool_info()[0], "path_pool_gb": round(integ.pool_info()[1] / 1e9, 2)},
             "msamples_per_s": round(msamples, 2), "rays": int(rays), "camera_samples": int(tot["camera_rays"]),
             "seconds": round(dt, 4),
             "film_mean_per_sample": round(float(film32[..., :31].mean().item()) / total_spp, 6),

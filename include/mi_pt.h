@@ -283,8 +283,9 @@ typedef struct mi_film {
  * global samplers: sample (pixel, n) is a pure function of its index, so a parallel render reproduces the reference sample
  * for sample. RANDOM (src/samplers/random.cpp:42-60) draws from one PCG32 stream per film tile in the reference, in the order
  * its thread happens to consume them -- the count per sample depends on the path -- which no parallel schedule can
- * reproduce; here every camera sample owns a PCG32 stream of its own (sequence number = sample-bounds pixel index *
- * samples_per_pixel + n, rng.h:98-105), consumed in the reference's order: the same estimator on other random numbers. */
+ * reproduce; here every camera sample owns a PCG32 stream of its own (sequence number = n * pixel count of the sample bounds +
+ * pixel index, rng.h:98-105: distinct for every pixel and sample number, also when a pass renders sample numbers beyond
+ * samples_per_pixel), consumed in the reference's order: the same estimator on other random numbers. */
 typedef enum mi_sampler_type { MI_SAMPLER_HALTON = 0, MI_SAMPLER_SOBOL = 1, MI_SAMPLER_RANDOM = 2 } mi_sampler_type;
 #define MI_SOBOL_MATRIX_SIZE 52 /* SobolMatrixSize, src/core/sobolmatrices.h:48 */
 typedef struct mi_sampler {
@@ -391,6 +392,11 @@ int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats);
  * [4]=shadow, [5]=mis, [6]=closest-hit traversal kernel alone. The sub-renderers of one
  * render run concurrently, so [1..6] add up to more than [0]. */
 int mi_pt_last_timings(mi_pt *pt, double *seconds, int n);
+/* The path pool the last render ran on (summed over the renderer's sub-renderers): resident path slots and the device bytes
+ * behind them. mi_render_params.path_pool = 0 asks for the default (one slot per camera sample of the shard, 4M .. 96M), which
+ * takes at most 65 % of the free device memory and falls back to half, a quarter, ... if the allocation fails: this says what
+ * was had. */
+int mi_pt_pool_info(mi_pt *pt, uint64_t *slots, uint64_t *bytes);
 void mi_pt_destroy(mi_pt *pt);
 const char *mi_pt_last_error(void);
 

@@ -173,9 +173,9 @@ struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one 
         if (s.type == MI_SAMPLER_SOBOL)   // SobolSampler::GetIndexForSample, sobol.cpp:42-45
             intervalSampleIndex = (int64_t)SobolIntervalToIndex(s, (uint64_t)sampleNum, curPx - d.film.sample_bounds[0], curPy - d.film.sample_bounds[1]);
         else if (s.type == MI_SAMPLER_RANDOM) {   // one stream per camera sample (see mi_sampler_type)
-            const int64_t w = d.film.sample_bounds[2] - d.film.sample_bounds[0];
+            const int64_t w = d.film.sample_bounds[2] - d.film.sample_bounds[0], h = d.film.sample_bounds[3] - d.film.sample_bounds[1];
             const int64_t pix = (int64_t)(curPy - d.film.sample_bounds[1]) * w + (curPx - d.film.sample_bounds[0]);
-            rng.SetSequence((uint64_t)(pix * s.samples_per_pixel + sampleNum));
+            rng.SetSequence((uint64_t)(sampleNum * (w * h) + pix));   // (distinct for every pixel and sample number of any pass)
         } else intervalSampleIndex = offsetForCurrentPixel + sampleNum * s.sample_stride;
     }
     Float SampleDimension(int64_t index, int dim) const {  // halton.cpp:120-127 / sobol.cpp:47-59

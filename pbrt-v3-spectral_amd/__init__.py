@@ -218,6 +218,7 @@ def hip_lib():
                                      C.POINTER(Counters)]
         lib.mi_pt_device_film.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         lib.mi_pt_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        lib.mi_pt_pool_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.mi_pt_destroy.argtypes = [C.c_void_p]
         lib.mi_pt_last_error.restype = C.c_char_p
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
@@ -363,6 +364,12 @@ class PathIntegrator:
         t = (C.c_double * 8)()
         hip_lib().mi_pt_last_timings(self._h, t, 8)
         return list(t)
+
+    def pool_info(self):
+        """(slots, bytes) of the path pool the last render ran on (mi_pt_pool_info)."""
+        n, b = C.c_uint64(), C.c_uint64()
+        hip_lib().mi_pt_pool_info(self._h, C.byref(n), C.byref(b))
+        return int(n.value), int(b.value)
 
     def device_film(self):
         p = C.c_void_p()

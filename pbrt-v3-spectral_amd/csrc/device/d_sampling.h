@@ -102,9 +102,11 @@ DEV uint32_t PcgNext(uint64_t &state, uint64_t inc) {
 }
 DEV float PcgFloat(uint64_t &state, uint64_t inc) { return minf(kOneMinusEpsilon, (float)PcgNext(state, inc) * 0x1p-32f); }
 DEV uint64_t RandomStreamInc(const DScene &s, int px, int py, long long sampleNum) {
-    const long long w = s.sampleBounds[2] - s.sampleBounds[0];
+    // stream number = sample number * pixel count + pixel index: distinct for every (pixel, sample number) whatever range of
+    // sample numbers a pass renders (mi_render_params.sample_begin / spp_override may go beyond the scene's samples per pixel)
+    const long long w = s.sampleBounds[2] - s.sampleBounds[0], h = s.sampleBounds[3] - s.sampleBounds[1];
     const long long pix = (long long)(py - s.sampleBounds[1]) * w + (px - s.sampleBounds[0]);
-    return (((uint64_t)(pix * s.samplesPerPixel + sampleNum)) << 1u) | 1u;
+    return (((uint64_t)(sampleNum * (w * h) + pix)) << 1u) | 1u;
 }
 DEV uint64_t RandomStreamStart(uint64_t inc) {   // RNG::SetSequence, rng.h:98-105
     uint64_t state = 0u;

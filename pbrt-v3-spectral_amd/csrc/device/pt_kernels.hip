@@ -72,6 +72,7 @@ constexpr int BLOCK = 256;
 #endif
 constexpr int STACK_LDS = MIPT_STACK_LDS;       // traversal stack entries (node, meta, tMin) staged in LDS per lane
 constexpr int STACK_SPILL = 64 - STACK_LDS;     // deeper entries (pbrt allows 64 in total, bvh.cpp:670)
+static_assert(STACK_LDS >= 1 && STACK_LDS <= 63 && STACK_LDS * BLOCK * 12 <= 160 * 1024, "MIPT_STACK_LDS: 1..63 entries, and the block's stack must fit the CU's LDS");
 
 // ---- float planes
 enum : int {
@@ -612,10 +613,13 @@ constexpr int TRI_BATCH = MIPT_TRI_BATCH;
 #ifndef MIPT_COOP_KMAX
 #define MIPT_COOP_KMAX 4
 #endif
+static_assert(MIPT_TRAV_BLOCKS_PER_CU >= 1 && MIPT_TRAV_BLOCKS_PER_CU <= 8 && MIPT_REFILL_BELOW >= 1 && MIPT_REFILL_BELOW <= 64 && MIPT_TRI_BATCH >= 1 &&
+              MIPT_TRI_BATCH <= 64 && MIPT_COOP_KMAX >= 1 && MIPT_COOP_KMAX <= 8, "traversal tuning macros out of range");
 constexpr int COOP_KMAX = MIPT_COOP_KMAX;   // (triangle, ray) pairs a waiting lane hands to the wave per pass (pbrt's default leaf size)
 #ifndef MIPT_TRAV_CHUNK
 #define MIPT_TRAV_CHUNK 128
 #endif
+static_assert(MIPT_TRAV_CHUNK >= 64 && MIPT_TRAV_CHUNK <= (1 << 20), "MIPT_TRAV_CHUNK: at least a wave's worth of entries per cursor atomic");
 constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserves per cursor atomic (twice that for launches of
                                              // 8M rays and more: the cursor word takes ~88 adds/us, and 30M rays in chunks of
                                              // 128 are 234k adds -- same-box A/B: killeroo +3.7 % with 256, the 10M-triangle
@@ -986,6 +990,13 @@ DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const
 #define MIPT_SLOT_CHUNKS 8
 #endif
 constexpr int SLOT_CHUNKS = MIPT_SLOT_CHUNKS;
+// k_resolve_extend keeps a slot's rank within its (chunk, wave, class) in 8 bits per chunk of two 32-bit words (rankLo /
+// rankHi), k_generate a bit per chunk in 32-bit masks and the block's slot numbers in 16 bits: more than 8 chunks would
+// shift ranks out of their word (round 2's `-DMIPT_SLOT_CHUNKS=16` tuning build queued slots twice, overran a ray queue and
+// died of a GPU memory fault -- the "Aborted" of gpurun_out/call_var.log -- which also left the device unusable for the two
+// builds benched after it in that call). The tuning macros are checked where they are defined.
+static_assert(SLOT_CHUNKS >= 1 && SLOT_CHUNKS <= 8, "MIPT_SLOT_CHUNKS: 1..8 (rank words of k_resolve_extend, chunk masks of k_generate)");
+static_assert(SLOT_CHUNKS * BLOCK / 2 + SLOT_CHUNKS * BLOCK / 4 <= BLOCK * 33, "k_generate: the free-slot list and its flags live in the flush rows");
 
 template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, DevCounters *ctr) {
@@ -2549,6 +2560,7 @@ struct SubRenderer {
     hipEvent_t evIter[2][N_EV] = {{nullptr}};  // per-iteration kernel boundaries, two alternating sets
     double t[7] = {0};
     int poolQuadPlanes = 0;   // spectral planes the pool was allocated with (spectralpath needs one set more)
+    size_t poolBytes = 0;     // bytes of device memory behind the pool
     unsigned long long iterations = 0;
     DevCounters result{};
 };
@@ -2600,6 +2612,12 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
     return MI_OK;
 }
 
+// Device bytes of one path slot: planes, records, spectra and its entries in the queues.
+size_t PoolSlotBytes(int nQuadPlanes) {
+    return (size_t)P_COUNT * sizeof(float) + (size_t)nQuadPlanes * sizeof(float4) + (size_t)R_COUNT * sizeof(float4) + (size_t)I_COUNT * sizeof(int) +
+           (size_t)(3 + MAX_CLASSES + 3) * sizeof(uint32_t);
+}
+
 void FreePool(Pool &p) {
     hipFree(p.f); hipFree(p.q); hipFree(p.r); hipFree(p.i); hipFree(p.shadowQ); hipFree(p.extQ); hipFree(p.misQ); hipFree(p.shadeQ); hipFree(p.ovfQ);
     p = Pool{};   // n = 0, every pointer null: a later render cannot mistake a half-built pool for a usable one
@@ -2612,6 +2630,7 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     if (p.n == n && p.f && sub.poolQuadPlanes == nQuadPlanes) return MI_OK;
     FreePool(p);
     sub.poolQuadPlanes = 0;
+    sub.poolBytes = 0;
     Pool t{};
     const bool ok = hipMalloc((void **)&t.f, (size_t)P_COUNT * n * sizeof(float)) == hipSuccess &&
                     hipMalloc((void **)&t.q, (size_t)nQuadPlanes * n * sizeof(float4)) == hipSuccess &&
@@ -2631,6 +2650,7 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
     t.n = n;
     p = t;
     sub.poolQuadPlanes = nQuadPlanes;
+    sub.poolBytes = (size_t)n * PoolSlotBytes(nQuadPlanes);
     return MI_OK;
 }
 
@@ -2677,7 +2697,14 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (d->tri_mesh[i] >= d->n_meshes) { g_err = "triangle mesh index out of range"; return MI_ERR_INVALID; }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         if (d->materials[i].n_bxdfs < 0 || d->materials[i].n_bxdfs > MI_MAX_BXDFS) { g_err = "material lobe count out of range"; return MI_ERR_INVALID; }
-        if (d->materials[i].bump_tex >= (int)d->n_textures) { g_err = "mi_material.bump_tex out of range"; return MI_ERR_INVALID; }
+        if (d->materials[i].bump_tex >= (int)d->n_textures || d->materials[i].bump_tex < -1) { g_err = "mi_material.bump_tex out of range"; return MI_ERR_INVALID; }
+        for (int k = 0; k < 2; ++k) {   // roughness maps: float image textures with a pyramid behind them (EvalFloatImageTexture)
+            const int rt = d->materials[i].rough_tex[k];
+            if (rt < -1 || rt >= (int)d->n_textures) { g_err = "mi_material.rough_tex out of range"; return MI_ERR_INVALID; }
+            if (rt >= 0 && (d->textures[rt].type != MI_TEX_IMAGEMAP || (uint32_t)d->textures[rt].mipmap >= d->n_mipmaps)) {
+                g_err = "mi_material.rough_tex must name an image texture with a mipmap"; return MI_ERR_INVALID;
+            }
+        }
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const mi_light &l = d->lights[i];
@@ -3394,6 +3421,17 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         poolN = (uint32_t)std::min<unsigned long long>(3ull << 25, std::max<unsigned long long>(floorN, quarter));
     }
     poolN = std::max<uint32_t>(BLOCK, poolN / subCount / BLOCK * BLOCK);
+    if (rp->path_pool == 0) {
+        // the default is a preference: it takes at most 65 % of what the device has free (counting what this sub-renderer's
+        // present pool would give back), so that what comes after the pool -- the film staging of the hand-over, RCCL's
+        // buffers at the first collective, another renderer in the process -- still finds memory
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t budget = (size_t)(0.65 * (double)(freeB + sub.poolBytes)) / (size_t)subCount;
+            const size_t fit = budget / PoolSlotBytes(Q_COUNT + (s.nBands > 1 ? NQ : 0)) / BLOCK * BLOCK;
+            if (fit < poolN) poolN = (uint32_t)std::max<size_t>(fit, (size_t)BLOCK);
+        } else (void)hipGetLastError();
+    }
     if (wd.totalWork < poolN) poolN = (uint32_t)((wd.totalWork + BLOCK - 1) / BLOCK * BLOCK);
     if (poolN < BLOCK) poolN = BLOCK;
     int rc = EnsurePool(sub, poolN, Q_COUNT + (s.nBands > 1 ? NQ : 0));
@@ -3499,6 +3537,10 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
     hipStream_t st = (hipStream_t)rp->stream;
     if (!(rp->flags & MI_RENDER_ACCUMULATE)) HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));
     HIPCHK(hipStreamSynchronize(st));
+    if (!(rp->flags & MI_RENDER_FILM_ON_DEVICE)) {   // the hand-over's staging before the pools size themselves
+        if (film_sum && !pt->stageSum) HIPCHK(hipMalloc((void **)&pt->stageSum, pt->nPix * 31 * sizeof(float)));
+        if (weight_sum && !pt->stageW) HIPCHK(hipMalloc((void **)&pt->stageW, pt->nPix * sizeof(float)));
+    }
     const int nSub = (int)pt->subs.size();
     std::vector<int> rcs(nSub, MI_OK);
     std::vector<std::string> errs(nSub);
@@ -3548,9 +3590,7 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         const bool onDev = (rp->flags & MI_RENDER_FILM_ON_DEVICE) != 0;
         float *dSum = nullptr, *dW = nullptr;
         if (onDev) { dSum = film_sum; dW = weight_sum; }
-        else {   // staging for the host hand-over: allocated once per renderer, freed by mi_pt_destroy
-            if (film_sum && !pt->stageSum) HIPCHK(hipMalloc((void **)&pt->stageSum, pt->nPix * 31 * sizeof(float)));
-            if (weight_sum && !pt->stageW) HIPCHK(hipMalloc((void **)&pt->stageW, pt->nPix * sizeof(float)));
+        else {   // staging for the host hand-over: allocated once per renderer (above), freed by mi_pt_destroy
             if (film_sum) dSum = pt->stageSum;
             if (weight_sum) dW = pt->stageW;
         }
@@ -3570,6 +3610,13 @@ int mi_pt_device_film(mi_pt *pt, void **dev_ptr, uint64_t *n_floats) {
     if (!pt || !dev_ptr || !n_floats) { g_err = "null argument"; return MI_ERR_INVALID; }
     *dev_ptr = pt->film;
     *n_floats = pt->nPix * 32;
+    return MI_OK;
+}
+
+int mi_pt_pool_info(mi_pt *pt, uint64_t *slots, uint64_t *bytes) {
+    if (!pt || !slots || !bytes) { g_err = "null argument"; return MI_ERR_INVALID; }
+    *slots = 0; *bytes = 0;
+    for (const SubRenderer &sub : pt->subs) { *slots += sub.pool.n; *bytes += sub.poolBytes; }
     return MI_OK;
 }
 

@@ -917,7 +917,7 @@ void Api::WorldEnd() {
         d.sampler.n_dims = nDims;
         if (d.sampler.type == MI_SAMPLER_SOBOL) {
             const int extent = std::max(d.film.sample_bounds[2] - d.film.sample_bounds[0], d.film.sample_bounds[3] - d.film.sample_bounds[1]);
-            const int nSobol = std::min(nDims, 256);
+            const int nSobol = std::min(nDims, 1024);   // NumSobolDimensions, sobolmatrices.h:47
             if (!ComputeSobolTables(extent, nSobol, scene, &d.sampler.sobol_resolution, &d.sampler.sobol_log2_resolution)) {
                 Err("Sampler \"sobol\": film resolution beyond the tabulated pixel-index matrices; using halton.");
                 d.sampler.type = MI_SAMPLER_HALTON;

@@ -121,6 +121,23 @@ class ShardedFrame:
                 "imbalance": round(max(render) / max(1e-12, sum(render) / len(render)), 4)}
 
 
+def broadcast_string(value, src=0):
+    """rank `src`'s string on every rank (None elsewhere on entry). No-op for a single process."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    import torch
+    dev = _collective_device()
+    raw = value.encode() if dist.get_rank() == src else b""
+    n = torch.tensor([len(raw)], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=dev)
+    if dist.get_rank() == src:
+        buf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+    dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().tolist()).decode()
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -21,8 +23,10 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("ptdist", os.path.join(%(root)r, "pbrt-v3-spectral_amd", "distributed.py"))
 ptdist = importlib.util.module_from_spec(spec); spec.loader.exec_module(ptdist)
 rank, world, local = ptdist.init_from_env(backend="gloo")
-# rank 0 loads the scene and saves the binary cache, rank 1 reads it back (as bench.py does)
-cache = %(cache)r
+# rank 0 loads the scene and saves the binary cache, rank 1 reads it back (as bench.py does: the file sits in a directory
+# of the job's own whose name rank 0 hands over)
+cache = ptdist.broadcast_string(%(cache)r if rank == 0 else None)
+assert cache == %(cache)r
 if rank == 0:
     scene = pt.Scene(text=st.material_zoo(res=48, spp=4))
     scene.save_cache(cache)
@@ -93,6 +97,26 @@ def test_scene_cache_round_trip_and_rejection(pt, ob, tmp_path):
         pt.Scene(cache=str(tmp_path / "foreign.bin"))
     with pytest.raises(RuntimeError, match="cannot open"):
         pt.Scene(cache=str(tmp_path / "missing.bin"))
+    # forged files: an element count whose byte size wraps around 2^64 (the loader divides instead of multiplying), a table
+    # shorter than the counts of the description promise (mi_pt_create would read past it), a symbolic link in place of the file
+    import struct
+    import pbrt_v3_spectral_amd as m
+    s = pt.Scene(text=st.furnace_point(res=8, spp=1))
+    good = str(tmp_path / "good.bin")
+    s.save_cache(good)
+    raw = bytearray(open(good, "rb").read())
+    head = 8 + 4 * 4 + C.sizeof(m.SceneDesc) + C.sizeof(m.SceneStats) - 3 * 4 + 2   # magic, 4 words, desc, stats (7 ints), 2 flags
+    assert struct.unpack_from("<Q", raw, head)[0] == s.desc.n_nodes   # (the first array's count: the BVH nodes)
+    forged = bytearray(raw)
+    struct.pack_into("<Q", forged, head, (1 << 64) // 32 + 1)           # * sizeof(mi_bvh_node) wraps to 32
+    (tmp_path / "wrap.bin").write_bytes(bytes(forged))
+    with pytest.raises(RuntimeError, match="truncated or inconsistent"):
+        pt.Scene(cache=str(tmp_path / "wrap.bin"))
+    os.symlink(good, str(tmp_path / "link.bin"))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        pt.Scene(cache=str(tmp_path / "link.bin"))
+    assert pt.Scene(cache=good).stats == s.stats
+    assert (os.stat(good).st_mode & 0o077) == 0   # written for the owner alone
 
 
 def test_shards_partition_the_tiles(pt, ob):

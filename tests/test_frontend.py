@@ -776,3 +776,27 @@ def test_checkerboard_texture_binding(pt):
                          ('Texture "c" "spectrum" "checkerboard" "string mapping" "planar"\n', "mapping")]:
         s = pt.Scene(text=head + body + "WorldEnd\n")
         assert any(needle in e for e in s.errors), (needle, s.errors)
+
+
+def test_tuning_macros_outside_their_range_do_not_compile():
+    """Round 2's `-DMIPT_SLOT_CHUNKS=16` tuning build compiled, queued slots twice (k_resolve_extend packs a slot's rank in
+    8 bits per chunk of two 32-bit words) and died of a GPU memory fault. The kernels' tuning macros are now checked where
+    they are defined: the build refuses the value."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "pbrt-v3-spectral_amd", "csrc", "device", "pt_kernels.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-DMIPT_SLOT_CHUNKS=16", "-DMIPT_PART=0",
+                        "--offload-device-only", "-fsyntax-only", src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "MIPT_SLOT_CHUNKS: 1..8" in r.stdout
+
+
+def test_sobol_tables_cover_deep_paths(pt, ob):
+    """The reference's generator matrices have NumSobolDimensions = 1024 rows (sobolmatrices.h:47); a path of maxdepth 40
+    needs 6 + 8 * 40 = 326 of them (round 2 shipped the first 256: such a scene parsed and then failed in mi_pt_create)."""
+    text = st.furnace_point(res=8, spp=4, depth=40).replace('Sampler "halton"', 'Sampler "sobol"')
+    s = pt.Scene(text=text)
+    assert s.errors == [] and s.desc.sampler.type == 1 and s.desc.sampler.n_sobol_dims >= 6 + 8 * 40
+    film, weight, c, _ = ob.render(s, n_threads=2)
+    assert c.camera_rays == 8 * 8 * 4 and abs(film.mean() / 4 - 1) < 0.1   # (the furnace: radiance 1)
