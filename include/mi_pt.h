@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 8
+#define MI_ABI_VERSION 9
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -286,7 +286,16 @@ typedef struct mi_film {
  * reproduce; here every camera sample owns a PCG32 stream of its own (sequence number = n * pixel count of the sample bounds +
  * pixel index, rng.h:98-105: distinct for every pixel and sample number, also when a pass renders sample numbers beyond
  * samples_per_pixel), consumed in the reference's order: the same estimator on other random numbers. */
-typedef enum mi_sampler_type { MI_SAMPLER_HALTON = 0, MI_SAMPLER_SOBOL = 1, MI_SAMPLER_RANDOM = 2 } mi_sampler_type;
+/* ZEROTWO ("02sequence" / "lowdiscrepancy", src/samplers/zerotwosequence.cpp:53-69) and STRATIFIED (src/samplers/stratified.cpp:43-71)
+ * are PixelSamplers (src/core/sampler.cpp:100-135): at StartPixel they tabulate, for each of `pixel_dims` sampled dimensions, one
+ * 1D and one 2D value per sample of the pixel -- randomly scrambled / jittered and shuffled with the sampler's RNG -- and a
+ * sample's Get1D / Get2D calls read the next 1D / 2D table until the tables run out, then fall back to that RNG. In the
+ * reference the RNG is one stream per film tile, carried through its pixels and samples in the order the thread consumes it
+ * (a count that depends on the paths). The convention here, identical on device and oracle, as for RANDOM: the tables of pixel
+ * p come from a PCG32 stream of their own (sequence number = pixel index of the sample bounds), generated in the reference's
+ * order (all 1D tables, then all 2D tables); the fall-back draws of sample n of pixel p come from the stream
+ * (n + 1) * pixel count + pixel index. Same estimator, same stratification, other random numbers. */
+typedef enum mi_sampler_type { MI_SAMPLER_HALTON = 0, MI_SAMPLER_SOBOL = 1, MI_SAMPLER_RANDOM = 2, MI_SAMPLER_ZEROTWO = 3, MI_SAMPLER_STRATIFIED = 4 } mi_sampler_type;
 #define MI_SOBOL_MATRIX_SIZE 52 /* SobolMatrixSize, src/core/sobolmatrices.h:48 */
 typedef struct mi_sampler {
     int64_t samples_per_pixel; /* SOBOL: rounded up to a power of two (sobol.h:52) */
@@ -306,6 +315,10 @@ typedef struct mi_sampler {
     const uint32_t *sobol_matrices; /* [n_sobol_dims * 52] SobolMatrices32 */
     const uint64_t *sobol_vdc;      /* [52] VdCSobolMatrices[log2_resolution - 1] */
     const uint64_t *sobol_vdc_inv;  /* [52] VdCSobolMatricesInv[log2_resolution - 1] */
+    /* ABI v9: the pixel samplers */
+    int32_t pixel_dims;             /* ZEROTWO / STRATIFIED: nSampledDimensions ("integer dimensions", default 4) */
+    int32_t x_samples, y_samples;   /* STRATIFIED: samples_per_pixel = x_samples * y_samples */
+    int32_t jitter;                 /* STRATIFIED: "bool jitter" */
 } mi_sampler;
 
 typedef struct mi_integrator {

@@ -140,8 +140,99 @@ struct PCG32 {  // RNG, rng.h:61-144
         uint32_t rot = (uint32_t)(oldstate >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
     }
+    uint32_t UniformUInt32(uint32_t b) {   // rng.h:112-121
+        uint32_t threshold = (~b + 1u) % b;
+        while (true) {
+            uint32_t r = UniformUInt32();
+            if (r >= threshold) return r % b;
+        }
+    }
     Float UniformFloat() { return std::min(OneMinusEpsilon, Float(UniformUInt32() * 0x1p-32f)); }
 };
+
+// ---- the pixel samplers' tables (mi_sampler_type: ZEROTWO, STRATIFIED)
+// Shuffle, sampling.h:150-157
+template <typename T>
+static void Shuffle(T *samp, int count, int nDimensions, PCG32 &rng) {
+    for (int i = 0; i < count; ++i) {
+        int other = i + rng.UniformUInt32(count - i);
+        for (int j = 0; j < nDimensions; ++j) std::swap(samp[nDimensions * i + j], samp[nDimensions * other + j]);
+    }
+}
+// MultiplyGenerator / SampleGeneratorMatrix / GrayCodeSample, lowdiscrepancy.h:93-147
+static uint32_t MultiplyGenerator(const uint32_t *C, uint32_t a) {
+    uint32_t v = 0;
+    for (int i = 0; a != 0; ++i, a >>= 1)
+        if (a & 1) v ^= C[i];
+    return v;
+}
+static Float SampleGeneratorMatrix(const uint32_t *C, uint32_t a, uint32_t scramble = 0) {
+    return std::min((MultiplyGenerator(C, a) ^ scramble) * Float(0x1p-32), OneMinusEpsilon);
+}
+static void GrayCodeSample(const uint32_t *C, uint32_t n, uint32_t scramble, Float *p) {
+    uint32_t v = scramble;
+    for (uint32_t i = 0; i < n; ++i) {
+        p[i] = std::min(v * Float(0x1p-32), OneMinusEpsilon);
+        v ^= C[__builtin_ctz(i + 1)];
+    }
+}
+static void GrayCodeSample2(const uint32_t *C0, const uint32_t *C1, uint32_t n, const uint32_t scramble[2], Float *p /* x, y pairs */) {
+    uint32_t v[2] = {scramble[0], scramble[1]};
+    for (uint32_t i = 0; i < n; ++i) {
+        p[2 * i] = std::min(v[0] * Float(0x1p-32), OneMinusEpsilon);
+        p[2 * i + 1] = std::min(v[1] * Float(0x1p-32), OneMinusEpsilon);
+        v[0] ^= C0[__builtin_ctz(i + 1)];
+        v[1] ^= C1[__builtin_ctz(i + 1)];
+    }
+}
+// The generator matrices: van der Corput's is the bit-reversed identity (lowdiscrepancy.h:155-203), the second Sobol' one
+// Pascal's triangle mod 2 (lowdiscrepancy.h:208-224) -- column i of it is column i - 1 XOR itself shifted right by one.
+struct ZeroTwoMatrices {
+    uint32_t vdc[32], sobol1[32];
+    ZeroTwoMatrices() {
+        for (int i = 0; i < 32; ++i) vdc[i] = 0x80000000u >> i;
+        sobol1[0] = 0x80000000u;
+        for (int i = 1; i < 32; ++i) sobol1[i] = sobol1[i - 1] ^ (sobol1[i - 1] >> 1);
+    }
+};
+static const ZeroTwoMatrices kZeroTwo;
+// VanDerCorput / Sobol2D, lowdiscrepancy.h:149-227
+static void VanDerCorput(int nSamplesPerPixelSample, int nPixelSamples, Float *samples, PCG32 &rng) {
+    uint32_t scramble = rng.UniformUInt32();
+    int totalSamples = nSamplesPerPixelSample * nPixelSamples;
+    GrayCodeSample(kZeroTwo.vdc, totalSamples, scramble, samples);
+    for (int i = 0; i < nPixelSamples; ++i) Shuffle(samples + i * nSamplesPerPixelSample, nSamplesPerPixelSample, 1, rng);
+    Shuffle(samples, nPixelSamples, nSamplesPerPixelSample, rng);
+}
+static void Sobol2D(int nSamplesPerPixelSample, int nPixelSamples, Float *samples /* pairs */, PCG32 &rng) {
+    uint32_t scramble[2];
+    scramble[0] = rng.UniformUInt32();
+    scramble[1] = rng.UniformUInt32();
+    GrayCodeSample2(kZeroTwo.vdc, kZeroTwo.sobol1, nSamplesPerPixelSample * nPixelSamples, scramble, samples);
+    struct P2 { Float x, y; };
+    P2 *sp = reinterpret_cast<P2 *>(samples);
+    for (int i = 0; i < nPixelSamples; ++i) Shuffle(sp + i * nSamplesPerPixelSample, nSamplesPerPixelSample, 1, rng);
+    Shuffle(sp, nPixelSamples, nSamplesPerPixelSample, rng);
+}
+// StratifiedSample1D / 2D, sampling.cpp:42-60
+static void StratifiedSample1D(Float *samp, int nSamples, PCG32 &rng, bool jitter) {
+    Float invNSamples = (Float)1 / nSamples;
+    for (int i = 0; i < nSamples; ++i) {
+        Float delta = jitter ? rng.UniformFloat() : 0.5f;
+        samp[i] = std::min((i + delta) * invNSamples, OneMinusEpsilon);
+    }
+}
+static void StratifiedSample2D(Float *samp /* pairs */, int nx, int ny, PCG32 &rng, bool jitter) {
+    Float dx = (Float)1 / nx, dy = (Float)1 / ny;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            Float jx = jitter ? rng.UniformFloat() : 0.5f;
+            Float jy = jitter ? rng.UniformFloat() : 0.5f;
+            samp[0] = std::min((x + jx) * dx, OneMinusEpsilon);
+            samp[1] = std::min((y + jy) * dy, OneMinusEpsilon);
+            samp += 2;
+        }
+}
 
 struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one pixel sample; RandomSampler with one stream per sample
     const mi_scene_desc &d;
@@ -150,11 +241,48 @@ struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one 
     int dimension = 0;
     int curPx = 0, curPy = 0;
     PCG32 rng;
+    // PixelSampler (sampler.cpp:100-135): the pixel's tables, the sample in hand, the next 1D / 2D table
+    std::vector<std::vector<Float>> samples1D, samples2D;   // [dimension][sample] / [dimension][2 * sample]
+    int64_t curSample = 0;
+    int current1DDimension = 0, current2DDimension = 0;
+    bool IsPixelSampler() const { return d.sampler.type == MI_SAMPLER_ZEROTWO || d.sampler.type == MI_SAMPLER_STRATIFIED; }
+    int64_t PixelIndex() const {
+        const int64_t w = d.film.sample_bounds[2] - d.film.sample_bounds[0];
+        return (int64_t)(curPy - d.film.sample_bounds[1]) * w + (curPx - d.film.sample_bounds[0]);
+    }
+    int64_t PixelCount() const {
+        return (int64_t)(d.film.sample_bounds[2] - d.film.sample_bounds[0]) * (d.film.sample_bounds[3] - d.film.sample_bounds[1]);
+    }
     explicit Sampler(const mi_scene_desc &d) : d(d) {}
+    // ZeroTwoSequenceSampler::StartPixel (zerotwosequence.cpp:53-69) / StratifiedSampler::StartPixel (stratified.cpp:43-71), the
+    // pixel's own stream standing in for the tile's (mi_sampler_type); no sample arrays are requested on this path
+    void StartPixelTables() {
+        const mi_sampler &s = d.sampler;
+        const int spp = (int)s.samples_per_pixel;
+        PCG32 prng;
+        prng.SetSequence((uint64_t)PixelIndex());
+        samples1D.assign(s.pixel_dims, std::vector<Float>(spp));
+        samples2D.assign(s.pixel_dims, std::vector<Float>(2 * (size_t)spp));
+        struct P2 { Float x, y; };
+        if (s.type == MI_SAMPLER_ZEROTWO) {
+            for (auto &v : samples1D) VanDerCorput(1, spp, v.data(), prng);
+            for (auto &v : samples2D) Sobol2D(1, spp, v.data(), prng);
+        } else {
+            for (auto &v : samples1D) {
+                StratifiedSample1D(v.data(), s.x_samples * s.y_samples, prng, s.jitter != 0);
+                Shuffle(v.data(), s.x_samples * s.y_samples, 1, prng);
+            }
+            for (auto &v : samples2D) {
+                StratifiedSample2D(v.data(), s.x_samples, s.y_samples, prng, s.jitter != 0);
+                Shuffle(reinterpret_cast<P2 *>(v.data()), s.x_samples * s.y_samples, 1, prng);
+            }
+        }
+    }
     void StartPixel(int px, int py) {  // halton.cpp:98-118 (offset part of GetIndexForSample)
         const mi_sampler &s = d.sampler;
         curPx = px; curPy = py;
         offsetForCurrentPixel = 0;
+        if (IsPixelSampler()) { StartPixelTables(); return; }
         if (s.type != MI_SAMPLER_HALTON) return;
         const int kMaxResolution = 128;
         if (s.sample_stride > 1) {
@@ -170,6 +298,12 @@ struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one 
     void StartSample(int64_t sampleNum) {
         const mi_sampler &s = d.sampler;
         dimension = 0;
+        if (IsPixelSampler()) {   // PixelSampler::SetSampleNumber; the sample's own stream for the draws beyond the tables
+            curSample = sampleNum;
+            current1DDimension = current2DDimension = 0;
+            rng.SetSequence((uint64_t)((sampleNum + 1) * PixelCount() + PixelIndex()));
+            return;
+        }
         if (s.type == MI_SAMPLER_SOBOL)   // SobolSampler::GetIndexForSample, sobol.cpp:42-45
             intervalSampleIndex = (int64_t)SobolIntervalToIndex(s, (uint64_t)sampleNum, curPx - d.film.sample_bounds[0], curPy - d.film.sample_bounds[1]);
         else if (s.type == MI_SAMPLER_RANDOM) {   // one stream per camera sample (see mi_sampler_type)
@@ -195,10 +329,21 @@ struct Sampler {  // GlobalSampler + HaltonSampler / SobolSampler state for one 
     }
     // arrayStartDim == arrayEndDim == 5 (no sample arrays requested): no skipping, sampler.cpp:178-195
     Float Get1D() {
+        if (IsPixelSampler()) {   // PixelSampler::Get1D, sampler.cpp:119-126
+            if (current1DDimension < (int)samples1D.size()) return samples1D[current1DDimension++][curSample];
+            return rng.UniformFloat();
+        }
         if (d.sampler.type == MI_SAMPLER_RANDOM) { ++dimension; return rng.UniformFloat(); }   // random.cpp:44-48
         return SampleDimension(intervalSampleIndex, dimension++);
     }
     void Get2D(Float u[2]) {
+        if (IsPixelSampler()) {   // PixelSampler::Get2D, sampler.cpp:128-135
+            if (current2DDimension < (int)samples2D.size()) {
+                const std::vector<Float> &v = samples2D[current2DDimension++];
+                u[0] = v[2 * curSample]; u[1] = v[2 * curSample + 1];
+            } else { u[0] = rng.UniformFloat(); u[1] = rng.UniformFloat(); }
+            return;
+        }
         if (d.sampler.type == MI_SAMPLER_RANDOM) { dimension += 2; u[0] = rng.UniformFloat(); u[1] = rng.UniformFloat(); return; }   // random.cpp:50-54
         u[0] = SampleDimension(intervalSampleIndex, dimension);
         u[1] = SampleDimension(intervalSampleIndex, dimension + 1);
@@ -1131,6 +1276,19 @@ float oracle_sample_dimension(const mi_scene_desc *desc, int px, int py, int64_t
     s.StartPixel(px, py);
     s.StartSample(sample_num);
     return s.SampleDimension(s.intervalSampleIndex, dim);
+}
+// The pieces the reference's LowDiscrepancy.GeneratorMatrix / GrayCodeSample tests exercise (tests/sampling.cpp:76-118).
+uint32_t oracle_multiply_generator(const uint32_t *C, uint32_t a) { return MultiplyGenerator(C, a); }
+float oracle_sample_generator_matrix(const uint32_t *C, uint32_t a, uint32_t scramble) { return SampleGeneratorMatrix(C, a, scramble); }
+void oracle_gray_code_sample(const uint32_t *C, uint32_t n, uint32_t scramble, float *out) { GrayCodeSample(C, n, scramble, out); }
+void oracle_zerotwo_matrices(uint32_t *vdc32, uint32_t *sobol32) { memcpy(vdc32, kZeroTwo.vdc, 128); memcpy(sobol32, kZeroTwo.sobol1, 128); }
+// One sample's first calls through the sampler interface: out = {Get2D (2), Get1D, Get2D (2), Get1D, Get2D (2), ...} n values
+// alternating one 2D and one 1D call -- the camera sample's order (sampler.cpp:46-52) continued.
+void oracle_sampler_calls(const mi_scene_desc *desc, int px, int py, int64_t sample_num, int n_pairs, float *out) {
+    Sampler s(*desc);
+    s.StartPixel(px, py);
+    s.StartSample(sample_num);
+    for (int i = 0; i < n_pairs; ++i) { s.Get2D(out + 3 * i); out[3 * i + 2] = s.Get1D(); }
 }
 // SobolSampleFloat(index, dim) itself (lowdiscrepancy.h:259-274), for the reference's LowDiscrepancy.Sobol test.
 float oracle_sobol_sample(const mi_scene_desc *desc, int64_t index, int dim) { return SobolSampleFloat(desc->sampler, index, dim); }

@@ -114,7 +114,8 @@ class Sampler(C.Structure):
                 ("perms", C.POINTER(C.c_uint16)), ("n_perms", C.c_uint32),
                 ("type", C.c_int32), ("sobol_resolution", C.c_int32), ("sobol_log2_resolution", C.c_int32),
                 ("n_sobol_dims", C.c_int32), ("sobol_matrices", C.POINTER(C.c_uint32)),
-                ("sobol_vdc", C.POINTER(C.c_uint64)), ("sobol_vdc_inv", C.POINTER(C.c_uint64))]
+                ("sobol_vdc", C.POINTER(C.c_uint64)), ("sobol_vdc_inv", C.POINTER(C.c_uint64)),
+                ("pixel_dims", C.c_int32), ("x_samples", C.c_int32), ("y_samples", C.c_int32), ("jitter", C.c_int32)]
 
 
 class Integrator(C.Structure):

@@ -108,6 +108,17 @@ DEV uint64_t RandomStreamInc(const DScene &s, int px, int py, long long sampleNu
     const long long pix = (long long)(py - s.sampleBounds[1]) * w + (px - s.sampleBounds[0]);
     return (((uint64_t)(sampleNum * (w * h) + pix)) << 1u) | 1u;
 }
+// ---- the pixel samplers (mi_sampler_type: ZEROTWO, STRATIFIED): PixelSampler::Get1D / Get2D, sampler.cpp:119-135
+DEV bool IsPixelSampler(const DScene &s) { return s.samplerType >= MI_SAMPLER_ZEROTWO; }
+DEV long long SamplePixelCount(const DScene &s) { return (long long)(s.sampleBounds[2] - s.sampleBounds[0]) * (s.sampleBounds[3] - s.sampleBounds[1]); }
+DEV long long SamplePixelIndex(const DScene &s, int px, int py) {
+    return (long long)(py - s.sampleBounds[1]) * (s.sampleBounds[2] - s.sampleBounds[0]) + (px - s.sampleBounds[0]);
+}
+// the stream of a sample's draws beyond the tables: (sample number + 1) * pixel count + pixel index (the pixel's own stream,
+// number = pixel index, makes the tables)
+DEV uint64_t PixelSampleStreamInc(const DScene &s, int px, int py, long long sampleNum) {
+    return (((uint64_t)((sampleNum + 1) * SamplePixelCount(s) + SamplePixelIndex(s, px, py))) << 1u) | 1u;
+}
 DEV uint64_t RandomStreamStart(uint64_t inc) {   // RNG::SetSequence, rng.h:98-105
     uint64_t state = 0u;
     PcgNext(state, inc);
@@ -200,6 +211,33 @@ struct PathSampler {
 // private memory and send every later field access through scratch -- measured: k_shade 2.3x slower.)
 // HALTON_ONLY: the shading instances of Halton-sampled scenes (every BASELINE workload) are compiled without the other two
 // samplers (TM_SAMPLERS, d_bsdf.h)
+// A pixel sampler's state in PathSampler: `index` = the state of the sample's fall-back stream, `dim` = the next 1D table
+// (bits 0-15) and the next 2D table (bits 16-31).
+DEV float PixelGet1D(const DScene &s, PathSampler &ps, int px, int py, long long sampleNum) {
+    const int d1 = ps.dim & 0xffff;
+    if (d1 < s.pixelDims) {
+        ps.dim += 1;
+        return s.pixTab1[((size_t)SamplePixelIndex(s, px, py) * s.pixelDims + d1) * (size_t)s.samplesPerPixel + (size_t)sampleNum];
+    }
+    uint64_t state = ps.index;
+    const float u = PcgFloat(state, PixelSampleStreamInc(s, px, py, sampleNum));
+    ps.index = state;
+    return u;
+}
+DEV void PixelGet2D(const DScene &s, PathSampler &ps, int px, int py, long long sampleNum, float *u0, float *u1) {
+    const int d2 = (ps.dim >> 16) & 0xffff;
+    if (d2 < s.pixelDims) {
+        ps.dim += 0x10000;
+        const float2 v = *reinterpret_cast<const float2 *>(s.pixTab2 + 2 * (((size_t)SamplePixelIndex(s, px, py) * s.pixelDims + d2) * (size_t)s.samplesPerPixel + (size_t)sampleNum));
+        *u0 = v.x; *u1 = v.y;
+        return;
+    }
+    uint64_t state = ps.index;
+    const uint64_t inc = PixelSampleStreamInc(s, px, py, sampleNum);
+    *u0 = PcgFloat(state, inc);
+    *u1 = PcgFloat(state, inc);
+    ps.index = state;
+}
 template <bool HALTON_ONLY = false>
 DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelPlane, const int *__restrict__ samplePlane, uint32_t slot) {
 #ifdef MIPT_EXP_FASTRNG
@@ -210,6 +248,10 @@ DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelP
     }
 #endif
     if constexpr (HALTON_ONLY) return ScrambledDimension(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim++);
+    if (IsPixelSampler(s)) {
+        const int pixelWord = pixelPlane[slot];
+        return PixelGet1D(s, ps, (int)(short)(pixelWord & 0xffff), pixelWord >> 16, (long long)samplePlane[slot]);
+    }
     if (s.samplerType == MI_SAMPLER_RANDOM) {
         const int pixelWord = pixelPlane[slot];
         const uint64_t inc = RandomStreamInc(s, (int)(short)(pixelWord & 0xffff), pixelWord >> 16, (long long)samplePlane[slot]);
@@ -220,6 +262,20 @@ DEV float Get1D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelP
         return u;
     }
     return SampleDimensionFrom2(s, ps.index, ps.dim++);
+}
+// Sampler::Get2D: two consecutive dimensions of the index-based samplers and of the random stream, the next 2D table of a
+// pixel sampler.
+template <bool HALTON_ONLY = false>
+DEV void Get2D(const DScene &s, PathSampler &ps, const int *__restrict__ pixelPlane, const int *__restrict__ samplePlane, uint32_t slot, float *u0, float *u1) {
+    if constexpr (!HALTON_ONLY) {
+        if (IsPixelSampler(s)) {
+            const int pixelWord = pixelPlane[slot];
+            PixelGet2D(s, ps, (int)(short)(pixelWord & 0xffff), pixelWord >> 16, (long long)samplePlane[slot], u0, u1);
+            return;
+        }
+    }
+    *u0 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
+    *u1 = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
 }
 // GetCameraSample (sampler.cpp:46-52) of sample `sampleNum` of pixel (px, py): pFilm offsets = dims 0, 1; time = dim 2;
 // pLens = dims 3, 4. Returns the sample's index (or, RANDOM, its stream state after the five draws).
@@ -248,8 +304,20 @@ static DEV_CALL SobolCamera CameraSampleSobol(const uint32_t *__restrict__ matri
     if (lens) { r.lu = SobolSampleFloat(matrices, index, 3); r.lv = SobolSampleFloat(matrices, index, 4); }
     return r;
 }
-DEV uint64_t CameraSampleDims(const DScene &s, int px, int py, long long sampleNum, float *u0, float *u1, float *lu, float *lv) {
+// *dimAfter: the path's sampler dimension after the camera sample (5; a pixel sampler's packed table counters).
+DEV uint64_t CameraSampleDims(const DScene &s, int px, int py, long long sampleNum, float *u0, float *u1, float *lu, float *lv, int *dimAfter = nullptr) {
     *lu = *lv = 0.f;
+    if (dimAfter) *dimAfter = 5;
+    if (IsPixelSampler(s)) {   // pFilm = Get2D(), time = Get1D(), pLens = Get2D()
+        PathSampler ps;
+        ps.index = RandomStreamStart(PixelSampleStreamInc(s, px, py, sampleNum));
+        ps.dim = 0;
+        PixelGet2D(s, ps, px, py, sampleNum, u0, u1);
+        (void)PixelGet1D(s, ps, px, py, sampleNum);
+        PixelGet2D(s, ps, px, py, sampleNum, lu, lv);
+        if (dimAfter) *dimAfter = ps.dim;
+        return ps.index;
+    }
     if (s.samplerType == MI_SAMPLER_RANDOM) {
         const uint64_t inc = RandomStreamInc(s, px, py, sampleNum);
         uint64_t state = RandomStreamStart(inc);

@@ -83,6 +83,10 @@ struct DScene {
     const uint32_t *sobolMatrices;         // [n_sobol_dims * 52]
     const uint64_t *sobolVdc, *sobolVdcInv;
     long long samplesPerPixel;             // (RANDOM: the stream number of a camera sample)
+    // pixel samplers (ZEROTWO / STRATIFIED): the tables of every pixel of the sample bounds, built at create (k_pixel_tables):
+    // pixTab1[(pixel * pixelDims + dimension) * spp + sample], pixTab2[((pixel * pixelDims + dimension) * spp + sample) * 2 + {0, 1}]
+    const float *pixTab1, *pixTab2;
+    int pixelDims, xSamples, ySamples, jitter;
     // integrator
     int maxDepth;
     float rrThreshold;

@@ -1568,7 +1568,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         if (got) {
             // GetCameraSample (sampler.cpp:46-52): pFilm = dims 0,1; time = dim 2; pLens = dims 3,4
             float u0, u1, lu, lv;
-            const uint64_t index = CameraSampleDims(s, px, py, sampleNum, &u0, &u1, &lu, &lv);
+            int dimAfter;
+            const uint64_t index = CameraSampleDims(s, px, py, sampleNum, &u0, &u1, &lu, &lv, &dimAfter);
             float pfx = (float)px + u0, pfy = (float)py + u1;
             Ray ray;
             CameraRay(s, pfx, pfy, lu, lv, &ray);
@@ -1579,11 +1580,11 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
 
             pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
             pool.I(I_SAMPLE, slot) = (int)sampleNum;
-            if (!(restart && s.samplerType == MI_SAMPLER_RANDOM)) {   // (a restarted band draws on from where its stream stands)
+            if (!(restart && s.samplerType >= MI_SAMPLER_RANDOM)) {   // (a restarted band draws on from where its stream stands)
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
                 pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
             }
-            if (!restart) pool.I(I_DIM, slot) = 5;
+            if (!restart) pool.I(I_DIM, slot) = dimAfter;
             if (nBands > 1) {
                 pool.I(I_BAND, slot) = restart ? band + 1 : 0;
                 if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1967,7 +1968,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                                         s.ldFuncInt[di], (int)s.nLights, u5[0], &selPdf);
                     if (selPdf != 0) {
                         if constexpr (FUSED_HALTON) ps.dim += 4;
-                        else { for (int k = 1; k < 5; ++k) u5[k] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); }
+                        else {   // uLight = Get2D(), uScattering = Get2D() (integrator.cpp:100-101)
+                            Get2D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot, &u5[1], &u5[2]);
+                            Get2D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot, &u5[3], &u5[4]);
+                        }
                         const float uL0 = u5[1], uL1 = u5[2], uS0 = u5[3], uS1 = u5[4];
         STAMP(5);
                         const mi_light &light = s.lights[lightNum];
@@ -2208,7 +2212,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 int sflags = 0;
                 float u2[2];
                 if constexpr (FUSED_HALTON) { ScrambledDimensionsFused<2>(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim, u2); ps.dim += 2; }
-                else { u2[0] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); u2[1] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot); }
+                else Get2D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot, &u2[0], &u2[1]);
                 const float u0 = u2[0], u1 = u2[1];
                 BSDFEvalT<NL> ev;
                 const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
@@ -2321,7 +2325,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             }
         STAMP(16);
             pool.I(I_DIM, slot) = ps.dim;
-            if (!HALTON_ONLY && s.samplerType == MI_SAMPLER_RANDOM) {   // the stream moves on with the path
+            if (!HALTON_ONLY && s.samplerType >= MI_SAMPLER_RANDOM) {   // the stream moves on with the path
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)ps.index;
                 pool.I(I_IDXHI, slot) = (int)(uint32_t)(ps.index >> 32);
             }
@@ -2407,6 +2411,77 @@ __global__ void k_build_spatial(DScene s, float *func, float *cdf, float *funcIn
     if (fi == 0) { for (int j = 1; j < nL + 1; ++j) c[j] = (float)j / (float)nL; }
     else { for (int j = 1; j < nL + 1; ++j) c[j] /= fi; }
     funcInt[vox] = fi;
+}
+
+// ------------------------------------------------------------------ pixel samplers' tables (create time)
+// ZeroTwoSequenceSampler::StartPixel (zerotwosequence.cpp:53-69) / StratifiedSampler::StartPixel (stratified.cpp:43-58) for every
+// pixel at once, one lane per pixel, each with the pixel's own PCG32 stream (mi_sampler_type): all 1D tables, then all 2D
+// tables, each scrambled / jittered and shuffled in the reference's order of RNG draws (VanDerCorput / Sobol2D,
+// lowdiscrepancy.h:149-227; StratifiedSample1D / 2D, sampling.cpp:42-60; Shuffle, sampling.h:150-157).
+DEV uint32_t PcgBounded(uint64_t &state, uint64_t inc, uint32_t b) {   // RNG::UniformUInt32(b), rng.h:112-121
+    const uint32_t threshold = (~b + 1u) % b;
+    while (true) {
+        const uint32_t r = PcgNext(state, inc);
+        if (r >= threshold) return r % b;
+    }
+}
+__global__ void k_pixel_tables(DScene s, float *tab1, float *tab2, unsigned long long nPix) {
+    const unsigned long long pix = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= nPix) return;
+    const int spp = (int)s.samplesPerPixel, dims = s.pixelDims;
+    const uint64_t inc = (((uint64_t)pix) << 1u) | 1u;
+    uint64_t state = RandomStreamStart(inc);
+    const bool zeroTwo = s.samplerType == MI_SAMPLER_ZEROTWO;
+    for (int d = 0; d < dims; ++d) {   // the 1D tables
+        float *v = tab1 + ((size_t)pix * dims + d) * (size_t)spp;
+        if (zeroTwo) {   // VanDerCorput(1, spp, ...): the generator matrix is the bit-reversed identity, C[k] = 2^(31 - k)
+            uint32_t x = PcgNext(state, inc);
+            for (int i = 0; i < spp; ++i) {
+                v[i] = minf((float)x * 0x1p-32f, kOneMinusEpsilon);
+                x ^= 0x80000000u >> __builtin_ctz((unsigned)(i + 1));
+            }
+            for (int i = 0; i < spp; ++i) (void)PcgBounded(state, inc, 1u);   // Shuffle of each sample's single value: one draw apiece
+        } else {
+            const float invN = 1.f / (float)spp;
+            for (int i = 0; i < spp; ++i) {
+                const float delta = s.jitter ? PcgFloat(state, inc) : 0.5f;
+                v[i] = minf(((float)i + delta) * invN, kOneMinusEpsilon);
+            }
+        }
+        for (int i = 0; i < spp; ++i) {   // Shuffle(v, spp, 1, rng)
+            const int other = i + (int)PcgBounded(state, inc, (uint32_t)(spp - i));
+            const float t = v[i]; v[i] = v[other]; v[other] = t;
+        }
+    }
+    for (int d = 0; d < dims; ++d) {   // the 2D tables
+        float2 *v = reinterpret_cast<float2 *>(tab2) + ((size_t)pix * dims + d) * (size_t)spp;
+        if (zeroTwo) {   // Sobol2D(1, spp, ...): second matrix = Pascal's triangle mod 2, column k = column k-1 ^ (column k-1 >> 1)
+            uint32_t x0 = PcgNext(state, inc), x1 = PcgNext(state, inc);
+            uint32_t col[32];
+            col[0] = 0x80000000u;
+            for (int k = 1; k < 32; ++k) col[k] = col[k - 1] ^ (col[k - 1] >> 1);
+            for (int i = 0; i < spp; ++i) {
+                v[i] = make_float2(minf((float)x0 * 0x1p-32f, kOneMinusEpsilon), minf((float)x1 * 0x1p-32f, kOneMinusEpsilon));
+                const int k = __builtin_ctz((unsigned)(i + 1));
+                x0 ^= 0x80000000u >> k;
+                x1 ^= col[k];
+            }
+            for (int i = 0; i < spp; ++i) (void)PcgBounded(state, inc, 1u);
+        } else {
+            const float dx = 1.f / (float)s.xSamples, dy = 1.f / (float)s.ySamples;
+            int i = 0;
+            for (int y = 0; y < s.ySamples; ++y)
+                for (int x = 0; x < s.xSamples; ++x, ++i) {
+                    const float jx = s.jitter ? PcgFloat(state, inc) : 0.5f;
+                    const float jy = s.jitter ? PcgFloat(state, inc) : 0.5f;
+                    v[i] = make_float2(minf(((float)x + jx) * dx, kOneMinusEpsilon), minf(((float)y + jy) * dy, kOneMinusEpsilon));
+                }
+        }
+        for (int i = 0; i < spp; ++i) {
+            const int other = i + (int)PcgBounded(state, inc, (uint32_t)(spp - i));
+            const float2 t = v[i]; v[i] = v[other]; v[other] = t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ texture lookups on their own (mi_pt_texture_lookup)
@@ -2711,7 +2786,17 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (l.type == MI_LIGHT_DIFFUSE_AREA && (l.shape >= 0 ? (uint32_t)l.shape >= d->n_tris : (uint32_t)(~l.shape) >= d->n_spheres)) { g_err = "area light shape index out of range"; return MI_ERR_INVALID; }
     }
     if (d->integrator.n_ca_bands < 1 || d->integrator.n_ca_bands > MI_NSPEC) { g_err = "n_ca_bands must be in [1, 31]"; return MI_ERR_INVALID; }
-    if (d->sampler.type != MI_SAMPLER_HALTON && d->sampler.type != MI_SAMPLER_SOBOL && d->sampler.type != MI_SAMPLER_RANDOM) { g_err = "unknown mi_sampler.type"; return MI_ERR_INVALID; }
+    if (d->sampler.type < MI_SAMPLER_HALTON || d->sampler.type > MI_SAMPLER_STRATIFIED) { g_err = "unknown mi_sampler.type"; return MI_ERR_INVALID; }
+    if (d->sampler.samples_per_pixel < 1) { g_err = "mi_sampler.samples_per_pixel must be positive"; return MI_ERR_INVALID; }
+    if (d->sampler.type >= MI_SAMPLER_ZEROTWO) {
+        const mi_sampler &sm = d->sampler;
+        if (sm.pixel_dims < 0 || sm.pixel_dims > 64) { g_err = "mi_sampler.pixel_dims must be in [0, 64]"; return MI_ERR_INVALID; }
+        if (sm.samples_per_pixel > (1 << 20)) { g_err = "pixel samplers tabulate every sample of a pixel: at most 2^20 samples per pixel"; return MI_ERR_UNSUPPORTED; }
+        if (sm.type == MI_SAMPLER_STRATIFIED && (sm.x_samples < 1 || sm.y_samples < 1 || (int64_t)sm.x_samples * sm.y_samples != sm.samples_per_pixel)) {
+            g_err = "stratified sampler: samples_per_pixel must be x_samples * y_samples"; return MI_ERR_INVALID;
+        }
+        if (sm.type == MI_SAMPLER_ZEROTWO && (sm.samples_per_pixel & (sm.samples_per_pixel - 1)) != 0) { g_err = "02sequence sampler: samples_per_pixel must be a power of two"; return MI_ERR_INVALID; }
+    }
     if (d->sampler.type == MI_SAMPLER_SOBOL) {
         if (!d->sampler.sobol_matrices || !d->sampler.sobol_vdc || !d->sampler.sobol_vdc_inv || d->sampler.sobol_log2_resolution < 0 ||
             d->sampler.sobol_log2_resolution > 25 || d->sampler.sobol_resolution != (1 << d->sampler.sobol_log2_resolution)) { g_err = "malformed Sobol' sampler tables"; return MI_ERR_INVALID; }
@@ -3211,6 +3296,8 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     s.sampleAtPixelCenter = d->sampler.sample_at_pixel_center;
     s.samplerType = d->sampler.type;
     s.samplesPerPixel = d->sampler.samples_per_pixel;
+    s.pixTab1 = s.pixTab2 = nullptr;
+    s.pixelDims = d->sampler.pixel_dims; s.xSamples = d->sampler.x_samples; s.ySamples = d->sampler.y_samples; s.jitter = d->sampler.jitter;
     s.sobolResolution = d->sampler.sobol_resolution;
     s.sobolLog2Resolution = d->sampler.sobol_log2_resolution;
     s.maxDepth = d->integrator.max_depth;
@@ -3219,6 +3306,25 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     s.bandDelta = (int)std::round((float)MI_NSPEC / (float)s.nBands);  // spectralpath.cpp:258
     pt->spp = d->sampler.samples_per_pixel;
     if (d->n_nodes) for (int i = 0; i < 3; ++i) { s.wbMin[i] = d->nodes[0].bmin[i]; s.wbMax[i] = d->nodes[0].bmax[i]; }
+    if (d->sampler.type >= MI_SAMPLER_ZEROTWO && d->sampler.pixel_dims > 0) {
+        // the pixel samplers' tables: every sampled dimension of every sample of every pixel of the sample bounds (StartPixel of
+        // the reference, done once for all pixels), 12 bytes per (pixel, dimension, sample)
+        const size_t nPix = (size_t)(s.sampleBounds[2] - s.sampleBounds[0]) * (size_t)(s.sampleBounds[3] - s.sampleBounds[1]);
+        const size_t nVal = nPix * (size_t)s.pixelDims * (size_t)s.samplesPerPixel;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); freeB = ~(size_t)0; }
+        if (nVal * 12 > freeB / 2) { g_err = "the pixel sampler's tables (" + std::to_string(nVal * 12 >> 20) + " MiB) exceed half the free device memory"; mi_pt_destroy(pt); return MI_ERR_NOMEM; }
+        float *t1 = nullptr, *t2 = nullptr;
+        if (hipMalloc((void **)&t1, nVal * 4 + 16) != hipSuccess || hipMalloc((void **)&t2, nVal * 8 + 16) != hipSuccess) {
+            (void)hipGetLastError();
+            if (t1) hipFree(t1);
+            g_err = "hipMalloc(pixel sampler tables) failed"; mi_pt_destroy(pt); return MI_ERR_NOMEM;
+        }
+        pt->allocs.push_back(t1); pt->allocs.push_back(t2);
+        s.pixTab1 = t1; s.pixTab2 = t2;
+        hipLaunchKernelGGL(k_pixel_tables, dim3((unsigned)((nPix + 127) / 128)), dim3(128), 0, 0, s, t1, t2, (unsigned long long)nPix);
+        if (hipDeviceSynchronize() != hipSuccess) { g_err = "k_pixel_tables failed"; mi_pt_destroy(pt); return MI_ERR_HIP; }
+    }
     // light-selection distributions
     s.ldType = d->light_distrib.type;
     for (int i = 0; i < 3; ++i) s.nVoxels[i] = d->light_distrib.n_voxels[i];
@@ -3533,6 +3639,11 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
 int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *weight_sum, mi_counters *counters) {
     if (!pt || !rp) { g_err = "null argument"; return MI_ERR_INVALID; }
     if (rp->shard_count < 1 || rp->shard_index < 0 || rp->shard_index >= rp->shard_count) { g_err = "bad shard"; return MI_ERR_INVALID; }
+    if (pt->scene.samplerType >= MI_SAMPLER_ZEROTWO &&
+        (rp->sample_begin < 0 || rp->sample_begin + (rp->spp_override > 0 ? rp->spp_override : pt->spp) > pt->spp)) {
+        g_err = "a pixel sampler (02sequence / stratified) has tables for samples_per_pixel samples: the pass asks for sample numbers beyond them";
+        return MI_ERR_INVALID;
+    }
     HIPCHK(hipSetDevice(pt->device));
     hipStream_t st = (hipStream_t)rp->stream;
     if (!(rp->flags & MI_RENDER_ACCUMULATE)) HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));

@@ -837,10 +837,11 @@ void Api::WorldEnd() {
         s.type = MI_SAMPLER_HALTON;
         if (samplerName == "sobol") s.type = MI_SAMPLER_SOBOL;          // CreateSobolSampler, sobol.cpp:66-71
         else if (samplerName == "random") s.type = MI_SAMPLER_RANDOM;   // CreateRandomSampler, random.cpp:62-65
+        else if (samplerName == "02sequence" || samplerName == "lowdiscrepancy") s.type = MI_SAMPLER_ZEROTWO;   // api.cpp:859-860
+        else if (samplerName == "stratified") s.type = MI_SAMPLER_STRATIFIED;
         else if (samplerName != "halton")
-            Err("Sampler \"" + samplerName + "\" is not built on this path (\"stratified\" and \"02sequence\" carry one RNG through the "
-                "pixels of a tile, SURVEY 8f item 3); using halton.");
-        int nsamp = samplerParams.FindOneInt("pixelsamples", s.type == MI_SAMPLER_HALTON ? 16 : (s.type == MI_SAMPLER_SOBOL ? 16 : 4));
+            Err("Sampler \"" + samplerName + "\" is not built on this path (SURVEY 2: \"maxmindist\" is outside the hot-path scope); using halton.");
+        int nsamp = samplerParams.FindOneInt("pixelsamples", s.type == MI_SAMPLER_RANDOM ? 4 : 16);
         if (ov.spp > 0) nsamp = ov.spp;
         if (s.type == MI_SAMPLER_SOBOL) {   // GlobalSampler(RoundUpPow2(samplesPerPixel)), sobol.h:52-57
             int p2 = 1;
@@ -848,6 +849,28 @@ void Api::WorldEnd() {
             if (p2 != nsamp) Warn("Non power-of-two sample count rounded up to " + std::to_string(p2) + " for SobolSampler.");
             nsamp = p2;
         }
+        s.pixel_dims = 0; s.x_samples = s.y_samples = 0; s.jitter = 1;
+        if (s.type == MI_SAMPLER_ZEROTWO) {   // ZeroTwoSequenceSampler ctor + CreateZeroTwoSequenceSampler, zerotwosequence.cpp:43-51,77-82
+            int p2 = 1;
+            while (p2 < nsamp) p2 *= 2;
+            if (p2 != nsamp) Warn("Pixel samples being rounded up to power of 2 (from " + std::to_string(nsamp) + " to " + std::to_string(p2) + ").");
+            nsamp = p2;
+            s.pixel_dims = samplerParams.FindOneInt("dimensions", 4);
+        }
+        if (s.type == MI_SAMPLER_STRATIFIED) {   // CreateStratifiedSampler, stratified.cpp:79-86
+            s.jitter = samplerParams.FindOneBool("jitter", true) ? 1 : 0;
+            s.x_samples = samplerParams.FindOneInt("xsamples", 4);
+            s.y_samples = samplerParams.FindOneInt("ysamples", 4);
+            if (ov.spp > 0) {   // a sample-count override keeps the pixel's grid square-ish: the largest divisor of spp below its root
+                int xs = 1;
+                for (int k = 1; (long long)k * k <= ov.spp; ++k) if (ov.spp % k == 0) xs = k;
+                s.x_samples = ov.spp / xs; s.y_samples = xs;
+            }
+            if (s.x_samples < 1 || s.y_samples < 1) { Err("Sampler \"stratified\": xsamples and ysamples must be positive; using 1."); s.x_samples = std::max(1, s.x_samples); s.y_samples = std::max(1, s.y_samples); }
+            nsamp = s.x_samples * s.y_samples;
+            s.pixel_dims = samplerParams.FindOneInt("dimensions", 4);
+        }
+        if (s.pixel_dims < 0 || s.pixel_dims > 64) { Err("Sampler \"" + samplerName + "\": dimensions must be in [0, 64]; using 4."); s.pixel_dims = 4; }
         s.samples_per_pixel = nsamp;
         s.sample_at_pixel_center = samplerParams.FindOneBool("samplepixelcenter", false) ? 1 : 0;
         int res[2] = {d.film.sample_bounds[2] - d.film.sample_bounds[0], d.film.sample_bounds[3] - d.film.sample_bounds[1]};

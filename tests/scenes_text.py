@@ -696,7 +696,19 @@ def random_scene(seed, res=32, spp=8):
     filt = rng.choice(["box", "triangle", "gaussian", "mitchell"])
     out.append('PixelFilter "%s"' % filt)
     out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (res, res))
-    out.append('Sampler "%s" "integer pixelsamples" [%d]' % (rng.choice(["halton", "halton", "sobol", "random"]), spp))
+    sampler = rng.choice(["halton", "halton", "sobol", "random"])
+    rng2 = np.random.default_rng(seed + 7_000_003)   # (a generator of its own: the scenes of earlier rounds keep their other draws)
+    if rng2.random() < .3:
+        sampler = rng2.choice(["02sequence", "stratified"])
+    if sampler == "stratified":
+        xs = max(1, int(round(spp ** .5)))
+        while spp % xs: xs -= 1
+        out.append('Sampler "stratified" "integer xsamples" [%d] "integer ysamples" [%d] "bool jitter" ["%s"] "integer dimensions" [%d]'
+                   % (spp // xs, xs, "true" if rng2.random() < .8 else "false", int(rng2.integers(1, 6))))
+    elif sampler == "02sequence":
+        out.append('Sampler "02sequence" "integer pixelsamples" [%d] "integer dimensions" [%d]' % (spp, int(rng2.integers(1, 6))))
+    else:
+        out.append('Sampler "%s" "integer pixelsamples" [%d]' % (sampler, spp))
     integ = "spectralpath" if rng.random() < .25 else "path"
     extra = ' "integer numCABands" [%d]' % int(rng.integers(2, 5)) if integ == "spectralpath" else ""
     out.append('Integrator "%s" "integer maxdepth" [%d] "string lightsamplestrategy" "%s"%s'

@@ -113,7 +113,7 @@ def test_directives_transforms_named_materials_textures(pt):
 def test_out_of_scope_features_are_reported_not_ignored(pt):
     txt = """
     Camera "orthographic"
-    Sampler "stratified"
+    Sampler "maxmindist"
     Integrator "bdpt"
     WorldBegin
     Material "hair"
@@ -124,7 +124,7 @@ def test_out_of_scope_features_are_reported_not_ignored(pt):
     """
     s = pt.Scene(text=txt)
     errs = "\n".join(s.errors)
-    for word in ("orthographic", "stratified", "bdpt", "hair", "cylinder", "goniometric"):
+    for word in ("orthographic", "maxmindist", "bdpt", "hair", "cylinder", "goniometric"):
         assert word in errs, word
     assert s.stats["n_triangles"] == 1
 

@@ -363,7 +363,8 @@ def test_procedural_many_mesh_scene_against_oracle(pt, ob, tmp_path):
     _parity(pt, ob, s, "procedural 200k triangles 96x96 16spp", exact=False, rel_tol=1e-3, counter_tol=5e-4)
 
 
-@pytest.mark.parametrize("sampler,lens", [("sobol", False), ("sobol", True), ("random", False), ("random", True)])
+@pytest.mark.parametrize("sampler,lens", [("sobol", False), ("sobol", True), ("random", False), ("random", True),
+                                          ("02sequence", False), ("02sequence", True), ("stratified", False), ("stratified", True)])
 def test_sobol_and_random_samplers_against_oracle(pt, ob, sampler, lens):
     """Sampler "sobol" (sobol.cpp, lowdiscrepancy.h:229-274: the sample of (pixel, n) is a pure function of its index, as
     with Halton) and Sampler "random" (one PCG32 stream per camera sample, include/mi_pt.h mi_sampler_type) on the material
@@ -371,9 +372,37 @@ def test_sobol_and_random_samplers_against_oracle(pt, ob, sampler, lens):
     txt = st.material_zoo(res=64, spp=16, depth=6).replace('Sampler "halton"', 'Sampler "%s"' % sampler)
     if lens:
         txt = txt.replace('Camera "perspective" "float fov" [40]', 'Camera "perspective" "float fov" [40] "float lensradius" [.15] "float focaldistance" [8]')
+    if sampler == "stratified":   # (the pixel samplers: tables per pixel from the pixel's own stream, include/mi_pt.h mi_sampler_type)
+        txt = txt.replace('"integer pixelsamples" [16]', '"integer xsamples" [8] "integer ysamples" [2] "integer dimensions" [3]')
     s = pt.Scene(text=txt)
-    assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2}[sampler]
+    assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2, "02sequence": 3, "stratified": 4}[sampler] and s.spp == 16
     _parity(pt, ob, s, "zoo sampler %s lens=%s" % (sampler, lens))
+
+
+def test_furnace_scenes_under_all_five_samplers_on_the_device(pt, ob):
+    """The perspective half of tests/analytic_scenes.cpp:250-267 on the HIP path: the three furnace scenes under halton, sobol,
+    random, 02sequence and stratified -- radiance 1 +- 0.02 (the reference's own pass mark), and equal to the oracle."""
+    for sampler in ("halton", "sobol", "random", "02sequence", "stratified"):
+        for text in (st.furnace_point(), st.furnace_area(), st.furnace_uber()):
+            text = text.replace('Sampler "halton"', 'Sampler "%s"' % sampler)
+            if sampler == "stratified":
+                text = text.replace('"integer pixelsamples" [256]', '"integer xsamples" [16] "integer ysamples" [16]')
+            s = pt.Scene(text=text)
+            assert s.errors == [] and s.spp == 256
+            film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "furnace %s" % sampler)
+            assert abs(float((film / weight[..., None]).mean()) - 1.0) < 0.02, sampler
+
+
+def test_pixel_sampler_passes_stay_inside_the_tables(pt):
+    """A pixel sampler has tables for samples_per_pixel samples of every pixel: a pass beyond them is an error code."""
+    s = pt.Scene(text=st.furnace_point(res=8, spp=16).replace('Sampler "halton"', 'Sampler "02sequence"'))
+    integ = pt.CreatePathIntegrator(s)
+    a, wa = integ.Render(spp=8, sample_begin=0)
+    b, wb = integ.Render(spp=8, sample_begin=8, accumulate=True)
+    full, wf = integ.Render()
+    assert np.array_equal(wb, wf) and _rel_l2(b, full) < 1e-6   # two passes = the frame
+    with pytest.raises(RuntimeError, match="beyond them"):
+        integ.Render(spp=16, sample_begin=8)
 
 
 def test_sobol_sampler_on_the_killeroo_frame(pt, ob):

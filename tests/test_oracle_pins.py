@@ -446,17 +446,140 @@ def test_sobol_rounds_the_sample_count_up_to_a_power_of_two(pt):
     assert s.spp == 16 and any("rounded up to 16" in w for w in s.warnings)
 
 
-@pytest.mark.parametrize("sampler", ["sobol", "random"])
+@pytest.mark.parametrize("sampler", ["sobol", "random", "02sequence", "stratified"])
 def test_furnace_scenes_with_the_other_samplers(pt, ob, sampler):
     """tests/analytic_scenes.cpp:250-267 runs every furnace scene under every sampler: radiance 1 +- 0.02."""
     for text in (st.furnace_point(), st.furnace_area(), st.furnace_uber()):
         text = text.replace('Sampler "halton"', 'Sampler "%s"' % sampler)
+        if sampler == "stratified":
+            text = text.replace('"integer pixelsamples" [256]', '"integer xsamples" [16] "integer ysamples" [16]')
         s = pt.Scene(text=text)
-        assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2}[sampler]
+        assert s.errors == [] and s.desc.sampler.type == {"sobol": 1, "random": 2, "02sequence": 3, "stratified": 4}[sampler] and s.spp == 256
         film, weight, c, _ = ob.render(s, n_threads=4)
         assert abs(float((film / weight[..., None]).mean()) - 1.0) < 0.02, sampler
 
 
-def test_other_pixel_samplers_are_reported(pt):
-    s = _sampler_scene(pt, "stratified", 8, 4)
-    assert any("stratified" in e for e in s.errors) and s.desc.sampler.type == 0
+def test_samplers_outside_the_scope_are_reported(pt):
+    s = _sampler_scene(pt, "maxmindist", 8, 4)
+    assert any("maxmindist" in e for e in s.errors) and s.desc.sampler.type == 0
+
+
+# ------------------------------------------------------------------ Sampler "02sequence" / "stratified" (SURVEY 8f item 3)
+def _u32(a):
+    return np.ascontiguousarray(a, np.uint32).ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _rev32(x):
+    return int("{:032b}".format(int(x))[::-1], 2)
+
+
+def test_generator_matrix_products(pt, ob):
+    """tests/sampling.cpp:76-104 (LowDiscrepancy.GeneratorMatrix): the identity matrix gives a back, its bit reversal the
+    base-2 radical inverse; for a random matrix, reversing the product's bits equals the product with the reversed columns."""
+    lib = ob.lib()
+    lib.oracle_multiply_generator.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    lib.oracle_multiply_generator.restype = C.c_uint32
+    lib.oracle_sample_generator_matrix.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    lib.oracle_sample_generator_matrix.restype = C.c_float
+    s = _sampler_scene(pt, "halton", 8, 1)
+    Cm = np.array([1 << i for i in range(32)], np.uint32)
+    Crev = np.array([_rev32(c) for c in Cm], np.uint32)
+    for a in range(128):
+        assert lib.oracle_multiply_generator(_u32(Cm), a) == a
+        ri = lib.oracle_radical_inverse(s.desc_ptr, 0, a)
+        assert ri == np.float32(_rev32(a)) * np.float32(2.3283064365386963e-10)
+        assert ri == lib.oracle_sample_generator_matrix(_u32(Crev), a, 0)
+    rng = np.random.default_rng(3)
+    Cm = rng.integers(0, 1 << 32, 32, dtype=np.uint64).astype(np.uint32)
+    Crev = np.array([_rev32(c) for c in Cm], np.uint32)
+    for a in range(1024):
+        assert _rev32(lib.oracle_multiply_generator(_u32(Cm), a)) == lib.oracle_multiply_generator(_u32(Crev), a)
+
+
+def test_gray_code_sample_enumerates_the_generated_points(pt, ob):
+    """tests/sampling.cpp:106-118 (LowDiscrepancy.GrayCodeSample): the Gray-code walk visits exactly the points the plain
+    matrix product generates."""
+    lib = ob.lib()
+    lib.oracle_multiply_generator.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    lib.oracle_multiply_generator.restype = C.c_uint32
+    lib.oracle_gray_code_sample.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+    Cm = np.array([1 << i for i in range(32)], np.uint32)
+    v = np.zeros(64, np.float32)
+    lib.oracle_gray_code_sample(_u32(Cm), 64, 0, v.ctypes.data_as(C.POINTER(C.c_float)))
+    for a in range(64):
+        u = np.float32(lib.oracle_multiply_generator(_u32(Cm), a)) * np.float32(2.3283064365386963e-10)
+        assert u in v
+
+
+def test_zero_two_generator_matrices(ob):
+    """The two generator matrices of the (0,2)-sequence as the oracle builds them: van der Corput's is the bit-reversed
+    identity, the second is Pascal's triangle mod 2 (lowdiscrepancy.h:155-224: column c has bit 31 - r set iff C(c, r) is odd)."""
+    import math
+    lib = ob.lib()
+    vdc, sob = np.zeros(32, np.uint32), np.zeros(32, np.uint32)
+    lib.oracle_zerotwo_matrices.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.oracle_zerotwo_matrices(_u32(vdc), _u32(sob))
+    assert [int(v) for v in vdc] == [0x80000000 >> i for i in range(32)]
+    assert [int(v) for v in sob] == [sum((math.comb(c, r) & 1) << (31 - r) for r in range(32)) for c in range(32)]
+    assert [int(v) for v in sob[:8]] == [0x80000000, 0xc0000000, 0xa0000000, 0xf0000000, 0x88000000, 0xcc000000, 0xaa000000, 0xff000000]
+
+
+def _sampler_calls(ob, s, px, py, n_samples, n_pairs=1):
+    lib = ob.lib()
+    lib.oracle_sampler_calls.argtypes = [C.POINTER(type(s.desc)), C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]
+    out = np.zeros((n_samples, n_pairs, 3), np.float32)
+    for k in range(n_samples):
+        lib.oracle_sampler_calls(s.desc_ptr, px, py, k, n_pairs, out[k].ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+@pytest.mark.parametrize("log_samples", [2, 4, 7, 10])
+def test_zero_two_pixel_samples_fill_the_elementary_intervals(pt, ob, log_samples):
+    """tests/sampling.cpp:139-186 (LowDiscrepancy.ElementaryIntervals, the ZeroTwoSequenceSampler(2^k, 2) case): the first
+    Get2D of the 2^k samples of a pixel puts exactly one point into every elementary interval 2^-i x 2^-(k-i) -- under the
+    random scramble and shuffle of the pixel's tables -- and so does the second 2D dimension; the 1D tables are stratified."""
+    n = 1 << log_samples
+    s = _sampler_scene(pt, "02sequence", 10, n, '"integer dimensions" [2]')
+    assert s.errors == [] and s.desc.sampler.type == 3 and s.desc.sampler.pixel_dims == 2 and s.spp == n
+    for px, py in ((0, 0), (7, 3)):
+        calls = _sampler_calls(ob, s, px, py, n, n_pairs=3)
+        for dim in (0, 1):
+            pts = calls[:, dim, :2].astype(np.float64)
+            assert (pts >= 0).all() and (pts < 1).all()
+            for i in range(log_samples + 1):
+                nx, ny = 1 << i, 1 << (log_samples - i)
+                idx = np.floor(pts[:, 1] * ny).astype(int) * nx + np.floor(pts[:, 0] * nx).astype(int)
+                assert len(np.unique(idx)) == n, (px, py, dim, i)
+            assert len(np.unique(np.floor(calls[:, dim, 2].astype(np.float64) * n).astype(int))) == n   # van der Corput: one per 1/n
+        # the third pair lies beyond the two tabulated dimensions: plain random numbers of the sample's own stream
+        assert len(np.unique(calls[:, 2, 0])) > 0.9 * n
+    a, b = _sampler_calls(ob, s, 0, 0, n), _sampler_calls(ob, s, 1, 0, n)
+    assert not np.array_equal(a, b)   # (another pixel, another scramble)
+
+
+def test_zero_two_rounds_the_sample_count_up_to_a_power_of_two(pt):
+    s = _sampler_scene(pt, "lowdiscrepancy", 8, 12)
+    assert s.spp == 16 and s.desc.sampler.type == 3 and any("rounded up to power of 2 (from 12 to 16)" in w for w in s.warnings)
+
+
+@pytest.mark.parametrize("jitter", [True, False])
+def test_stratified_pixel_samples_hit_every_stratum_once(pt, ob, jitter):
+    """StratifiedSampler::StartPixel (stratified.cpp:43-58): per pixel and sampled dimension, one 1D value in each of the
+    x * y strata and one 2D value in each cell of the x by y grid, in shuffled order; without jitter they sit at the
+    strata's centres."""
+    nx, ny = 5, 3
+    txt = st._HEAD % dict(res=6, spp=1, depth=1, extra="") + 'Shape "sphere"\nWorldEnd\n'
+    txt = txt.replace('Sampler "halton" "integer pixelsamples" [1]',
+                      'Sampler "stratified" "integer xsamples" [%d] "integer ysamples" [%d] "bool jitter" ["%s"] "integer dimensions" [3]'
+                      % (nx, ny, "true" if jitter else "false"))
+    s = pt.Scene(text=txt)
+    assert s.errors == [] and s.desc.sampler.type == 4 and s.spp == nx * ny and s.desc.sampler.jitter == int(jitter)
+    calls = _sampler_calls(ob, s, 2, 4, nx * ny, n_pairs=3)
+    for dim in range(3):
+        p2, p1 = calls[:, dim, :2].astype(np.float64), calls[:, dim, 2].astype(np.float64)
+        cells = np.floor(p2[:, 1] * ny).astype(int) * nx + np.floor(p2[:, 0] * nx).astype(int)
+        assert sorted(cells) == list(range(nx * ny))
+        assert sorted(np.floor(p1 * nx * ny).astype(int)) == list(range(nx * ny))
+        if not jitter:
+            assert np.allclose((p2[:, 0] * nx) % 1, .5, atol=1e-5) and np.allclose((p1 * nx * ny) % 1, .5, atol=1e-5)
+    assert not np.array_equal(cells, np.arange(nx * ny))   # (shuffled)
