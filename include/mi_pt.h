@@ -433,6 +433,16 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  * I_HITPRIM as the traversal kernel left it, before the quadric step (int32 bits)}. Host pointers; n <= 2^24. */
 int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra);
 
+/* Parity tool for the scalar helpers under the shape and sampling code, each run on the device for n inputs (x, y: 2 floats per
+ * element; out: 3 floats per element) -- the reference's own tests of them are restated over this entry point and the oracle's:
+ *   op 0: NextFloatUp(x0), NextFloatDown(x0)                     pbrt.h:244-268  (OffsetRayOrigin; tests/fp_tests.cpp:29-47)
+ *   op 1..4: EFloat(x0, err x1) {+, -, *, /} EFloat(y0, err y1)  efloat.h:48-200 (Sphere::Intersect; tests/fp_tests.cpp:166-260)
+ *            -> value, lower bound, upper bound
+ *   op 5: FindInterval over the array 0, 1, ..., 9 with the predicate a[i] <= x0, as Distribution1D::SampleDiscrete runs it
+ *         (pbrt.h:405-418, sampling.h:91-98; tests/find_interval.cpp:8) -> the interval
+ * Host pointers; needs no scene. */
+int mi_pt_math_probe(int device_ordinal, int op, uint32_t n, const float *x, const float *y, float *out);
+
 /* Parity tool for image textures: MIPMap<RGBSpectrum>::Lookup(st, dstdx, dstdy) (src/core/mipmap.h:281-319) of texture
  * `tex` for n queries on the device. queries: 6 floats each (s, t, dsdx, dtdx, dsdy, dtdy) in texture space, i.e. after
  * the UVMapping2D; rgb: 3 floats per query. */

@@ -1277,6 +1277,30 @@ float oracle_sample_dimension(const mi_scene_desc *desc, int px, int py, int64_t
     s.StartSample(sample_num);
     return s.SampleDimension(s.intervalSampleIndex, dim);
 }
+// Scalar helpers on their own, for the reference's FloatingPoint.NextUpDownFloat, EFloat.{Add,Sub,Mul,Div} and
+// FindInterval.Basics tests (tests/fp_tests.cpp:29-47,166-260, tests/find_interval.cpp:8) -- the same operations and layout as
+// the device's mi_pt_math_probe. x, y: 2 floats per element, out: 3 floats per element.
+//   op 0: NextFloatUp(x0), NextFloatDown(x0)      op 1..4: EFloat(x0, x1) {+, -, *, /} EFloat(y0, y1) -> v, LowerBound, UpperBound
+//   op 5: FindInterval(10, [&](int i) { return i <= x0; }) over the array 0, 1, ..., 9, as Distribution1D::SampleDiscrete runs it
+void oracle_math_probe(int op, uint32_t n, const float *x, const float *y, float *out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1], y0 = y ? y[2 * i] : 0.f, y1 = y ? y[2 * i + 1] : 0.f;
+        float *o = out + 3 * i;
+        o[0] = o[1] = o[2] = 0.f;
+        if (op == 0) { o[0] = NextFloatUp(x0); o[1] = NextFloatDown(x0); }
+        else if (op >= 1 && op <= 4) {
+            const EFloat a(x0, x1), b(y0, y1);
+            const EFloat r = op == 1 ? a + b : (op == 2 ? a - b : (op == 3 ? a * b : a / b));
+            o[0] = r.v; o[1] = r.low; o[2] = r.high;
+        } else if (op == 5) {
+            const float cdf[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, func[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+            Distribution1D dist(func, 9);
+            dist.cdf.assign(cdf, cdf + 10);   // (the reference test's array in place of a cdf: FindInterval sees the same values)
+            float pdf;
+            o[0] = (float)dist.SampleDiscrete(x0, &pdf);
+        }
+    }
+}
 // The pieces the reference's LowDiscrepancy.GeneratorMatrix / GrayCodeSample tests exercise (tests/sampling.cpp:76-118).
 uint32_t oracle_multiply_generator(const uint32_t *C, uint32_t a) { return MultiplyGenerator(C, a); }
 float oracle_sample_generator_matrix(const uint32_t *C, uint32_t a, uint32_t scramble) { return SampleGeneratorMatrix(C, a, scramble); }

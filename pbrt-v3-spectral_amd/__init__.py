@@ -223,6 +223,7 @@ def hip_lib():
         lib.mi_pt_destroy.argtypes = [C.c_void_p]
         lib.mi_pt_last_error.restype = C.c_char_p
         lib.mi_pt_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+        lib.mi_pt_math_probe.argtypes = [C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_trace_wavefront.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_texture_lookup.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.mi_pt_light_distribution.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
@@ -428,6 +429,17 @@ class PathIntegrator:
         if rc != 0:
             raise RuntimeError("mi_pt_texture_lookup failed: %s" % hip_lib().mi_pt_last_error().decode())
         return out
+
+
+def math_probe(op, x, y=None, device=0):
+    """mi_pt_math_probe: the device's scalar helpers on arrays. x, y: [n, 2] float32; returns [n, 3]."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(x if y is None else y, np.float32)
+    out = np.zeros((x.shape[0], 3), np.float32)
+    rc = hip_lib().mi_pt_math_probe(device, int(op), x.shape[0], _fptr(x), _fptr(y), _fptr(out))
+    if rc != 0:
+        raise RuntimeError("mi_pt_math_probe failed: %s" % hip_lib().mi_pt_last_error().decode())
+    return out
 
 
 def CreatePathIntegrator(scene, device=0):

@@ -2493,6 +2493,25 @@ __global__ void k_texture_lookup(DScene s, int tex, const float *q, uint32_t n, 
     out[3 * i] = v.r; out[3 * i + 1] = v.g; out[3 * i + 2] = v.b;
 }
 
+// ------------------------------------------------------------------ scalar helpers on their own (mi_pt_math_probe)
+__global__ void k_math_probe(int op, uint32_t n, const float *x, const float *y, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = x[2 * i], x1 = x[2 * i + 1], y0 = y[2 * i], y1 = y[2 * i + 1];
+    float *o = out + 3 * (size_t)i;
+    o[0] = o[1] = o[2] = 0.f;
+    if (op == 0) { o[0] = NextFloatUp(x0); o[1] = NextFloatDown(x0); }
+    else if (op >= 1 && op <= 4) {
+        const EFloat a(x0, x1), b(y0, y1);
+        const EFloat r = op == 1 ? a + b : (op == 2 ? a - b : (op == 3 ? a * b : a / b));
+        o[0] = r.v; o[1] = r.low; o[2] = r.high;
+    } else if (op == 5) {
+        const float cdf[10] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, func[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+        float pdf;
+        o[0] = (float)SampleDiscrete(func, cdf, 1.f, 9, x0, &pdf);
+    }
+}
+
 // ------------------------------------------------------------------ standalone traversal (mi_pt_trace)
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, uint32_t n, int anyHit, float *hits) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -3876,6 +3895,25 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(hits, dh.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_pt_math_probe(int device_ordinal, int op, uint32_t n, const float *x, const float *y, float *out) {
+    if (!x || !y || !out || op < 0 || op > 5) { g_err = "mi_pt_math_probe: bad argument"; return MI_ERR_INVALID; }
+    if (n == 0) return MI_OK;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || device_ordinal < 0 || device_ordinal >= nDev) { g_err = "no HIP device available (this path has no CPU fallback)"; return MI_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device_ordinal));
+    DevBuf dx, dy, dout;
+    HIPCHK(dx.alloc((size_t)n * 2 * sizeof(float)));
+    HIPCHK(dy.alloc((size_t)n * 2 * sizeof(float)));
+    HIPCHK(dout.alloc((size_t)n * 3 * sizeof(float)));
+    HIPCHK(hipMemcpy(dx.p, x, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy.p, y, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_math_probe, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, op, n, dx.as<float>(), dy.as<float>(), dout.as<float>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

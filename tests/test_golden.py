@@ -216,10 +216,12 @@ def test_gpu_killeroo_1024spp_full_frame(pt):
 def test_gpu_cornell_glass_4096spp_full_frame(pt):
     """BASELINE configs[2]: the Cornell box with the glass sphere, 512x512, maxdepth 8, 4096 spp. Against the glibc-libm
     oracle the image-wide figure is dominated by a few caustic samples thousands of times the mean radiance that exist
-    on one side only (the oracle's own two libm modes differ by 2.1e-3, tools/make_golden.py): 5e-3, and one pixel in ten
-    may sit above the per-pixel target (measured 4.6 %; none does against the correctly rounded oracle)."""
+    on one side only (the oracle's own two libm modes differ by 2.1e-3, tools/make_golden.py). Measured
+    (tools/diag/cornell_measure.py): image relative L2 2.1e-3, 4.6 % of the pixels above the per-pixel target, the worst
+    0.16 x the mean radiance -- the bars sit one notch above that: 3e-3, 6 %, 0.25 (none of it against the correctly
+    rounded oracle, where every pixel is within 2e-4)."""
     z, counters, exact = _load("cornell_4096spp_tiles.npz")
-    _full_frame_against_tiles(pt, pt.Scene(CORNELL, spp=4096), z, counters, exact, 5e-3, 0.1, 2.0)
+    _full_frame_against_tiles(pt, pt.Scene(CORNELL, spp=4096), z, counters, exact, 3e-3, 0.06, 0.25)
 
 
 @pytest.mark.gpu
