@@ -109,7 +109,7 @@ enum : int {
 DEV float Get4(const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 DEV void Set4(float4 &v, int k, float x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
 // ---- int planes
-enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM, I_BOUNCES, I_FLAGS, I_MISLIGHT,
+enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM /* pixel samplers only: see StateWord */, I_FLAGS, I_MISLIGHT,
              I_NPEND, I_PEND0, I_PEND1, I_PEND2, I_PEND3,  // quadrics postponed by the traversal kernel
              I_BAND,                                       // spectralpath: band (path number) of the camera sample
              I_HITINST,                                    // instance the hit primitive was reached through, -1 = none (scenes with instances)
@@ -133,6 +133,17 @@ enum : int {
     // that point away from the sphere), so its contribution was neither formed nor stored in Q_LMIS.
     F_MIS_DARK = 8192
 };
+// The I_FLAGS word carries the path's bounce count and sampler dimension beside the flags: bits 0-13 the flags above, 14-21
+// `bounces` (mi_pt_create bounds max_depth by 255), 22-31 the next sampler dimension (the Halton / Sobol' tables end at 1000 /
+// 1024 dimensions; the random sampler only counts). Three 4-byte planes used to hold them: a shading lane read and wrote
+// all three at scattered slots (~45 B each way at the memory side, PMC of round 2), k_generate stored all three per new
+// path. One word: every kernel that reads the flags has the other two for nothing. (A pixel sampler's two table counters
+// need 32 bits: they stay in the I_DIM plane.)
+constexpr int FLAG_BITS = 14, FLAG_MASK = (1 << FLAG_BITS) - 1, BOUNCE_SHIFT = 14, DIM_SHIFT = 22;
+static_assert(F_MIS_DARK < (1 << FLAG_BITS), "slot flags outgrew their field");
+DEV int StateWord(int flags, int bounces, int dim) { return (flags & FLAG_MASK) | ((bounces & 0xff) << BOUNCE_SHIFT) | (int)((unsigned)(dim & 0x3ff) << DIM_SHIFT); }
+DEV int StateBounces(int word) { return (word >> BOUNCE_SHIFT) & 0xff; }
+DEV int StateDim(int word) { return (int)((unsigned)word >> DIM_SHIFT); }
 // Conservative: false only if the ray o + t d, t >= 0, stays outside the box.
 DEV bool RayMayHitBox(const V3 &o, const V3 &d, const float4 &bmin, const float4 &bmax) {
     float t0 = 0.f, t1 = kInfinity;
@@ -1491,7 +1502,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the rows are read before the next chunk overwrites them
         __builtin_amdgcn_wave_barrier();
-        const bool want = valid && flags == 0 && !restart;
+        const bool want = valid && (flags & FLAG_MASK) == 0 && !restart;
         if (want) wantBits |= 1u << ch;
         if (restart) restartBits |= 1u << ch;
         if (valid && (flags & F_ALIVE)) contBits |= 1u << ch;
@@ -1535,7 +1546,9 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         bool got = false;
         int px = 0, py = 0, band = 0;
         long long sampleNum = 0;
+        int dimBefore = 0;
         if (restart) {  // next band of the same camera sample
+            dimBefore = StateDim(pool.I(I_FLAGS, slot));   // (the band's path goes on with the sampler dimension the last one reached)
             const int pix = pool.I(I_PIXEL, slot);
             px = (int)(short)(pix & 0xffff); py = pix >> 16;
             sampleNum = pool.I(I_SAMPLE, slot);
@@ -1584,13 +1597,13 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
                 pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
             }
-            if (!restart) pool.I(I_DIM, slot) = dimAfter;
+            const bool pixelSampler = IsPixelSampler(s);
+            if (!restart && pixelSampler) pool.I(I_DIM, slot) = dimAfter;
             if (nBands > 1) {
                 pool.I(I_BAND, slot) = restart ? band + 1 : 0;
                 if (!restart) for (int c = 0; c < NQ; ++c) pool.Q(Q_LCA + c, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            pool.I(I_BOUNCES, slot) = 0;
-            pool.I(I_FLAGS, slot) = F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF;   // L = 0, beta = 1, not stored
+            pool.I(I_FLAGS, slot) = StateWord(F_ALIVE | F_L_ZERO | F_BETA_ONE | F_DIFF, 0, pixelSampler ? 0 : (restart ? dimBefore : dimAfter));   // L = 0, beta = 1, not stored
             sGot[e] = 1;
         } else if (want) pool.I(I_FLAGS, slot) = 0;   // stays free (its finished path has been flushed)
     }
@@ -1776,10 +1789,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     uint32_t slot = 0;
     if (cls >= 0 && qi < count) {
         slot = pool.shadeQ[(size_t)cls * pool.n + qi];
-        const int flags = pool.I(I_FLAGS, slot);
+        const int word = pool.I(I_FLAGS, slot);   // flags | bounces | sampler dimension (StateWord)
+        const int flags = word & FLAG_MASK;
         bool lZero = (flags & F_L_ZERO) != 0, betaWritten = false;
         const bool betaOne = (flags & F_BETA_ONE) != 0;
-        const int bounces = pool.I(I_BOUNCES, slot);
+        const int bounces = StateBounces(word);
+        int dimNow = StateDim(word);
         const int prim = pool.I(I_HITPRIM, slot);
         const bool found = prim >= 0;
         auto loadBeta = [&](int c) -> float4 { return LoadBeta(pool, c, slot, betaOne); };
@@ -1857,7 +1872,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             Ray r = SpawnRay(isect, rd);
             pool.R(R_RAY0, slot) = make_float4(r.o.x, r.o.y, r.o.z, r.tMax);
             passThrough = true;  // flags and bounce count stay as they are (but the spawned ray has no differentials)
-            if (flags & F_DIFF) pool.I(I_FLAGS, slot) = flags & ~F_DIFF;
+            if (flags & F_DIFF) pool.I(I_FLAGS, slot) = word & ~F_DIFF;
         }
         if (!finished && !passThrough) {
             const mi_material *mat = &s.materials[s.prims[prim].material];
@@ -1948,7 +1963,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
             PathSampler ps;
             ps.index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
-            ps.dim = pool.I(I_DIM, slot);
+            ps.dim = dimNow;
+            if constexpr (!HALTON_ONLY) { if (IsPixelSampler(s)) ps.dim = pool.I(I_DIM, slot); }
             const int *__restrict__ pixelPlane = pool.i + (size_t)I_PIXEL * pool.n, *__restrict__ samplePlane = pool.i + (size_t)I_SAMPLE * pool.n;
             const int nonSpec = MI_BSDF_ALL & ~MI_BSDF_SPECULAR;
         STAMP(4);
@@ -2324,7 +2340,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 if (!(ok && pdf != 0.f && fNonBlack)) finished = true;
             }
         STAMP(16);
-            pool.I(I_DIM, slot) = ps.dim;
+            dimNow = ps.dim;
+            if constexpr (!HALTON_ONLY) { if (IsPixelSampler(s)) { pool.I(I_DIM, slot) = ps.dim; dimNow = 0; } }
             if (!HALTON_ONLY && s.samplerType >= MI_SAMPLER_RANDOM) {   // the stream moves on with the path
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)ps.index;
                 pool.I(I_IDXHI, slot) = (int)(uint32_t)(ps.index >> 32);
@@ -2337,7 +2354,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_NEE_IN_L | F_NEE_NZ | F_MIS_DARK)) | F_FINISHED;
             } else {
                 newFlags |= F_ALIVE;
-                pool.I(I_BOUNCES, slot) = bounces + 1;
             }
             if (lZero) newFlags |= F_L_ZERO;
             if (betaOne && !betaWritten) newFlags |= F_BETA_ONE;
@@ -2345,7 +2361,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             wantMis = (newFlags & F_MIS) != 0;
             // a direct-lighting estimate with neither ray pending is already known to be black
             if ((newFlags & F_NEE) && !wantShadow && !wantMis) { ++zeroNow; newFlags &= ~F_NEE; }
-            pool.I(I_FLAGS, slot) = newFlags;
+            pool.I(I_FLAGS, slot) = StateWord(newFlags, finished ? bounces : bounces + 1, dimNow);
         }
     }
     STAMP(17);
@@ -2805,6 +2821,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (l.type == MI_LIGHT_DIFFUSE_AREA && (l.shape >= 0 ? (uint32_t)l.shape >= d->n_tris : (uint32_t)(~l.shape) >= d->n_spheres)) { g_err = "area light shape index out of range"; return MI_ERR_INVALID; }
     }
     if (d->integrator.n_ca_bands < 1 || d->integrator.n_ca_bands > MI_NSPEC) { g_err = "n_ca_bands must be in [1, 31]"; return MI_ERR_INVALID; }
+    if (d->integrator.max_depth < 0 || d->integrator.max_depth > 255) { g_err = "max_depth must be in [0, 255] (a path's bounce count travels in 8 bits of its state word)"; return MI_ERR_UNSUPPORTED; }
     if (d->sampler.type < MI_SAMPLER_HALTON || d->sampler.type > MI_SAMPLER_STRATIFIED) { g_err = "unknown mi_sampler.type"; return MI_ERR_INVALID; }
     if (d->sampler.samples_per_pixel < 1) { g_err = "mi_sampler.samples_per_pixel must be positive"; return MI_ERR_INVALID; }
     if (d->sampler.type >= MI_SAMPLER_ZEROTWO) {
@@ -3848,7 +3865,10 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         HIPCHK(hipStreamSynchronize(st));
         int bounces = 0, prim = -1, dim = 0;
         float ray0[4], ray1[4], hit[4];
-        HIPCHK(I1(I_BOUNCES, slot, &bounces)); HIPCHK(I1(I_HITPRIM, slot, &prim)); HIPCHK(I1(I_DIM, slot, &dim));
+        int word0 = 0;
+        HIPCHK(I1(I_FLAGS, slot, &word0)); HIPCHK(I1(I_HITPRIM, slot, &prim));
+        bounces = (word0 >> BOUNCE_SHIFT) & 0xff;
+        if (s.samplerType >= MI_SAMPLER_ZEROTWO) HIPCHK(I1(I_DIM, slot, &dim)); else dim = (int)((unsigned)word0 >> DIM_SHIFT);
         HIPCHK(F4(R_RAY0, slot, ray0)); HIPCHK(F4(R_RAY1, slot, ray1)); HIPCHK(F4(R_HIT, slot, hit));
         r[0] = (float)bounces; r[1] = (float)prim; r[2] = (float)dim;
         r[4] = ray0[0]; r[5] = ray0[1]; r[6] = ray0[2]; r[7] = prim >= 0 ? hit[0] : ray0[3];
@@ -3867,7 +3887,8 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int fl = 0;
-        HIPCHK(I1(I_FLAGS, slot, &fl)); HIPCHK(I1(I_DIM, slot, &dim));
+        HIPCHK(I1(I_FLAGS, slot, &fl));
+        if (s.samplerType >= MI_SAMPLER_ZEROTWO) HIPCHK(I1(I_DIM, slot, &dim)); else dim = (int)((unsigned)fl >> DIM_SHIFT);
         HIPCHK(F4(R_RAY0, slot, ray0)); HIPCHK(F4(R_RAY1, slot, ray1));
         r[3] = (fl & F_ALIVE) ? 0.f : 1.f;
         r[12] = ray0[0]; r[13] = ray0[1]; r[14] = ray0[2]; r[15] = (float)dim;

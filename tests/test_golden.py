@@ -269,7 +269,9 @@ def test_gpu_procedural_10M_triangles_2048spp_in_8_shards(pt, tmp_path):
     # (1.6e-5 at 2048 equal samples), linear in N; the device adds a pixel's samples in groups of 64 first and stays within
     # 7e-7 of the exact sum. The device's own passes agree to 2.3e-7 whatever their structure (tools/diag/spp_scaling.py:
     # one 2048-spp pass, eight 256-spp passes, other pool sizes); with random sample values both orders agree to 7e-7.
-    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, 1e-4, 2e-3, 0.05, exact_rel=2e-5)
+    # (per pixel the same drift is 1.6e-5 of the PIXEL's value: on a pixel that looks into an emitter, 30 x the mean radiance,
+    # 4.5e-4 of the mean -- measured maximum; the bar 1e-3 is BASELINE's per-pixel target itself)
+    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, 1e-4, 2e-3, 0.05, exact_max=1e-3, exact_rel=2e-5)
     # the 8 shards of configs[4] through ShardedFrame.step
     film32 = ptdist.device_film_tensor(integ)
     acc = np.zeros((h, w, 32), np.float32)
