@@ -85,6 +85,9 @@ struct DScene {
     long long samplesPerPixel;             // (RANDOM: the stream number of a camera sample)
     // pixel samplers (ZEROTWO / STRATIFIED): the tables of every pixel of the sample bounds, built at create (k_pixel_tables):
     // pixTab1[(pixel * pixelDims + dimension) * spp + sample], pixTab2[((pixel * pixelDims + dimension) * spp + sample) * 2 + {0, 1}]
+    // set per render (mi_pt_render): the Halton indices of the pass fit 32 bits (I_IDXHI is neither stored nor read); somebody
+    // reads a path's pixel and sample number after k_generate (other samplers, spectralpath bands, textured lens cameras)
+    int index32, storePixelSample;
     const float *pixTab1, *pixTab2;
     int pixelDims, xSamples, ySamples, jitter;
     // integrator

@@ -1179,7 +1179,8 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
     if (!OVF && (npend & PEND_OVERFLOW)) { pool.ovfQ[2 * (size_t)pool.n + atomicAdd(&ctr->ovfCount[2].v, 1u)] = slot; return; }
     if (npend != 0) { loadRay(); found = ResolveQuadrics<false, INST, OVF>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
     bool added = false;
-    if (!found && s.lights[pool.I(I_MISLIGHT, slot)].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
+    const int misLight = s.nLights > 1 ? pool.I(I_MISLIGHT, slot) : 0;
+    if (!found && s.lights[misLight].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
         const bool lZero = (flags & F_L_ZERO) != 0;
         for (int c = 0; c < NQ; ++c) {
             const float4 a = pool.Q(Q_LMIS + c, slot);
@@ -1192,7 +1193,7 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
         flags &= ~F_L_ZERO;
     }
     if (found) {
-        const int lightNum = pool.I(I_MISLIGHT, slot);
+        const int lightNum = misLight;
         if (s.prims[h.prim].area_light == lightNum && !(flags & F_MIS_DARK)) {   // (dark: cannot happen, the bounds are conservative)
             const mi_light &l = s.lights[lightNum];
             bool emit = l.two_sided != 0;
@@ -1591,11 +1592,13 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             pool.R(R_RAY1, slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, 1.f);   // etaScale = 1
             pool.F(P_FILMX, slot) = pfx; pool.F(P_FILMY, slot) = pfy;
 
-            pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
-            pool.I(I_SAMPLE, slot) = (int)sampleNum;
+            if (s.storePixelSample) {
+                pool.I(I_PIXEL, slot) = (px & 0xffff) | (py << 16);
+                pool.I(I_SAMPLE, slot) = (int)sampleNum;
+            }
             if (!(restart && s.samplerType >= MI_SAMPLER_RANDOM)) {   // (a restarted band draws on from where its stream stands)
                 pool.I(I_IDXLO, slot) = (int)(uint32_t)index;
-                pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
+                if (!s.index32) pool.I(I_IDXHI, slot) = (int)(uint32_t)(index >> 32);
             }
             const bool pixelSampler = IsPixelSampler(s);
             if (!restart && pixelSampler) pool.I(I_DIM, slot) = dimAfter;
@@ -1962,7 +1965,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             // BSDF ctor, reflection.h:170-176 (after Bump(): it reads the shading geometry)
             fr.ns = isect.shN; fr.ng = isect.n; fr.ss = Normalize(isect.shDpdu); fr.ts = Cross(fr.ns, fr.ss);
             PathSampler ps;
-            ps.index = ((uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32) | (uint32_t)pool.I(I_IDXLO, slot);
+            ps.index = (uint32_t)pool.I(I_IDXLO, slot);
+            if (!s.index32) ps.index |= (uint64_t)(uint32_t)pool.I(I_IDXHI, slot) << 32;
             ps.dim = dimNow;
             if constexpr (!HALTON_ONLY) { if (IsPixelSampler(s)) ps.dim = pool.I(I_DIM, slot); }
             const int *__restrict__ pixelPlane = pool.i + (size_t)I_PIXEL * pool.n, *__restrict__ samplePlane = pool.i + (size_t)I_SAMPLE * pool.n;
@@ -2213,7 +2217,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     if (dark) newFlags |= F_MIS_DARK;
                                     pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
                                     pool.R(R_MI1, slot) = make_float4(mr.d.y, mr.d.z, 0.f, 0.f);
-                                    pool.I(I_MISLIGHT, slot) = lightNum;
+                                    if (s.nLights > 1) pool.I(I_MISLIGHT, slot) = lightNum;   // (one light: k_resolve_mis knows which)
                                     newFlags |= F_MIS;
                                 }
                             }
@@ -3333,6 +3337,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
     s.samplerType = d->sampler.type;
     s.samplesPerPixel = d->sampler.samples_per_pixel;
     s.pixTab1 = s.pixTab2 = nullptr;
+    s.index32 = 0; s.storePixelSample = 1;
     s.pixelDims = d->sampler.pixel_dims; s.xSamples = d->sampler.x_samples; s.ySamples = d->sampler.y_samples; s.jitter = d->sampler.jitter;
     s.sobolResolution = d->sampler.sobol_resolution;
     s.sobolLog2Resolution = d->sampler.sobol_log2_resolution;
@@ -3681,6 +3686,12 @@ int mi_pt_render(mi_pt *pt, const mi_render_params *rp, float *film_sum, float *
         return MI_ERR_INVALID;
     }
     HIPCHK(hipSetDevice(pt->device));
+    {   // what this pass lets the kernels leave out (DScene::index32 / storePixelSample)
+        DScene &sc = pt->scene;
+        const unsigned long long lastSample = (unsigned long long)rp->sample_begin + (unsigned long long)(rp->spp_override > 0 ? rp->spp_override : pt->spp);
+        sc.index32 = (sc.samplerType == MI_SAMPLER_HALTON && (lastSample + 1ull) * (unsigned long long)std::max(1, sc.sampleStride) < (1ull << 32)) ? 1 : 0;
+        sc.storePixelSample = (sc.samplerType >= MI_SAMPLER_RANDOM || sc.nBands > 1 || (pt->nTextures > 0 && sc.camera.lens_radius > 0)) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)rp->stream;
     if (!(rp->flags & MI_RENDER_ACCUMULATE)) HIPCHK(hipMemsetAsync(pt->film, 0, pt->nPix * 32 * sizeof(float), st));
     HIPCHK(hipStreamSynchronize(st));
@@ -3813,6 +3824,7 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
     DScene &s = pt->scene;
     if (px < s.sampleBounds[0] || px >= s.sampleBounds[2] || py < s.sampleBounds[1] || py >= s.sampleBounds[3]) { g_err = "pixel outside the sample bounds"; return MI_ERR_INVALID; }
     s.pixelBounds[0] = px; s.pixelBounds[1] = py; s.pixelBounds[2] = px + 1; s.pixelBounds[3] = py + 1;
+    s.index32 = 0; s.storePixelSample = 1;
     SubRenderer &sub = pt->subs[0];
     hipStream_t st = sub.stream;
     WorkDesc wd{};
