@@ -184,7 +184,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_node, 2), "tri_tests_per_ray": round(n_tri, 2),
                 "rays_per_launch": round(ext_rays / n_launch), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-                "launches": n_launch,
+                "launches": n_launch, "shaded_vertices": int(acc["total_paths"]),
                 "kernel_time_s": {"generate": round(t_kernel[1], 4), "trav0": round(t_kernel[6], 4), "extend": round(t_kernel[2], 4),
                                   "shade": round(t_kernel[3], 4), "shadow": round(t_kernel[4], 4),
                                   "mis": round(t_kernel[5], 4), "render_loop": round(t_kernel[0], 4)}}

@@ -6,7 +6,7 @@ import json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
-NAMES = {"killeroo": "killeroo-simple", "cornell": "cornell-glass", "procedural": "procedural-10000000tris"}
+NAMES = {"killeroo": "killeroo-simple", "cornell": "cornell-glass", "procedural": "procedural-10000000tris", "matzoo": "matzoo", "texzoo": "textured-zoo"}
 traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 try:
     traffic = json.load(open(traffic_path))
@@ -35,6 +35,22 @@ for w, wl in NAMES.items():
         "l2_hit_rate": round(float(vals["TCC_HIT_sum"]) / (float(vals["TCC_HIT_sum"]) + float(vals["TCC_MISS_sum"])), 3),
         "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE tallies 128-B reads at 64 B, MI355X_MICROARCH.md HBM section)",
         "source": "profiles/%s_%s_pmc_hbm_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_configs.sh)" % (rnd, w)}
+    # the shading instances: HBM bytes per launch of each k_shade<NL, TM>, and all of them per shaded vertex
+    shade = {}
+    for name, body in re.findall(r"(k_shade<[^\n]*)\n((?:   [^\n]*\n)+)", txt):
+        v = dict(re.findall(r"   (\S+)\s+mean/dispatch (\S+)", body))
+        nn = re.search(r"\(n=(\d+)\)", body)
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            shade[name.strip()] = {"hbm_bytes_per_launch": int((2 * float(v["FETCH_SIZE"]) + float(v["WRITE_SIZE"])) * 1024), "launches": int(nn.group(1))}
+    tot = sum(e["hbm_bytes_per_launch"] * e["launches"] for e in shade.values())
+    verts = None
+    try:
+        p1 = json.load(open(os.path.join(src, "pass1.json")))   # the counter pass's own bench line: one frame
+        verts = p1["roofline"].get("shaded_vertices")
+    except (OSError, ValueError, KeyError):
+        pass
+    traffic[wl]["k_shade"] = {"instances": shade, "hbm_bytes_per_frame": tot, "shaded_vertices_per_frame": verts,
+                              "hbm_bytes_per_vertex": round(tot / verts, 1) if verts else None, "algorithmic_bytes_per_vertex": 960}
     r = bench["roofline"]
     print("%-12s %.1f Mray/s  %.1f ms/frame  k_trav<0>: algorithmic %.2f GB/launch, HBM traffic %.2f GB/launch (%.2fx), frac %.3f" %
           (w, bench["value"], bench["ms_per_step"], r["bytes_per_ray"] * r["rays_per_launch"] / 1e9, traffic[wl]["k_trav0_hbm_bytes_per_launch"] / 1e9,
