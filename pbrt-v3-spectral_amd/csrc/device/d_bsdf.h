@@ -751,12 +751,86 @@ DEV float4 SimpleEvalQuad(const SimpleLobes<NL> &sl, const mi_bxdf *bx, int c, D
 // `acc |= bits(|x|)`: acc != 0 afterwards iff some x was != 0 (a NaN counts, as in `x != 0.f`)
 DEV void OrNonZero(unsigned &acc, float x) { acc |= __float_as_uint(x) & 0x7fffffffu; }
 
+// BSDF::f(woW, wiW, flags) (reflection.cpp:670-683) summed lobe by lobe into the caller's spectrum (rd(c) / wr(c, quad): quad c of
+// the lane's column of the LDS tile), for the instances with more than two lobes: ONE lobe description alive at a time and
+// one copy of LobeF's switch, where the list form keeps NL descriptions (73 registers at NL = 8, indexed at run time: the
+// Disney instance ran them through 2 500 scratch instructions) behind NL unrolled copies of the switch (96 k instructions),
+// and EvalBin fetched every bin of every lobe with a load of its own. The sum runs in lobe order, from 0.f: the same
+// additions as EvalBin's. Returns the number of lobes that contributed.
+template <int NL, unsigned TM, typename RD, typename WR>
+DEV int AccumulateLobe(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL> *lt, RD rd, WR wr) {
+    const int li = le.lobe & 0xff;
+    const mi_bxdf &b = bx[li];
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        float4 acc = rd(c);
+        float R[4], Sv[4] = {0.f, 0.f, 0.f, 0.f}, Kv[4] = {0.f, 0.f, 0.f, 0.f}, Sc[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr ((TM & TM_TEXTURED) != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bin = min(4 * c + k, MI_NSPEC - 1);
+                R[k] = TexturedSpec(*lt, b, li, (le.lobe & 0x100) ? 1 : 0, bin);
+                if constexpr (TM_NEEDS_S(TM)) Sv[k] = TexturedSpec(*lt, b, li, 1, bin);
+            }
+        } else {
+            const float4 r4 = LoadSpec4((le.lobe & 0x100) ? b.S : b.R, c);
+            R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w;
+            if constexpr (TM_NEEDS_S(TM)) { const float4 s4 = LoadSpec4(b.S, c); Sv[0] = s4.x; Sv[1] = s4.y; Sv[2] = s4.z; Sv[3] = s4.w; }
+        }
+        if constexpr (TM_NEEDS_K(TM)) { const float4 k4 = LoadSpec4(b.K, c); Kv[0] = k4.x; Kv[1] = k4.y; Kv[2] = k4.z; Kv[3] = k4.w; }
+        const bool scaled = (TM & TM_SCALED) != 0 && (le.lobe & 0x200);
+        if (scaled) { const float4 c4 = LoadSpec4(b.scale, c); Sc[0] = c4.x; Sc[1] = c4.y; Sc[2] = c4.z; Sc[3] = c4.w; }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = LobeValueCore<TM>(le, R[k], Sv[k], Kv[k]);
+            if (scaled) v[k] = Sc[k] * v[k];
+        }
+        if (c == 7) v[3] = 0.f;   // bin 31 does not exist
+        acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
+        wr(c, acc);
+    }
+    return 1;
+}
+// (wo, wi: in the shading frame; reflect: Dot(wiW, ng) * Dot(woW, ng) > 0)
+template <int NL, unsigned TM, typename RD, typename WR>
+DEV int AccumulateFLocal(const BSDFFrame &fr, const V3 &wo, const V3 &wi, bool reflect, int flags, const LobeTexT<NL> *lt, RD rd, WR wr) {
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) wr(c, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (wo.z == 0) return 0;
+    const mi_material *m = fr.m;
+    int n = 0;
+#pragma unroll 1
+    for (int i = 0; i < m->n_bxdfs; ++i) {
+        if (!fr.On(i)) continue;
+        const mi_bxdf &b = m->bxdf[i];
+        if (!(MatchesFlags(b, flags) && ((reflect && (b.flags & MI_BSDF_REFLECTION)) || (!reflect && (b.flags & MI_BSDF_TRANSMISSION))))) continue;
+        const LobeEval le = LobeF<TM>(b, i, wo, wi, fr.ov);
+        if ((le.kind & 0xff) == LK_NONE) continue;
+        n += AccumulateLobe<NL, TM>(le, m->bxdf, lt, rd, wr);
+    }
+    return n;
+}
+template <int NL, unsigned TM, typename RD, typename WR>
+DEV int AccumulateF(const BSDFFrame &fr, const V3 &woW, const V3 &wiW, int flags, const LobeTexT<NL> *lt, RD rd, WR wr) {
+    return AccumulateFLocal<NL, TM>(fr, fr.WorldToLocal(woW), fr.WorldToLocal(wiW), Dot(wiW, fr.ng) * Dot(woW, fr.ng) > 0, flags, lt, rd, wr);
+}
+// (a specular sample's single lobe, the same way)
+template <int NL, unsigned TM, typename RD, typename WR>
+DEV void AccumulateSpecular(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL> *lt, RD rd, WR wr) {
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) wr(c, make_float4(0.f, 0.f, 0.f, 0.f));
+    AccumulateLobe<NL, TM>(le, bx, lt, rd, wr);
+}
+
 // BSDF::Sample_f (reflection.cpp:703-768). Returns false when the reference returns a
 // black f (including the early-outs that leave *pdf untouched). On success the value is
 // described by *ev (one specular LobeEval, or the lobe list for the sampled direction).
-template <int NL, unsigned TM>
+// FILL = false (the shading instances with more than two lobes): a non-specular sample leaves the lobe list empty -- the
+// caller sums f over the lobes straight into its spectrum tile (AccumulateF) -- a specular one still describes its single lobe.
+template <int NL, unsigned TM, bool FILL = true>
 DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, float u0, float u1, float *pdf, int type,
-                       int *sampledType, BSDFEvalT<NL> *ev) {
+                       int *sampledType, BSDFEvalT<NL> *ev, V3 *wiLocalOut = nullptr) {
     const mi_material *m = fr.m;
     const AlphaOv &ov = fr.ov;
     ev->n = 0;
@@ -869,6 +943,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     }
     if (*pdf == 0) { *sampledType = 0; return false; }
     *wiWorld = fr.LocalToWorld(wi);
+    if (wiLocalOut) *wiLocalOut = wi;   // (the lobes are evaluated with the sampled local direction itself, not with its way back from the world)
     if (!isSpecular && matchingComps > 1)
         for (int i = 0; i < m->n_bxdfs; ++i)
             if (i != bi && fr.On(i) && MatchesFlags(m->bxdf[i], type)) *pdf += LobePdf<TM>(m->bxdf[i], wo, wi, fr.ov);
@@ -876,7 +951,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     if (isSpecular) {
         ev->n = 1;
         ev->lobes[0] = spec;
-    } else {
+    } else if constexpr (FILL) {
         bool reflect = Dot(*wiWorld, fr.ng) * Dot(woWorld, fr.ng) > 0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {

@@ -1777,12 +1777,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 #else
     constexpr bool SIMPLE_SPECTRA = NL <= 2 && TM_SIMPLE_KINDS(TM);   // the straight-line spectral passes (d_bsdf.h, SimpleLobes)
 #endif
+    // more than two lobes: f is summed lobe by lobe into the lane's column of the spectrum tile (AccumulateF, d_bsdf.h)
+#ifdef MIPT_NO_ACCUMULATE
+    constexpr bool ACCUM = false;
+#else
+    constexpr bool ACCUM = NL > 2;
+#endif
 #ifdef MIPT_FUSED_HALTON
     constexpr bool FUSED_HALTON = HALTON_ONLY;
 #else
     constexpr bool FUSED_HALTON = false;   // (measured: the side-by-side digit loops cost 29 more scratch instructions and 7 % of the kernel)
 #endif
     __shared__ SpectrumTile tile;
+    auto rdTile = [&](int c) -> float4 { return tile.q[c][threadIdx.x]; };
+    auto wrTile = [&](int c, const float4 &v) { tile.q[c][threadIdx.x] = v; };
 #ifdef MIPT_EXP_STAMPS
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
     const bool stampOn = (blockIdx.x % 61u) == 0u;   // (one block in 61 reports: the atomics of every wave would be the kernel)
@@ -2002,7 +2010,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         const float lightPdf = ls.pdf;
                         if (lightPdf > 0 && !ls.black) {
                             BSDFEvalT<NL> ev;
-                            BSDF_f<NL, TM>(fr, isect.wo, ls.wi, nonSpec, &ev);
+                            if constexpr (ACCUM) AccumulateF<NL, TM>(fr, isect.wo, ls.wi, nonSpec, ltp, rdTile, wrTile);
+                            else BSDF_f<NL, TM>(fr, isect.wo, ls.wi, nonSpec, &ev);
+                            auto fQuad = [&](int c) -> float4 { if constexpr (ACCUM) return rdTile(c); else return EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp); };
                             const float absdot = AbsDot(ls.wi, isect.shN);
                             const float scatteringPdf = BSDF_Pdf<TM>(fr, isect.wo, ls.wi, nonSpec);
         STAMP(7);
@@ -2073,7 +2083,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 fNonBlack |= accF != 0u; liNonBlack |= accLi != 0u; nzAny |= accNz != 0u;
                             } else {
 #pragma unroll 1
-                                for (int c = 0; c < EXP_NQ; ++c) neeQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), LiQuad<TM>(s, light, ls, c));
+                                for (int c = 0; c < EXP_NQ; ++c) neeQuad(c, fQuad(c), LiQuad<TM>(s, light, ls, c));
                             }
                             // only a contribution whose shadow ray will be traced is ever read; into Q_L itself while the
                             // path's L is still empty (F_NEE_IN_L)
@@ -2094,7 +2104,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             float sPdf = 0;
                             int sampledType = 0;
                             BSDFEvalT<NL> ev;
-                            const bool ok = BSDF_Sample_f<NL, TM>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev);
+                            V3 wiLocal;
+                            const bool ok = BSDF_Sample_f<NL, TM, !ACCUM>(fr, isect.wo, &wi, uS0, uS1, &sPdf, nonSpec, &sampledType, &ev, &wiLocal);
+                            auto fQuad = [&](int c) -> float4 { if constexpr (ACCUM) return rdTile(c); else return EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp); };
         STAMP(10);
                             if (ok && sPdf > 0) {
                                 const float absdot = AbsDot(wi, isect.shN);
@@ -2117,6 +2129,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // traces it), but its contribution is never read: F_MIS_DARK
                                 const Ray mr = SpawnRay(isect, wi);
                                 const bool dark = go && !isEnvLight && !RayMayHitBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1]);
+                                if constexpr (ACCUM) {   // f of the sampled direction into the tile (only if something will read it)
+                                    if (go) {
+                                        if (ev.n > 0) AccumulateSpecular<NL, TM>(ev.lobes[0], mat->bxdf, ltp, rdTile, wrTile);
+                                        else AccumulateFLocal<NL, TM>(fr, fr.WorldToLocal(isect.wo), wiLocal, Dot(wi, fr.ng) * Dot(isect.wo, fr.ng) > 0, nonSpec, ltp, rdTile, wrTile);
+                                    }
+                                }
         STAMP(11);
                                 auto darkQuad = [&](int c, const float4 &fq) {   // (only: is f black? -- that decides whether the ray exists)
 #pragma unroll
@@ -2204,11 +2222,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 } else {
                                     if (dark) {
 #pragma unroll 1
-                                        for (int c = 0; c < EXP_NQ; ++c) darkQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp));
+                                        for (int c = 0; c < EXP_NQ; ++c) darkQuad(c, fQuad(c));
                                     }
                                     if (go && !dark) {
 #pragma unroll 1
-                                        for (int c = 0; c < EXP_NQ; ++c) misQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp), isEnvLight ? zero4 : LoadSpec4(light.L, c));
+                                        for (int c = 0; c < EXP_NQ; ++c) misQuad(c, fQuad(c), isEnvLight ? zero4 : LoadSpec4(light.L, c));
                                     }
                                 }
                                 StoreSpectrumLines(tile, pool, Q_LMIS, slot, EXP_STORE(go && !dark));   // whole 128-B lines, as for the light sample
@@ -2235,7 +2253,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 else Get2D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot, &u2[0], &u2[1]);
                 const float u0 = u2[0], u1 = u2[1];
                 BSDFEvalT<NL> ev;
-                const bool ok = BSDF_Sample_f<NL, TM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev);
+                V3 wiLocal;
+                const bool ok = BSDF_Sample_f<NL, TM, !ACCUM>(fr, wo, &wi, u0, u1, &pdf, MI_BSDF_ALL, &sflags, &ev, &wiLocal);
+                if constexpr (ACCUM) {
+                    if (ok && pdf != 0.f) {
+                        if (ev.n > 0) AccumulateSpecular<NL, TM>(ev.lobes[0], mat->bxdf, ltp, rdTile, wrTile);
+                        else AccumulateFLocal<NL, TM>(fr, fr.WorldToLocal(wo), wiLocal, Dot(wi, fr.ng) * Dot(wo, fr.ng) > 0, MI_BSDF_ALL, ltp, rdTile, wrTile);
+                    }
+                }
+                auto fQuad = [&](int c) -> float4 { if constexpr (ACCUM) return rdTile(c); else return EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp); };
         STAMP(13);
                 bool fNonBlack = false;
                 if (ok && pdf != 0.f) {
@@ -2301,7 +2327,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         fNonBlack |= accF != 0u;
                     } else {
 #pragma unroll 1
-                        for (int c = 0; c < EXP_NQ; ++c) contQuad(c, EvalQuad<NL, TM>(ev, mat->bxdf, c, ltp));
+                        for (int c = 0; c < EXP_NQ; ++c) contQuad(c, fQuad(c));
                     }
                     // (the new throughput is stored below, once it is known that a later vertex will read it)
                     bool killed = false;
