@@ -607,6 +607,34 @@ DEV float4 LoadSpec4(const float *spec, int c) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 DEV float Quad(const float4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+// TexBin / TexturedSpec for the four bins of quad c at once: the basis tables and the lobe's constant as 16-B loads (a textured
+// pass fetched four words per bin and lobe: ~750 loads per vertex on the textured zoo). Same operations per bin.
+DEV float4 TexQuad(const float *basis, const mi_texture *textures, const IllumRGB &q, int c) {
+    if (q.i1 < 0) {   // Checkerboard2DTexture
+        const mi_texture &t = textures[q.i2];
+        const float4 a = LoadSpec4(t.spec1, c), b = LoadSpec4(t.spec2, c);
+        return make_float4(clampf((1 - q.w0) * a.x + q.w0 * b.x, 0.f, kInfinity), clampf((1 - q.w0) * a.y + q.w0 * b.y, 0.f, kInfinity),
+                           clampf((1 - q.w0) * a.z + q.w0 * b.z, 0.f, kInfinity), clampf((1 - q.w0) * a.w + q.w0 * b.w, 0.f, kInfinity));
+    }
+    const float4 b0 = LoadSpec4(basis, c), b1 = LoadSpec4(basis + q.i1 * MI_NSPEC, c), b2 = LoadSpec4(basis + q.i2 * MI_NSPEC, c);
+    auto one = [&](float x0, float x1, float x2) {
+        float r = 0.f;
+        r += x0 * q.w0;
+        r += x1 * q.w1;
+        r += x2 * q.w2;
+        r *= .86445f;
+        return clampf(r, 0.f, kInfinity);
+    };
+    return make_float4(one(b0.x, b1.x, b2.x), one(b0.y, b1.y, b2.y), one(b0.z, b1.z, b2.z), one(b0.w, b1.w, b2.w));
+}
+template <int NL>
+DEV float4 TexturedQuad(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int c) {
+    const float4 k = LoadSpec4(which ? b.S : b.R, c);
+    if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return k;
+    const float4 T = TexQuad(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], c);
+    if (((which ? lt.mulS : lt.mulR) >> li) & 1u) return make_float4(k.x * T.x, k.y * T.y, k.z * T.z, k.w * T.w);
+    return T;
+}
 template <int NL, unsigned TM>
 DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c, const LobeTexT<NL> *lt) {
     if constexpr (NL > 2 || (TM & TM_TEXTURED) != 0) {   // long lobe lists: the quads of all lobes would not fit the register file
@@ -766,12 +794,9 @@ DEV int AccumulateLobe(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL>
         float4 acc = rd(c);
         float R[4], Sv[4] = {0.f, 0.f, 0.f, 0.f}, Kv[4] = {0.f, 0.f, 0.f, 0.f}, Sc[4] = {1.f, 1.f, 1.f, 1.f};
         if constexpr ((TM & TM_TEXTURED) != 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int bin = min(4 * c + k, MI_NSPEC - 1);
-                R[k] = TexturedSpec(*lt, b, li, (le.lobe & 0x100) ? 1 : 0, bin);
-                if constexpr (TM_NEEDS_S(TM)) Sv[k] = TexturedSpec(*lt, b, li, 1, bin);
-            }
+            const float4 r4 = TexturedQuad(*lt, b, li, (le.lobe & 0x100) ? 1 : 0, c);
+            R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w;
+            if constexpr (TM_NEEDS_S(TM)) { const float4 s4 = TexturedQuad(*lt, b, li, 1, c); Sv[0] = s4.x; Sv[1] = s4.y; Sv[2] = s4.z; Sv[3] = s4.w; }
         } else {
             const float4 r4 = LoadSpec4((le.lobe & 0x100) ? b.S : b.R, c);
             R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w;

@@ -1781,7 +1781,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 #ifdef MIPT_NO_ACCUMULATE
     constexpr bool ACCUM = false;
 #else
-    constexpr bool ACCUM = NL > 2;
+    constexpr bool ACCUM = NL > 2 || (TM & TM_TEXTURED) != 0;   // (image-textured lobes too: their spectra quad by quad, TexturedQuad)
 #endif
 #ifdef MIPT_FUSED_HALTON
     constexpr bool FUSED_HALTON = HALTON_ONLY;
@@ -1957,13 +1957,22 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             lt.hasS |= 1u << i;
                             if (ltx.flags & MI_LOBE_TEX_MUL_S) lt.mulS |= 1u << i;
                         }
-                        bool rNonBlack = false, sNonBlack = false, texNonBlack = false;
-                        for (int b = 0; b < MI_NSPEC; ++b) {
-                            rNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 0, b) != 0.f;
-                            sNonBlack |= TexturedSpec(lt, mat->bxdf[i], i, 1, b) != 0.f;
-                            if (ltx.tex_R >= 0) texNonBlack |= TexBin(lt.basis, lt.textures, lt.r[i], b) != 0.f;
-                            if (ltx.tex_S >= 0) texNonBlack |= TexBin(lt.basis, lt.textures, lt.s[i], b) != 0.f;
+                        // (the spectrum the material tests with IsBlack(), a quad of bins at a time; only what the lobe's rule reads)
+                        unsigned rNZ = 0u, sNZ = 0u, texNZ = 0u;
+                        auto orQuad = [](unsigned &acc, const float4 &q, int c) {
+                            OrNonZero(acc, q.x); OrNonZero(acc, q.y); OrNonZero(acc, q.z);
+                            if (c != NQ - 1) OrNonZero(acc, q.w);   // bin 31 does not exist
+                        };
+#pragma unroll 1
+                        for (int c = 0; c < NQ; ++c) {
+                            if (ltx.rule != MI_LOBE_IF_TEX) orQuad(rNZ, TexturedQuad(lt, mat->bxdf[i], i, 0, c), c);
+                            if (ltx.rule == MI_LOBE_IF_R_OR_S) orQuad(sNZ, TexturedQuad(lt, mat->bxdf[i], i, 1, c), c);
+                            if (ltx.rule == MI_LOBE_IF_TEX) {
+                                if (ltx.tex_R >= 0) orQuad(texNZ, TexQuad(lt.basis, lt.textures, lt.r[i], c), c);
+                                if (ltx.tex_S >= 0) orQuad(texNZ, TexQuad(lt.basis, lt.textures, lt.s[i], c), c);
+                            }
                         }
+                        const bool rNonBlack = rNZ != 0u, sNonBlack = sNZ != 0u, texNonBlack = texNZ != 0u;
                         const bool present = ltx.rule == MI_LOBE_IF_R_OR_S ? (rNonBlack || sNonBlack) : (ltx.rule == MI_LOBE_IF_TEX ? texNonBlack : rNonBlack);
                         if (present) mask |= 1u << i;
                     }
