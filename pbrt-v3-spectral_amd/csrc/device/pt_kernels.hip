@@ -1322,7 +1322,9 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     __shared__ float sFilter[256];  // the 16x16 filter table, one LDS copy per block
     __shared__ unsigned sWant[SLOT_CHUNKS][BLOCK / 64], sPrim[SLOT_CHUNKS][BLOCK / 64], sCont[SLOT_CHUNKS][BLOCK / 64];
     __shared__ unsigned long long sWorkBase;
-    __shared__ unsigned sPrimBase, sContBase, sTotWant;
+    __shared__ unsigned sPrimBase, sContBase, sTotWant, sTotFin;
+    __shared__ unsigned sFinCnt[SLOT_CHUNKS][BLOCK / 64];
+    __shared__ unsigned short sFin[SLOT_CHUNKS * BLOCK];   // the block's finished slots: offset in the block | 0x8000 if L reads as zero
     sFilter[threadIdx.x] = s.filterTable[threadIdx.x];
     __syncthreads();
     unsigned bad = 0, cam = 0;
@@ -1331,18 +1333,76 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int nBands = s.nBands;
     unsigned wantBits = 0, restartBits = 0, contBits = 0, gotBits = 0;   // bit ch: state of this thread's slot in chunk ch
+    unsigned finBits = 0, finZeroBits = 0;
+#ifdef MIPT_EXP_STAMPS
+    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+    const bool stampOn = (blockIdx.x % 61u) == 0u;
+#endif
     // ---------------------------------------------------------------- pass 1: film flush
+    // The finished paths are a third of the block's slots: they are listed first (in slot order: neighbours in the list are
+    // samples of the same pixel more often than not) and flushed by all lanes together, as the refill below -- chunk by
+    // chunk, a third of each wave worked through eight dependent round trips to memory (state word, then the L line) and
+    // the kernel waited them out at four blocks per CU (in-kernel stamps, round 3: 78 % of the kernel in this pass).
+    {
+        int fl[SLOT_CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {   // (all eight loads in flight together)
+            const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+            fl[ch] = slot < pool.n ? pool.I(I_FLAGS, slot) : -1;
+        }
+#pragma unroll
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
+            const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
+            const bool valid = slot < pool.n;
+            const int flags = fl[ch];
+            const bool fin = valid && (flags & F_FINISHED);
+            // Integrator "spectralpath" (spectralpath.cpp:258-318): nBands paths per camera sample; a finished
+            // path hands its bins to the sample's stitched spectrum and the slot restarts on the same camera ray
+            // with the sampler dimension running on; the last band flushes the stitched spectrum.
+            const bool restart = fin && nBands > 1 && pool.I(I_BAND, slot) + 1 < nBands;
+            const bool want = valid && (fin || (flags & FLAG_MASK) == 0) && !restart;   // (a flushed slot is free)
+            if (fin) finBits |= 1u << ch;
+            if (fin && (flags & F_L_ZERO)) finZeroBits |= 1u << ch;
+            if (want) wantBits |= 1u << ch;
+            if (restart) restartBits |= 1u << ch;
+            if (valid && !fin && (flags & F_ALIVE)) contBits |= 1u << ch;
+            const unsigned long long wm = __ballot(want), fm = __ballot(fin);
+            if (lane == 0) { sWant[ch][wave] = (unsigned)__popcll(wm); sFinCnt[ch][wave] = (unsigned)__popcll(fm); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // exclusive prefix over (chunk, wave) and the block's range of the work list in one add
+        unsigned tot = 0;
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sWant[ch][w]; sWant[ch][w] = tot; tot += n; }
+        sWorkBase = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : ~0ull;
+        sTotWant = tot;
+    }
+    if (threadIdx.x == 64) {
+        unsigned tot = 0;
+        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
+            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sFinCnt[ch][w]; sFinCnt[ch][w] = tot; tot += n; }
+        sTotFin = tot;
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
-        const uint32_t slot = (blockIdx.x * SLOT_CHUNKS + ch) * BLOCK + threadIdx.x;
-        const bool valid = slot < pool.n;
-        int flags = valid ? pool.I(I_FLAGS, slot) : 0;
-        const bool fin = valid && (flags & F_FINISHED);
+        const bool fin = (finBits >> ch) & 1u;
+        const unsigned long long fm = __ballot(fin);
+        if (fin) sFin[sFinCnt[ch][wave] + (unsigned)__popcll(fm & ltMask)] =
+            (unsigned short)((ch * BLOCK + threadIdx.x) | (((finZeroBits >> ch) & 1u) ? 0x8000u : 0u));
+    }
+    __syncthreads();
+    const unsigned totFin = sTotFin;
+    STAMP(19);
+#pragma unroll 1
+    for (unsigned round = 0; round < (totFin + BLOCK - 1) / BLOCK; ++round) {
+        const unsigned fi = round * BLOCK + threadIdx.x;
+        const bool fin = fi < totFin;
+        const unsigned fe = fin ? sFin[fi] : 0u;
+        const uint32_t slot = blockIdx.x * SLOT_CHUNKS * BLOCK + (fe & 0x7fffu);
         float myFx = 0, myFy = 0;
         int myZero = 0;
-        // Integrator "spectralpath" (spectralpath.cpp:258-318): nBands paths per camera sample; a finished
-        // path hands its bins to the sample's stitched spectrum and the slot restarts on the same camera ray
-        // with the sampler dimension running on; the last band flushes the stitched spectrum.
         bool restart = false;
         if (fin) {
             int band = 0;
@@ -1351,7 +1411,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             float yy = 0.f;
             bool hasNaN = false;
             float *row = &sL[threadIdx.x * 33];
-            const bool lZero = (flags & F_L_ZERO) != 0;
+            const bool lZero = (fe & 0x8000u) != 0;
             for (int c = 0; c < NQ; ++c) {
                 float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!lZero) v4 = pool.Q(Q_L + c, slot);
@@ -1410,11 +1470,13 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             myZero = zero ? 1 : 0;
             myFx = pool.F(P_FILMX, slot);
             myFy = pool.F(P_FILMY, slot);
-            flags = 0;
         }
-        // (a wave reads only the rows its own lanes staged)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (a wave reads only the rows its own lanes staged, and its LDS accesses complete in order: nothing to wait for, the
+        // fences keep the compiler from moving the accesses -- at workgroup scope each one also waited for every film atomic
+        // in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        STAMP(20);
         {
             const int half = lane >> 5, bin = lane & 31;
             const int filterTableSize = 16;
@@ -1501,22 +1563,9 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the rows are read before the next chunk overwrites them
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the rows are read before the next round overwrites them
         __builtin_amdgcn_wave_barrier();
-        const bool want = valid && (flags & FLAG_MASK) == 0 && !restart;
-        if (want) wantBits |= 1u << ch;
-        if (restart) restartBits |= 1u << ch;
-        if (valid && (flags & F_ALIVE)) contBits |= 1u << ch;
-        const unsigned long long wm = __ballot(want);
-        if (lane == 0) sWant[ch][wave] = (unsigned)__popcll(wm);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {   // exclusive prefix over (chunk, wave) and the block's range of the work list in one add
-        unsigned tot = 0;
-        for (int ch = 0; ch < SLOT_CHUNKS; ++ch)
-            for (int w = 0; w < BLOCK / 64; ++w) { const unsigned n = sWant[ch][w]; sWant[ch][w] = tot; tot += n; }
-        sWorkBase = tot ? atomicAdd(&ctr->nextWork, (unsigned long long)tot) : ~0ull;
-        sTotWant = tot;
+        STAMP(21);
     }
     __syncthreads();
     // ---------------------------------------------------------------- pass 2: refill
@@ -1610,6 +1659,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             sGot[e] = 1;
         } else if (want) pool.I(I_FLAGS, slot) = 0;   // stays free (its finished path has been flushed)
     }
+    STAMP(22);
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < SLOT_CHUNKS; ++ch) {
@@ -1641,6 +1691,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         if (isPrim) pool.extQ[sPrimBase + sPrim[ch][wave] + (unsigned)__popcll(pm & ltMask)] = slot;
         if (isCont) pool.extQ[pool.n - 1 - (sContBase + sCont[ch][wave] + (unsigned)__popcll(cm & ltMask))] = slot;
     }
+    STAMP(23);
     CountAdd(&Stats(ctr).cameraRays, cam);
     CountAdd(&Stats(ctr).badSamples, bad);
 }
@@ -3703,7 +3754,14 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
 #ifdef MIPT_EXP_STAMPS
     {
         unsigned long long tot = 0;
-        for (int k = 0; k < 24; ++k) tot += sub.result.phase[k];
+        for (int k = 0; k < 19; ++k) tot += sub.result.phase[k];
+        {
+            unsigned long long g = 0;
+            for (int k = 19; k < 24; ++k) g += sub.result.phase[k];
+            fprintf(stderr, "k_generate stamps (scan + lists | L read + guards | film rows | refill | extend lists):");
+            for (int k = 19; k < 24; ++k) fprintf(stderr, " %.1f%%", 100.0 * (double)sub.result.phase[k] / (double)std::max(1ull, g));
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "k_shade stamps: %llu waves, %.0f cycles per wave;", sub.result.phaseWaves, (double)tot / (double)std::max(1ull, sub.result.phaseWaves));
         for (int k = 0; k < 19; ++k) fprintf(stderr, " [%d] %.1f%%", k, 100.0 * (double)sub.result.phase[k] / (double)std::max(1ull, tot));
         fprintf(stderr, "\n");
