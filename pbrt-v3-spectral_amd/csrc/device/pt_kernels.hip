@@ -1407,6 +1407,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         if (fin) {
             int band = 0;
             if (nBands > 1) band = pool.I(I_BAND, slot);
+            myFx = pool.F(P_FILMX, slot);   // (asked for with the L line: behind the guards, the film rows waited a round trip of their own)
+            myFy = pool.F(P_FILMY, slot);
             // guards of SamplerIntegrator::Render, integrator.cpp:295-316
             float yy = 0.f;
             bool hasNaN = false;
@@ -1468,8 +1470,6 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                 for (int b = 0; b < MI_NSPEC; ++b) row[b] *= scaleL;
             }
             myZero = zero ? 1 : 0;
-            myFx = pool.F(P_FILMX, slot);
-            myFy = pool.F(P_FILMY, slot);
         }
         // (a wave reads only the rows its own lanes staged, and its LDS accesses complete in order: nothing to wait for, the
         // fences keep the compiler from moving the accesses -- at workgroup scope each one also waited for every film atomic
@@ -1530,7 +1530,11 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
                         else if (!zero) acc += (sL[(waveBase + p) * 33 + bin] * 1.f) * fw;      // contribSum += L * sampleWeight * fw
                     }
                 }
+#ifdef MIPT_EXP_NOFILMATOMIC
+                if (tgt >= 0 && acc == 12345.678f) atomicAdd(film + (size_t)tgt * 32 + bin, acc);   // (timing experiment)
+#else
                 if (tgt >= 0 && acc != 0.f) atomicAdd(film + (size_t)tgt * 32 + bin, acc);   // (x + 0 == x: a black bin is not sent)
+#endif
             }
             // Wider footprints (other filters, samples on a pixel border): one row update per sample and pixel reached.
             unsigned long long mask = __ballot(fin && !restart && myTarget < 0);
