@@ -1788,13 +1788,16 @@ DEV void StoreSpectrumLines(SpectrumTile &t, const Pool &pool, int spectrum, uin
         t.laneOf[wbase + rw] = (unsigned char)lane;
         t.specOf[wbase + rw] = (unsigned char)spectrum;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile and the list are written before they are read
+    // (the exchange stays inside the wave -- rows wbase .. wbase + 63 -- and a wave's LDS accesses complete in order: the
+    // fences only keep the compiler from moving them. At workgroup scope each one was also a wait for every load and store
+    // the wave had in flight, the second one for the line stores just issued)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile and the list are written before they are read
     __builtin_amdgcn_wave_barrier();
     const int ra = __popcll(active & lt), g = ra >> 3, c = ra & 7;
     if (g < nGroups)
         for (int e = g; e < nW; e += nGroups)
             pool.Q((int)t.specOf[wbase + e] + c, (uint32_t)t.slotOf[wbase + e]) = t.q[c][wbase + t.laneOf[wbase + e]];
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... and read before the tile is reused
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // ... and read before the tile is reused
     __builtin_amdgcn_wave_barrier();
 }
 
