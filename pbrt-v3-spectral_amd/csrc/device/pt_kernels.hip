@@ -339,12 +339,14 @@ struct TravSpill {
 struct RayCtx {  // per-lane ray constants
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
     bool n0, n1, n2;
+    bool slow;   // a component of the direction is zero (an infinite reciprocal): only then can a slab product be NaN (BoxTestFast)
     DEV int Octant() const { return (n0 ? 1 : 0) | (n1 ? 2 : 0) | (n2 ? 4 : 0); }
 };
 DEV void InitRayCtx(RayCtx &r, float ox, float oy, float oz, float dx, float dy, float dz) {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = 1.f / dx; r.iy = 1.f / dy; r.iz = 1.f / dz;
     r.n0 = r.ix < 0; r.n1 = r.iy < 0; r.n2 = r.iz < 0;
+    r.slow = !(absf(r.ix) < kInfinity && absf(r.iy) < kInfinity && absf(r.iz) < kInfinity);
 }
 // Bounds3::IntersectP(ray, invDir, dirIsNeg); also returns the final tMin.
 DEV bool BoxTest(const RayCtx &r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tMaxRay, float *tMinOut) {
@@ -366,6 +368,25 @@ DEV bool BoxTest(const RayCtx &r, float mnx, float mny, float mnz, float mxx, fl
     if (tzMax < tMx) tMx = tzMax;
     *tMinOut = tMin;
     return hit && (tMin < tMaxRay) && (tMx > 0);
+}
+
+// The same test for a ray whose reciprocal direction is finite (RayCtx::slow == false). Then no slab product is NaN (a
+// finite difference times a finite factor), and without NaNs the reference's selects and compare-and-assign steps are
+// minima and maxima: the near plane's product is the smaller of the two (rounding is monotone), `if (tyMin > tMin) tMin =
+// tyMin` is a maximum, and the two early-outs together reject exactly the rays whose largest entry exceeds their smallest
+// scaled exit (the x-y test failing implies the x-y-z test failing). Same products, same comparisons, same tMin: 29
+// instructions a box instead of 42 (six selects and four compare-and-select pairs become three v_min, three v_max, one
+// v_max3 and one v_min3). With a zero direction component (0 * inf = NaN when the origin lies in a slab plane) the NaN
+// takes the reference's path through the comparisons, and the wave takes BoxTest.
+DEV bool BoxTestFast(const RayCtx &r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tMaxRay, float *tMinOut) {
+    const float k = 1 + 2 * gammaf(3);
+    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
+    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
+    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
+    const float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tMx = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx) * k, __builtin_fmaxf(ay, by) * k), __builtin_fmaxf(az, bz) * k);
+    *tMinOut = tMin;
+    return (tMin <= tMx) && (tMin < tMaxRay) && (tMx > 0);
 }
 
 // One traversal state machine step set, shared by the persistent kernel and the plain
@@ -409,7 +430,7 @@ DEV void StackPop(TravSpill &sp, int lane, int &n, int *node, int *meta, float *
 // is monotone), and the entry-distance re-validation at pop time is the only tMax-dependent part of the test. So the lane
 // enters the same leaves in the same order against the same tMax as the BVH2 traversal -- closest hits, equal-t ties and
 // the count of primitive tests are unchanged -- with half the dependent node fetches per ray.
-template <int W, bool TMIN = true>
+template <int W, bool TMIN = true, bool FAST = false>
 DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, float tMax, TravSpill &spill, int lane, int &sp,
                   int *tkChild, int *tkMeta, unsigned &nodeCount) {
     if constexpr (W == 2) {
@@ -443,10 +464,18 @@ DEV bool OpenNode(const float4 *__restrict__ wnodes, int cur, const RayCtx &r, f
         const int cnt0 = (int)(c01 & 0xffffu), cnt1 = (int)(c01 >> 16), cnt2 = (int)(c23 & 0xffffu), cnt3 = (int)(c23 >> 16);
         const bool have1 = cnt1 != 0xffff, have2 = cnt2 != 0xffff, have3 = cnt3 != 0xffff;
         float t0, t1 = 0, t2 = 0, t3 = 0;
-        const bool h0 = BoxTest(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tMax, &t0);
-        const bool h1 = have1 && BoxTest(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tMax, &t1);
-        const bool h2 = have2 && BoxTest(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tMax, &t2);
-        const bool h3 = have3 && BoxTest(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tMax, &t3);
+        bool h0, h1, h2, h3;
+        if constexpr (FAST) {   // (every walking lane's reciprocal direction is finite: the caller asked the wave)
+            h0 = BoxTestFast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tMax, &t0);
+            h1 = BoxTestFast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tMax, &t1) && have1;
+            h2 = BoxTestFast(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tMax, &t2) && have2;
+            h3 = BoxTestFast(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tMax, &t3) && have3;
+        } else {
+            h0 = BoxTest(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tMax, &t0);
+            h1 = have1 && BoxTest(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tMax, &t1);
+            h2 = have2 && BoxTest(r, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, tMax, &t2);
+            h3 = have3 && BoxTest(r, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, tMax, &t3);
+        }
         nodeCount += 1u + (have1 ? 1u : 0u) + (have2 ? 1u : 0u) + (have3 ? 1u : 0u);
         const unsigned hm = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
         if (hm == 0u) return false;
@@ -750,7 +779,12 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
             bool needPop = false, got = false, finished = false;
             int tkChild = 0, tkMeta = 0;
             if (walking) {
+#ifdef MIPT_NO_FAST_BOX
                 got = OpenNode<W, !ANY>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
+#else
+                if (__any(r.slow)) got = OpenNode<W, !ANY, false>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
+                else got = OpenNode<W, !ANY, W == 4>(s.wnodes, st.cur, r, tMax, spill, lane, st.sp, &tkChild, &tkMeta, nodeCount);
+#endif
                 needPop = !got;
                 st.cur = -1;
             }

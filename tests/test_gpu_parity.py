@@ -175,6 +175,41 @@ def test_ties_and_near_ties_inside_a_leaf(pt, ob, monkeypatch, env):
     assert (prim >= 0).mean() > .5 and len(np.unique(prim[prim >= 0])) > 100   # (the winners are spread over the copies)
 
 
+def test_axis_parallel_rays_inside_slab_planes(pt, ob):
+    """Bounds3::IntersectP with a zero direction component and the origin IN a slab plane: (plane - o) * invDir = 0 * inf = NaN,
+    and the NaN walks through the reference's comparisons (geometry.h:1420-1447: every test with it is false, so tMin stays
+    NaN and the box is missed at `tMin < ray.tMax`). k_trav's box test for finite reciprocals (BoxTestFast: minima and
+    maxima) must not see such a ray: a wave that holds one takes the select-and-compare test. Axis-parallel rays from
+    integer coordinates through the stacked-sheets scene (quad corners, hence node planes, at integers), shuffled among
+    ordinary rays so that waves mix both kinds: hit records bit-equal to the oracle's."""
+    s = _stacked_sheets_scene(pt)
+    integ = pt.CreatePathIntegrator(s)
+    rng = np.random.default_rng(23)
+    n = 40000
+    o = np.stack([rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), np.where(rng.random(n) < .5, rng.uniform(-2, 4.5, n), rng.uniform(5.5, 9, n))], -1).astype(np.float32)
+    tgt = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), np.full(n, 5.0)], -1).astype(np.float32)
+    d = tgt - o
+    kind = rng.integers(0, 6, n)
+    grid = rng.integers(-3, 4, (n, 3)).astype(np.float32)
+    for k, zero in ((1, [0]), (2, [1]), (3, [0, 1])):   # d.x = 0 / d.y = 0 / both, the origin on an integer plane of that axis
+        m = kind == k
+        for a in zero:
+            d[m, a] = 0.0
+            o[m, a] = grid[m, a]
+    m = kind == 4                                        # in the sheets' own plane: d.z = 0 at z = 5
+    d[m, 2] = 0.0
+    o[m, 2] = 5.0
+    assert (d == 0).any(axis=1).mean() > .5
+    tmax = np.where(rng.random(n) < .7, np.inf, rng.uniform(.5, 12, n)).astype(np.float32)
+    rays = np.concatenate([o, d, tmax[:, None]], axis=1).astype(np.float32)
+    closest, occluded = tc.oracle_answers(ob, s)
+    want = closest(rays)
+    assert np.array_equal(integ.trace(rays).view(np.int32), want.view(np.int32))
+    hits, extra = tc.check_wavefront(integ, rays, closest, occluded)
+    prim = hits.view(np.int32)[:, 0]
+    assert (prim[(d[:, :2] == 0).all(axis=1)] >= 0).any() and (prim < 0).any()
+
+
 def test_killeroo_full_size_low_spp_against_oracle(pt, ob):
     """700x700, 4 spp (the size of BASELINE configs 1-2): counters, weights, film."""
     s = pt.Scene(KILLEROO, spp=4)
