@@ -101,7 +101,7 @@ constexpr int NQ = 8;
 enum : int {
     Q_L = 0,                // radiance gathered by the path
     Q_BETA = NQ,            // throughput
-    Q_LNEE = 2 * NQ,        // pending light-sample contribution (added when the shadow ray is unoccluded)
+    Q_LB = 2 * NQ,          // the second line of the path's radiance (F_L_IN_B, F_CAND)
     Q_LMIS = 3 * NQ,        // pending BSDF-sample (MIS) contribution
     Q_COUNT = 4 * NQ,
     Q_LCA = Q_COUNT         // Integrator "spectralpath" only: the sample's stitched bands
@@ -118,16 +118,21 @@ constexpr int MAX_PEND = 4;
 constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
 // ---- slot flags
 enum : int {
-    F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64, F_B_ADDED = 128,
+    F_ALIVE = 1, F_FINISHED = 2, F_SPECULAR = 4, F_SHADOW = 8, F_MIS = 16, F_NEE = 32, F_A_ADDED = 64,
+    // The path's radiance L has two lines, Q_L and Q_LB, and this bit says which one holds it. A light sample's contribution
+    // used to wait in a line of its own until its shadow ray was resolved, and k_resolve_shadow then read it, read L and
+    // wrote L: 384 B per unoccluded ray in a kernel that does nothing else. Now k_shade writes the CANDIDATE L + contribution
+    // into the line that does not hold L (F_CAND; it has the throughput and the contribution in hand, and L costs it one
+    // more read -- none while L is still empty), and an unoccluded ray flips this bit: the resolve moves no spectrum at all.
+    F_L_IN_B = 128,
     // A new path has L = 0 and beta = 1. Writing those 16 quads into freshly (sparsely) refilled slots cost as
     // much as the rest of k_generate, so they stay implicit until something else is written there:
     F_L_ZERO = 256,     // Q_L holds no value yet; it reads as 0 (0 + x == x)
     F_BETA_ONE = 512,   // Q_BETA holds no value yet; it reads as 1 (1 * x == x)
     F_DIFF = 1024,      // the path ray is still the camera ray: it has ray differentials (RayDifferential::hasDifferentials)
-    // The light sample's contribution of a path whose L is still empty (F_L_ZERO: most first vertices) is written into Q_L
-    // itself instead of Q_LNEE: an unoccluded shadow ray then only clears F_L_ZERO (0 + x == x), an occluded one leaves the
-    // line to read as zero -- k_resolve_shadow moves no spectrum for these. F_NEE_NZ: that contribution has a non-zero bin.
-    F_NEE_IN_L = 2048, F_NEE_NZ = 4096,
+    // F_CAND: the line that does not hold L holds L + the pending light sample's contribution (see F_L_IN_B); the shadow ray
+    // decides. F_NEE_NZ: that contribution has a non-zero bin.
+    F_CAND = 2048, F_NEE_NZ = 4096,
     // The BSDF-sampled (MIS) ray is traced, but it cannot reach the sampled area light (it misses the dilated bounds of the
     // light's shape: Sphere::Pdf gives every direction the cone's pdf, sphere.cpp:294-310, so the estimate goes on for rays
     // that point away from the sphere), so its contribution was neither formed nor stored in Q_LMIS.
@@ -141,6 +146,8 @@ enum : int {
 // need 32 bits: they stay in the I_DIM plane.)
 constexpr int FLAG_BITS = 14, FLAG_MASK = (1 << FLAG_BITS) - 1, BOUNCE_SHIFT = 14, DIM_SHIFT = 22;
 static_assert(F_MIS_DARK < (1 << FLAG_BITS), "slot flags outgrew their field");
+DEV int LPlane(int flags) { return (flags & F_L_IN_B) ? Q_LB : Q_L; }        // the line that holds the path's L
+DEV int LOtherPlane(int flags) { return (flags & F_L_IN_B) ? Q_L : Q_LB; }   // ... and the one for the candidate
 DEV int StateWord(int flags, int bounces, int dim) { return (flags & FLAG_MASK) | ((bounces & 0xff) << BOUNCE_SHIFT) | (int)((unsigned)(dim & 0x3ff) << DIM_SHIFT); }
 DEV int StateBounces(int word) { return (word >> BOUNCE_SHIFT) & 0xff; }
 DEV int StateDim(int word) { return (int)((unsigned)word >> DIM_SHIFT); }
@@ -1154,33 +1161,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
             myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
         }
     }
-    // L += contribution, eight lanes per path: lane (8j + c) of pass `it` adds quad c of entry 8*it + j, so every
-    // load and store of the wave is eight whole 128-B lines
-    const int lane = threadIdx.x & 63;
-    unsigned addedBits = 0;
-    for (int it = 0; it < 8; ++it) {
-        const int src = it * 8 + (lane >> 3);
-        const uint32_t sSlot = (uint32_t)__shfl((int)mySlot, src);
-        const int sAdd = __shfl((doAdd && !(myFlags & F_NEE_IN_L)) ? 1 : 0, src);
-        const int sZero = __shfl((myFlags & F_L_ZERO) ? 1 : 0, src);
-        bool nz = false;
-        if (sAdd) {
-            const int c = lane & 7;
-            const float4 a = pool.Q(Q_LNEE + c, sSlot);
-            nz = (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-            float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!sZero) l = pool.Q(Q_L + c, sSlot);
-            l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-            pool.Q(Q_L + c, sSlot) = l;
-        }
-        const unsigned long long m = __ballot(nz);
-        if ((lane >> 3) == it) addedBits = (unsigned)((m >> (8 * (lane & 7))) & 0xffull);
-    }
+    // L += contribution: the candidate line holds the sum already (F_CAND, written by k_shade), an unoccluded ray makes it the
+    // path's L; an occluded one leaves L where it is
     if (valid) {
         int flags = myFlags;
-        const bool added = (flags & F_NEE_IN_L) ? (doAdd && (flags & F_NEE_NZ)) : (addedBits != 0);
-        if (doAdd) flags &= ~F_L_ZERO;   // (F_NEE_IN_L: Q_L holds the contribution already; occluded: it goes on reading as zero)
-        flags &= ~(F_SHADOW | F_NEE_IN_L | F_NEE_NZ);
+        const bool added = doAdd && (flags & F_NEE_NZ);
+        if (doAdd) flags = (flags ^ F_L_IN_B) & ~F_L_ZERO;
+        flags &= ~(F_SHADOW | F_CAND | F_NEE_NZ);
         if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
         else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
         pool.I(I_FLAGS, mySlot) = flags;
@@ -1220,9 +1207,9 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
             const float4 a = pool.Q(Q_LMIS + c, slot);
             added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
             float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!lZero) l = pool.Q(Q_L + c, slot);
+            if (!lZero) l = pool.Q(LPlane(flags) + c, slot);
             l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-            pool.Q(Q_L + c, slot) = l;
+            pool.Q(LPlane(flags) + c, slot) = l;
         }
         flags &= ~F_L_ZERO;
     }
@@ -1243,16 +1230,16 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
                     const float4 a = pool.Q(Q_LMIS + c, slot);
                     added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
                     float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!lZero) l = pool.Q(Q_L + c, slot);
+                    if (!lZero) l = pool.Q(LPlane(flags) + c, slot);
                     l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-                    pool.Q(Q_L + c, slot) = l;
+                    pool.Q(LPlane(flags) + c, slot) = l;
                 }
                 flags &= ~F_L_ZERO;
             }
         }
     }
     if (!added && !(flags & F_A_ADDED)) ++zero;
-    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_B_ADDED | F_MIS_DARK);
+    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_MIS_DARK);
 }
 template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
@@ -1290,20 +1277,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool,
             const bool occluded = ResolveQuadrics<true, INST, true>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r0.w, r1.x, r1.y), 1 - kShadowEpsilon, &h, false, nodes, tris);
             int flags = pool.I(I_FLAGS, slot);
             bool added = false;
-            if (!occluded && (flags & F_NEE_IN_L)) { added = (flags & F_NEE_NZ) != 0; flags &= ~F_L_ZERO; }
-            else if (!occluded) {   // L += the light sample's contribution (k_resolve_shadow, one lane per path here)
-                const bool lZero = (flags & F_L_ZERO) != 0;
-                for (int c = 0; c < NQ; ++c) {
-                    const float4 a = pool.Q(Q_LNEE + c, slot);
-                    added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
-                    float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!lZero) l = pool.Q(Q_L + c, slot);
-                    l.x += a.x; l.y += a.y; l.z += a.z; l.w += a.w;
-                    pool.Q(Q_L + c, slot) = l;
-                }
-                flags &= ~F_L_ZERO;
-            }
-            flags &= ~(F_SHADOW | F_NEE_IN_L | F_NEE_NZ);
+            if (!occluded) { added = (flags & F_NEE_NZ) != 0; flags = (flags ^ F_L_IN_B) & ~F_L_ZERO; }   // the candidate becomes L (k_resolve_shadow)
+            flags &= ~(F_SHADOW | F_CAND | F_NEE_NZ);
             if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }
             else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
             pool.I(I_FLAGS, slot) = flags;
@@ -1358,7 +1333,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     __shared__ unsigned long long sWorkBase;
     __shared__ unsigned sPrimBase, sContBase, sTotWant, sTotFin;
     __shared__ unsigned sFinCnt[SLOT_CHUNKS][BLOCK / 64];
-    __shared__ unsigned short sFin[SLOT_CHUNKS * BLOCK];   // the block's finished slots: offset in the block | 0x8000 if L reads as zero
+    __shared__ unsigned short sFin[SLOT_CHUNKS * BLOCK];   // the block's finished slots: offset in the block | 0x8000 if L reads as zero | 0x4000 if it lives in Q_LB
+    static_assert(SLOT_CHUNKS * BLOCK <= 0x4000, "sFin: the offset shares its word with two flags");
     sFilter[threadIdx.x] = s.filterTable[threadIdx.x];
     __syncthreads();
     unsigned bad = 0, cam = 0;
@@ -1367,7 +1343,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int nBands = s.nBands;
     unsigned wantBits = 0, restartBits = 0, contBits = 0, gotBits = 0;   // bit ch: state of this thread's slot in chunk ch
-    unsigned finBits = 0, finZeroBits = 0;
+    unsigned finBits = 0, finZeroBits = 0, finInBBits = 0;
 #ifdef MIPT_EXP_STAMPS
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
     const bool stampOn = (blockIdx.x % 61u) == 0u;
@@ -1397,6 +1373,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             const bool want = valid && (fin || (flags & FLAG_MASK) == 0) && !restart;   // (a flushed slot is free)
             if (fin) finBits |= 1u << ch;
             if (fin && (flags & F_L_ZERO)) finZeroBits |= 1u << ch;
+            if (fin && (flags & F_L_IN_B)) finInBBits |= 1u << ch;
             if (want) wantBits |= 1u << ch;
             if (restart) restartBits |= 1u << ch;
             if (valid && !fin && (flags & F_ALIVE)) contBits |= 1u << ch;
@@ -1424,7 +1401,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         const bool fin = (finBits >> ch) & 1u;
         const unsigned long long fm = __ballot(fin);
         if (fin) sFin[sFinCnt[ch][wave] + (unsigned)__popcll(fm & ltMask)] =
-            (unsigned short)((ch * BLOCK + threadIdx.x) | (((finZeroBits >> ch) & 1u) ? 0x8000u : 0u));
+            (unsigned short)((ch * BLOCK + threadIdx.x) | (((finZeroBits >> ch) & 1u) ? 0x8000u : 0u) | (((finInBBits >> ch) & 1u) ? 0x4000u : 0u));
     }
     __syncthreads();
     const unsigned totFin = sTotFin;
@@ -1434,7 +1411,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
         const unsigned fi = round * BLOCK + threadIdx.x;
         const bool fin = fi < totFin;
         const unsigned fe = fin ? sFin[fi] : 0u;
-        const uint32_t slot = blockIdx.x * SLOT_CHUNKS * BLOCK + (fe & 0x7fffu);
+        const uint32_t slot = blockIdx.x * SLOT_CHUNKS * BLOCK + (fe & 0x3fffu);
         float myFx = 0, myFy = 0;
         int myZero = 0;
         bool restart = false;
@@ -1448,9 +1425,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(DScene s, Pool pool, float *
             bool hasNaN = false;
             float *row = &sL[threadIdx.x * 33];
             const bool lZero = (fe & 0x8000u) != 0;
+            const int lPlane = (fe & 0x4000u) ? Q_LB : Q_L;
             for (int c = 0; c < NQ; ++c) {
                 float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!lZero) v4 = pool.Q(Q_L + c, slot);
+                if (!lZero) v4 = pool.Q(lPlane + c, slot);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int b = 4 * c + k;
@@ -1895,6 +1873,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         const int word = pool.I(I_FLAGS, slot);   // flags | bounces | sampler dimension (StateWord)
         const int flags = word & FLAG_MASK;
         bool lZero = (flags & F_L_ZERO) != 0, betaWritten = false;
+        const int lPlane = LPlane(flags);   // the line that holds the path's L
         const bool betaOne = (flags & F_BETA_ONE) != 0;
         const int bounces = StateBounces(word);
         int dimNow = StateDim(word);
@@ -1937,14 +1916,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     for (int c = 0; c < NQ; ++c) {
                         const float4 bt = loadBeta(c);
                         float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!lZero) L4 = pool.Q(Q_L + c, slot);
+                        if (!lZero) L4 = pool.Q(lPlane + c, slot);
                         const float4 Le = LoadSpec4(l.L, c);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int b = 4 * c + k;
                             if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * Get4(Le, k));
                         }
-                        pool.Q(Q_L + c, slot) = L4;
+                        pool.Q(lPlane + c, slot) = L4;
                     }
                     lZero = false;
                 }
@@ -1957,13 +1936,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 for (int c = 0; c < NQ; ++c) {
                     const float4 bt = loadBeta(c);
                     float4 L4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!lZero) L4 = pool.Q(Q_L + c, slot);
+                    if (!lZero) L4 = pool.Q(lPlane + c, slot);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int b = 4 * c + k;
                         if (b < MI_NSPEC) Set4(L4, k, Get4(L4, k) + Get4(bt, k) * IllumBin(s, le, b));
                     }
-                    pool.Q(Q_L + c, slot) = L4;
+                    pool.Q(lPlane + c, slot) = L4;
                 }
                 lZero = false;
             }
@@ -2122,9 +2101,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             if (!delta) { float pf = 1 * lightPdf, pg = 1 * scatteringPdf; weight = (pf * pf) / (pf * pf + pg * pg); }
                             const Divisor lpDiv = MakeDivisor(lightPdf);
                             bool fNonBlack = false, liNonBlack = false, nzAny = false;
+                            // the path's L so far, quad c: the candidate is L + contribution (F_CAND)
+                            auto lBase = [&](int c) -> float4 { return lZero ? make_float4(0.f, 0.f, 0.f, 0.f) : pool.Q(lPlane + c, slot); };
                             auto neeQuad = [&](int c, const float4 &fq, const float4 &Lq) {
-                                const float4 bt = loadBeta(c);
-                                float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+                                const float4 bt = loadBeta(c), l4 = lBase(c);
+                                float4 out = l4;
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const int b = 4 * c + k;
@@ -2137,7 +2118,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         if (!selIsOne) Ld = DivBy(Ld, selDiv);
                                         const float contrib = Get4(bt, k) * Ld;
                                         nzAny |= (contrib != 0.f);
-                                        Set4(out, k, contrib);
+                                        Set4(out, k, Get4(l4, k) + contrib);
                                     }
                                 }
                                 tile.q[c][threadIdx.x] = out;
@@ -2153,7 +2134,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                     constexpr bool EXACT = decltype(exactTag)::value;
                                     DivTrack trk;
                                     trk.Reset(divFast);
-                                    const float4 bt = loadBeta(c);
+                                    const float4 bt = loadBeta(c), l4 = lBase(c);
                                     float4 fq = SimpleEvalQuad<NL, TM, EXACT>(sl, bx, c, trk), Lq = LiQuad<TM>(s, light, ls, c);
                                     if (c == NQ - 1) { fq.w = 0.f; Lq.w = 0.f; }   // bin 31 does not exist
                                     unsigned aF = 0u, aLi = 0u, aNz = 0u;
@@ -2174,7 +2155,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                         OrNonZero(aNz, o[k]);
                                     }
                                     if (!EXACT && __any(trk.Bad())) return false;
-                                    tile.q[c][threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
+                                    tile.q[c][threadIdx.x] = make_float4(l4.x + o[0], l4.y + o[1], l4.z + o[2], l4.w + o[3]);
                                     accF |= aF; accLi |= aLi; accNz |= aNz;
                                     return true;
                                 };
@@ -2186,12 +2167,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
 #pragma unroll 1
                                 for (int c = 0; c < EXP_NQ; ++c) neeQuad(c, fQuad(c), LiQuad<TM>(s, light, ls, c));
                             }
-                            // only a contribution whose shadow ray will be traced is ever read; into Q_L itself while the
-                            // path's L is still empty (F_NEE_IN_L)
+                            // the tile holds L + contribution, the candidate (F_CAND): only one whose shadow ray will be traced
+                            // is ever read
                             const bool traced = fNonBlack && liNonBlack;
         STAMP(8);
-                            StoreSpectrumLines(tile, pool, lZero ? Q_L : Q_LNEE, slot, EXP_STORE(traced));
-                            if (traced && lZero) newFlags |= F_NEE_IN_L | (nzAny ? F_NEE_NZ : 0);
+                            StoreSpectrumLines(tile, pool, LOtherPlane(flags), slot, EXP_STORE(traced));
+                            if (traced) newFlags |= F_CAND | (nzAny ? F_NEE_NZ : 0);
                             if (traced) {  // the shadow ray is traced iff f != 0 (integrator.cpp:138-150)
                                 Ray sr = SpawnRayTo(isect, ls.pLight);
                                 pool.R(R_SH0, slot) = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.d.x);
@@ -2482,11 +2463,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             if (finished) {
                 // ReportValue(pathLength, bounces): `bounces` at the break of path.cpp's loop
                 pathLen = (unsigned)bounces;
-                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_NEE_IN_L | F_NEE_NZ | F_MIS_DARK)) | F_FINISHED;
+                newFlags = (newFlags & (F_NEE | F_SHADOW | F_MIS | F_CAND | F_NEE_NZ | F_MIS_DARK)) | F_FINISHED;
             } else {
                 newFlags |= F_ALIVE;
             }
             if (lZero) newFlags |= F_L_ZERO;
+            newFlags |= flags & F_L_IN_B;
             if (betaOne && !betaWritten) newFlags |= F_BETA_ONE;
             wantShadow = (newFlags & F_SHADOW) != 0;
             wantMis = (newFlags & F_MIS) != 0;
@@ -2681,7 +2663,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene s, const float *rays, ui
 // ------------------------------------------------------------------ recorded rays through the render's own kernels (mi_pt_trace_wavefront)
 // Loads ray i into slot i of the pool exactly as k_generate / k_shade leave a path ray (mode 0), an NEE shadow ray (1) or a
 // BSDF-sampled MIS ray (2), and lists it in that mode's work list. The shadow mode's flags make k_resolve_shadow's commit
-// readable without a spectrum: the light sample "already sits in L" (F_NEE_IN_L), so an unoccluded ray only clears F_L_ZERO.
+// readable without a spectrum: the candidate line "holds L + the light sample" (F_CAND), so an unoccluded ray flips F_L_IN_B and clears F_L_ZERO.
 __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ctr, const float *rays, uint32_t n, int mode) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) {
@@ -2702,7 +2684,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
             pool.R(mode == 1 ? R_SH0 : R_MI0, i) = make_float4(r[0], r[1], r[2], r[3]);
             pool.R(mode == 1 ? R_SH1 : R_MI1, i) = make_float4(r[4], r[5], 0.f, 0.f);
             (mode == 1 ? pool.shadowQ : pool.misQ)[i] = i;
-            flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_NEE_IN_L | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
+            flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_CAND | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
         }
         pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
         pool.I(I_NPEND, i) = 0;
@@ -4041,7 +4023,7 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         r[16] = ray1[0]; r[17] = ray1[1]; r[18] = ray1[2]; r[19] = ray1[3];
         if (fl & F_BETA_ONE) for (int k = 0; k < 31; ++k) r[20 + k] = 1.f;
         else HIPCHK(Spec(Q_BETA, slot, r + 20));
-        if (!(fl & F_L_ZERO)) HIPCHK(Spec(Q_L, slot, r + 51));
+        if (!(fl & F_L_ZERO)) HIPCHK(Spec((fl & F_L_IN_B) ? Q_LB : Q_L, slot, r + 51));
         ++*n_records;
     }
     FreePool(sub.pool);   // the next render sizes its own
