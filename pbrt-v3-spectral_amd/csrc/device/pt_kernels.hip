@@ -2483,9 +2483,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
     BlockReserve2(&ctr->shadowCount.v, wantShadow, &ctr->misCount.v, wantMis, sAppend, &posS, &posM);
     if (wantShadow) pool.shadowQ[posS] = slot;
     if (wantMis) pool.misQ[posM] = slot;
-    CountAdd(&Stats(ctr).totalPaths, totalPaths);
-    CountAdd(&Stats(ctr).pathLengthSum, pathLen);
-    CountAdd(&Stats(ctr).zeroRadiancePaths, zeroNow);
+    {   // the three statistics of a wave in one reduction: per lane at most one path, one black estimate and 255 bounces
+        unsigned packed = totalPaths | (zeroNow << 8) | (pathLen << 16);
+        for (int off = 32; off > 0; off >>= 1) packed += __shfl_down(packed, off, 64);
+        if ((threadIdx.x & 63) == 0 && packed) {
+            DevStats &st8 = Stats(ctr);
+            if (packed & 0xffu) atomicAdd(&st8.totalPaths, (unsigned long long)(packed & 0xffu));
+            if ((packed >> 8) & 0xffu) atomicAdd(&st8.zeroRadiancePaths, (unsigned long long)((packed >> 8) & 0xffu));
+            if (packed >> 16) atomicAdd(&st8.pathLengthSum, (unsigned long long)(packed >> 16));
+        }
+    }
     STAMP(18);
 #ifdef MIPT_EXP_STAMPS
     if (stampOn && (threadIdx.x & 63) == 0) atomicAdd(&ctr->phaseWaves, 1ull);
