@@ -194,7 +194,7 @@ def main():
     # the concurrent streams overlap, so these are lower bounds of what each class reaches alone.
     other_rays = max(1, acc["regular_rays"] + acc["shadow_rays"] - acc["extend_rays"])
     other_bytes = 32.0 * (acc["bvh_nodes_visited"] - acc["extend_nodes"]) + 48.0 * (acc["tri_tests"] - acc["extend_tri_tests"]) \
-        + (64.0 + 248.0) * other_rays
+        + (64.0 + 24.0) * other_rays   # (until round 3: + 248 B, when k_resolve_shadow still moved the light sample's spectrum: DESIGN 4)
     vertices = max(1, acc["total_paths"])
 
     def _cls(nbytes, secs):
@@ -202,7 +202,7 @@ def main():
         return {"achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "unit": "GB/s", "seconds": round(secs, 4)}
     roofline["classes"] = {
         "extend (k_trav<0> + k_resolve_extend)": _cls(b_ray * ext_rays, t_kernel[2]),
-        "shadow + mis (k_trav<1,2> + resolves), B_ray + 248 B": _cls(other_bytes, t_kernel[4] + t_kernel[5]),
+        "shadow + mis (k_trav<1,2> + resolves), B_ray + 24 B": _cls(other_bytes, t_kernel[4] + t_kernel[5]),
         "shade (k_shade), 0.96 KB/vertex": _cls(960.0 * vertices, t_kernel[3]),
         "generate (k_generate), 408 B/sample": _cls(408.0 * acc["camera_rays"], t_kernel[1]),
     }
