@@ -179,7 +179,10 @@ struct Pool {
     float4 *q;   // spectral quad planes
     float4 *r;   // record planes
     int *i;
-    uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays
+    uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays. shadowQ[n + k]: the any-hit
+                               // traversal's answer for entry k (bit 31: occluded; below it the count of postponed quadrics |
+                               // PEND_OVERFLOW) -- in queue order, so k_resolve_shadow reads it as whole lines where the
+                               // hit words of the slot planes cost it a sector each
     uint32_t *extQ;            // this iteration's path rays: new camera rays from the front (coherent: consecutive
                                // samples of a pixel), continuing paths from the back
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
@@ -698,6 +701,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
     bool has = false;
     uint32_t slot = 0;
+    unsigned myEntry = 0;   // MODE 1: the ray's place in the shadow queue (its answer goes to shadowQ[n + myEntry])
     RayCtx r;
     InitRayCtx(r, 0, 0, 0, 1, 1, 1);
     float tMax = 0;
@@ -738,6 +742,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                     if (my < chunkEnd) {
                         if (MODE == 0) slot = queue[(my < nPrim) ? my : pool.n - nCont + (my - nPrim)];
                         else slot = queue[my];
+                        if (MODE == 1) myEntry = my;
                         {
                             const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
                             const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
@@ -752,6 +757,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                             curInst = hitInst = -1; hitInCur = false;
                             ++rayCount;
                             if (st.cur >= 0) has = true;
+                            else if (MODE == 1) pool.shadowQ[pool.n + myEntry] = 0u;   // nothing to traverse: unoccluded
                             else {  // the ray misses the world bound: nothing to traverse
                                 pool.I(I_HITPRIM, slot) = -1;
                                 pool.I(I_NPEND, slot) = 0;
@@ -965,6 +971,11 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                 if (tkMeta > 0) { leafOff = tkChild; leafCnt = tkMeta & LEAF_COUNT_MASK; leafSimple = (tkMeta & LEAF_SIMPLE) != 0; }
                 else st.cur = tkChild;
             }
+            if (finished && MODE == 1) {
+                pool.shadowQ[pool.n + myEntry] = (hitPrim >= 0 ? 0x80000000u : 0u) | (unsigned)nPend;
+                has = false;
+                leafCnt = 0;
+            } else
             if (finished) {
                 pool.I(I_HITPRIM, slot) = hitPrim;
                 pool.I(I_NPEND, slot) = nPend;
@@ -1002,8 +1013,8 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
 // them 40-56 VGPRs and all but 650 of 12 000 instructions): they hand a ray whose list overflowed to that kernel.
 template <bool ANY, bool INST, bool OVF = false>
 DEV bool ResolveQuadrics(const DScene &s, const Pool &pool, uint32_t slot, const V3 &ro, const V3 &rd, float tMaxIn,
-                         Hit *h, bool foundTri, unsigned &nodes, unsigned &tris) {
-    const int np = pool.I(I_NPEND, slot);
+                         Hit *h, bool foundTri, unsigned &nodes, unsigned &tris, int npGiven = -1) {
+    const int np = npGiven >= 0 ? npGiven : pool.I(I_NPEND, slot);
     if constexpr (OVF) {
         Hit h2;
         h2.prim = -1; h2.t = 0; h2.b0 = h2.b1 = h2.b2 = 0;
@@ -1148,15 +1159,16 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
     if (qi < ctr->shadowCount.v) {
         const uint32_t slot = pool.shadowQ[qi];
         int flags = pool.I(I_FLAGS, slot);
-        bool occluded = pool.I(I_HITPRIM, slot) >= 0;
-        const int npend = occluded ? 0 : pool.I(I_NPEND, slot);
+        const unsigned verdict = pool.shadowQ[pool.n + qi];   // k_trav<1>'s answer, in queue order
+        bool occluded = (verdict >> 31) != 0u;
+        const int npend = occluded ? 0 : (int)(verdict & 0x7fffffffu);
         if (npend & PEND_OVERFLOW) pool.ovfQ[(size_t)pool.n + atomicAdd(&ctr->ovfCount[1].v, 1u)] = slot;   // k_resolve_overflow commits this one
         else {
             if (npend != 0) {
                 const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
                 V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
                 Hit h;
-                occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris);
+                occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris, npend);
             }
             myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
         }
@@ -2694,6 +2706,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
             flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_CAND | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
         }
         pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
+        if (mode == 1) pool.shadowQ[pool.n + i] = 0xfffffffeu;   // (... a shadow ray's answer lies beside its queue entry)
         pool.I(I_NPEND, i) = 0;
         pool.I(I_HITINST, i) = -1;
         pool.I(I_MISLIGHT, i) = 0;
@@ -2701,9 +2714,15 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
     pool.I(I_FLAGS, i) = flags;
 }
 // what k_trav left in the planes, before the resolve step
-__global__ void __launch_bounds__(BLOCK) k_trace_raw(Pool pool, uint32_t n, float *extra) {
+__global__ void __launch_bounds__(BLOCK) k_trace_raw(Pool pool, uint32_t n, int mode, float *extra) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (mode == 1) {   // the answer word: -2 = never answered; else bit 31 occluded | postponed quadrics
+        const unsigned v = pool.shadowQ[pool.n + i];
+        extra[4 * (size_t)i + 2] = __int_as_float(v == 0xfffffffeu ? 0 : (int)(v & 0x7fffffffu));
+        extra[4 * (size_t)i + 3] = __int_as_float(v == 0xfffffffeu ? -2 : ((v >> 31) ? 0 : -1));
+        return;
+    }
     extra[4 * (size_t)i + 2] = __int_as_float(pool.I(I_NPEND, i));
     extra[4 * (size_t)i + 3] = __int_as_float(pool.I(I_HITPRIM, i));
 }
@@ -2845,7 +2864,7 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
 // Device bytes of one path slot: planes, records, spectra and its entries in the queues.
 size_t PoolSlotBytes(int nQuadPlanes) {
     return (size_t)P_COUNT * sizeof(float) + (size_t)nQuadPlanes * sizeof(float4) + (size_t)R_COUNT * sizeof(float4) + (size_t)I_COUNT * sizeof(int) +
-           (size_t)(3 + MAX_CLASSES + 3) * sizeof(uint32_t);
+           (size_t)(4 + MAX_CLASSES + 3) * sizeof(uint32_t);
 }
 
 void FreePool(Pool &p) {
@@ -2866,7 +2885,7 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
                     hipMalloc((void **)&t.q, (size_t)nQuadPlanes * n * sizeof(float4)) == hipSuccess &&
                     hipMalloc((void **)&t.r, (size_t)R_COUNT * n * sizeof(float4)) == hipSuccess &&
                     hipMalloc((void **)&t.i, (size_t)I_COUNT * n * sizeof(int)) == hipSuccess &&
-                    hipMalloc((void **)&t.shadowQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.shadowQ, (size_t)2 * n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.extQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.misQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)) == hipSuccess &&
@@ -4106,7 +4125,7 @@ int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, fl
     const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
     hipLaunchKernelGGL(k_trace_load, grid, block, 0, st, sub.pool, sub.ctr, dr.as<float>(), n, mode);
     LaunchTraversal(pt, sub, mode, travGrid);
-    hipLaunchKernelGGL(k_trace_raw, grid, block, 0, st, sub.pool, n, dx.as<float>());
+    hipLaunchKernelGGL(k_trace_raw, grid, block, 0, st, sub.pool, n, mode, dx.as<float>());
     const bool inst = pt->hasInstances;
 #define MIPT_BY_INST(K, G, ...) do { if (inst) hipLaunchKernelGGL((K<true>), G, block, 0, st, __VA_ARGS__); else hipLaunchKernelGGL((K<false>), G, block, 0, st, __VA_ARGS__); } while (0)
     if (mode == 0) MIPT_BY_INST(k_resolve_extend, chunkGrid, s, sub.pool, sub.ctr);
