@@ -182,7 +182,9 @@ struct Pool {
     uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays. shadowQ[n + k]: the any-hit
                                // traversal's answer for entry k (bit 31: occluded; below it the count of postponed quadrics |
                                // PEND_OVERFLOW) -- in queue order, so k_resolve_shadow reads it as whole lines where the
-                               // hit words of the slot planes cost it a sector each
+                               // hit words of the slot planes cost it a sector each. misQ[n + 2k], [n + 2k + 1]: hit
+                               // primitive and postponed quadrics of MIS ray k, likewise (its t and barycentrics, which
+                               // k_resolve_mis rarely needs, stay in the slot's R_HIT)
     uint32_t *extQ;            // this iteration's path rays: new camera rays from the front (coherent: consecutive
                                // samples of a pixel), continuing paths from the back
     uint32_t *shadeQ;          // slots to shade: MAX_CLASSES queues of n entries, one per shading class
@@ -701,7 +703,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
     bool has = false;
     uint32_t slot = 0;
-    unsigned myEntry = 0;   // MODE 1: the ray's place in the shadow queue (its answer goes to shadowQ[n + myEntry])
+    unsigned myEntry = 0;   // MODE 1, 2: the ray's place in its queue (the answer goes beside the queue: shadowQ[n + myEntry], misQ[n + 2 myEntry])
     RayCtx r;
     InitRayCtx(r, 0, 0, 0, 1, 1, 1);
     float tMax = 0;
@@ -742,7 +744,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                     if (my < chunkEnd) {
                         if (MODE == 0) slot = queue[(my < nPrim) ? my : pool.n - nCont + (my - nPrim)];
                         else slot = queue[my];
-                        if (MODE == 1) myEntry = my;
+                        if (MODE != 0) myEntry = my;
                         {
                             const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
                             const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
@@ -758,7 +760,10 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                             ++rayCount;
                             if (st.cur >= 0) has = true;
                             else if (MODE == 1) pool.shadowQ[pool.n + myEntry] = 0u;   // nothing to traverse: unoccluded
-                            else {  // the ray misses the world bound: nothing to traverse
+                            else if (MODE == 2) {
+                                *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2(0xffffffffu, 0u);
+                                pool.R(R_HIT, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            } else {  // the ray misses the world bound: nothing to traverse
                                 pool.I(I_HITPRIM, slot) = -1;
                                 pool.I(I_NPEND, slot) = 0;
                                 if (INST && MODE == 0) pool.I(I_HITINST, slot) = -1;
@@ -973,6 +978,12 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
             }
             if (finished && MODE == 1) {
                 pool.shadowQ[pool.n + myEntry] = (hitPrim >= 0 ? 0x80000000u : 0u) | (unsigned)nPend;
+                has = false;
+                leafCnt = 0;
+            } else
+            if (finished && MODE == 2) {
+                *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2((unsigned)hitPrim, (unsigned)nPend);
+                pool.R(R_HIT, slot) = make_float4(hitT, hitB0, hitB1, hitB2);
                 has = false;
                 leafCnt = 0;
             } else
@@ -1191,14 +1202,14 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, D
 // One MIS ray's commit. OVF = false (k_resolve_mis): a ray whose quadric list overflowed goes to k_resolve_overflow, which
 // runs this again with OVF = true.
 template <bool INST, bool OVF>
-DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, unsigned &zero) {
+DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, int hitPrim, int npend, unsigned &zero) {
     unsigned nodes = 0, tris = 0;
     int flags = pool.I(I_FLAGS, slot);
     // the ray and the hit record are fetched only by the few rays that need them: postponed quadrics, or a hit on the
     // sampled light whose facing has to be tested (most MIS rays hit something else: 48 B of scattered reads saved)
     V3 ro, rd;
     Hit h;
-    h.prim = pool.I(I_HITPRIM, slot); h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
+    h.prim = hitPrim; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f;
     bool haveRay = false;
     auto loadRay = [&]() {
         if (haveRay) return;
@@ -1208,9 +1219,8 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
         haveRay = true;
     };
     bool found = h.prim >= 0;
-    const int npend = pool.I(I_NPEND, slot);
     if (!OVF && (npend & PEND_OVERFLOW)) { pool.ovfQ[2 * (size_t)pool.n + atomicAdd(&ctr->ovfCount[2].v, 1u)] = slot; return; }
-    if (npend != 0) { loadRay(); found = ResolveQuadrics<false, INST, OVF>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris); }
+    if (npend != 0) { loadRay(); found = ResolveQuadrics<false, INST, OVF>(s, pool, slot, ro, rd, kInfinity, &h, found, nodes, tris, npend); }
     bool added = false;
     const int misLight = s.nLights > 1 ? pool.I(I_MISLIGHT, slot) : 0;
     if (!found && s.lights[misLight].type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray), integrator.cpp:204
@@ -1257,7 +1267,10 @@ template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0;
-    if (qi < ctr->misCount.v) ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], zero);
+    if (qi < ctr->misCount.v) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(pool.misQ + pool.n + 2 * (size_t)qi);   // k_trav<2>'s answer, in queue order
+        ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], (int)v.x, (int)v.y, zero);
+    }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
 
@@ -1295,7 +1308,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool,
             else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
             pool.I(I_FLAGS, slot) = flags;
         } else
-            ResolveMisSlot<INST, true>(s, pool, ctr, slot, zero);
+            ResolveMisSlot<INST, true>(s, pool, ctr, slot, -1, PEND_OVERFLOW, zero);   // (re-traversed from scratch)
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
@@ -2706,7 +2719,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
             flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_CAND | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
         }
         pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
-        if (mode == 1) pool.shadowQ[pool.n + i] = 0xfffffffeu;   // (... a shadow ray's answer lies beside its queue entry)
+        if (mode == 1) pool.shadowQ[pool.n + i] = 0xfffffffeu;   // (... a shadow or MIS ray's answer lies beside its queue entry)
+        if (mode == 2) { pool.misQ[pool.n + 2 * (size_t)i] = 0xfffffffeu; pool.misQ[pool.n + 2 * (size_t)i + 1] = 0u; }
         pool.I(I_NPEND, i) = 0;
         pool.I(I_HITINST, i) = -1;
         pool.I(I_MISLIGHT, i) = 0;
@@ -2723,6 +2737,11 @@ __global__ void __launch_bounds__(BLOCK) k_trace_raw(Pool pool, uint32_t n, int 
         extra[4 * (size_t)i + 3] = __int_as_float(v == 0xfffffffeu ? -2 : ((v >> 31) ? 0 : -1));
         return;
     }
+    if (mode == 2) {
+        extra[4 * (size_t)i + 2] = __int_as_float((int)pool.misQ[pool.n + 2 * (size_t)i + 1]);
+        extra[4 * (size_t)i + 3] = __int_as_float((int)pool.misQ[pool.n + 2 * (size_t)i]);
+        return;
+    }
     extra[4 * (size_t)i + 2] = __int_as_float(pool.I(I_NPEND, i));
     extra[4 * (size_t)i + 3] = __int_as_float(pool.I(I_HITPRIM, i));
 }
@@ -2733,7 +2752,7 @@ template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_trace_read(DScene s, Pool pool, uint32_t n, int mode, float *hits, float *extra) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    int prim = pool.I(I_HITPRIM, i), inst = -1;
+    int prim = mode == 2 ? (int)pool.misQ[pool.n + 2 * (size_t)i] : pool.I(I_HITPRIM, i), inst = -1;
     float4 hr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode == 0) { hr = pool.R(R_HIT, i); if (INST) inst = pool.I(I_HITINST, i); }
     else if (mode == 1) prim = (pool.I(I_FLAGS, i) & F_L_ZERO) ? 0 : -1;
@@ -2745,9 +2764,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_read(DScene s, Pool pool, uint3
         h.prim = prim; h.t = hr.x; h.b0 = hr.y; h.b1 = hr.z; h.b2 = hr.w;
         bool found = prim >= 0;
         unsigned nodes = 0, tris = 0;
-        const int npend = pool.I(I_NPEND, i);
+        const int npend = (int)pool.misQ[pool.n + 2 * (size_t)i + 1];
         if (npend & PEND_OVERFLOW) found = ResolveQuadrics<false, INST, true>(s, pool, i, ro, rd, kInfinity, &h, found, nodes, tris);
-        else if (npend != 0) found = ResolveQuadrics<false, INST, false>(s, pool, i, ro, rd, kInfinity, &h, found, nodes, tris);
+        else if (npend != 0) found = ResolveQuadrics<false, INST, false>(s, pool, i, ro, rd, kInfinity, &h, found, nodes, tris, npend);
         prim = found ? h.prim : -1;
         hr = make_float4(h.t, h.b0, h.b1, h.b2);
         inst = h.inst;
@@ -2864,7 +2883,7 @@ int Upload(mi_pt *pt, const T *src, size_t count, const T **dst) {
 // Device bytes of one path slot: planes, records, spectra and its entries in the queues.
 size_t PoolSlotBytes(int nQuadPlanes) {
     return (size_t)P_COUNT * sizeof(float) + (size_t)nQuadPlanes * sizeof(float4) + (size_t)R_COUNT * sizeof(float4) + (size_t)I_COUNT * sizeof(int) +
-           (size_t)(4 + MAX_CLASSES + 3) * sizeof(uint32_t);
+           (size_t)(6 + MAX_CLASSES + 3) * sizeof(uint32_t);
 }
 
 void FreePool(Pool &p) {
@@ -2887,7 +2906,7 @@ int EnsurePool(SubRenderer &sub, uint32_t n, int nQuadPlanes) {
                     hipMalloc((void **)&t.i, (size_t)I_COUNT * n * sizeof(int)) == hipSuccess &&
                     hipMalloc((void **)&t.shadowQ, (size_t)2 * n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.extQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
-                    hipMalloc((void **)&t.misQ, (size_t)n * sizeof(uint32_t)) == hipSuccess &&
+                    hipMalloc((void **)&t.misQ, (size_t)3 * n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.shadeQ, (size_t)MAX_CLASSES * n * sizeof(uint32_t)) == hipSuccess &&
                     hipMalloc((void **)&t.ovfQ, (size_t)3 * n * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
