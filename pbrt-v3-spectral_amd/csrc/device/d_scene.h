@@ -421,6 +421,11 @@ DEV Ray XfRay(const float *m, const Ray &r) {
 
 // ------------------------------------------------------------------ spheres
 // Root selection shared by Sphere::Intersect / IntersectP (sphere.cpp:49-112,158-214).
+// WANT_POINT = false (SphereHitT: only t is asked for): a sphere that is not clipped -- zMin <= -radius, zMax >= radius and
+// phiMax >= 2 pi AS FLOATS, so that `phi > phiMax` cannot hold for any phi that atan2 + 2 pi can produce -- passes the clipping
+// tests of sphere.cpp:91-110 whatever the hit point is, so the point, its re-projection (a square root and a division) and
+// phi (atan2) are not formed: a third of the function.
+template <bool WANT_POINT>
 __device__ __attribute__((noinline)) bool SphereRoots(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMaxIn, V3 *rayObjD, V3 *pHitOut, float *phiOut, float *tOut) {
     V3 oErr, dErr;
     V3 o = XfPointErr(s.w2o, ro, &oErr);
@@ -447,6 +452,9 @@ __device__ __attribute__((noinline)) bool SphereRoots(const mi_sphere &s, const 
         if (tShapeHit.high > rayTMax) return false;
     }
     const float radius = s.radius, zMin = s.z_min, zMax = s.z_max, phiMax = s.phi_max;
+    if constexpr (!WANT_POINT) {
+        if (!(zMin > -radius) && !(zMax < radius) && phiMax >= 2 * kPi) { *tOut = tShapeHit.v; return true; }
+    }
     V3 pHit = o + d * tShapeHit.v;
     pHit *= radius / Distance(pHit, V3(0, 0, 0));
     if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
@@ -468,13 +476,13 @@ __device__ __attribute__((noinline)) bool SphereRoots(const mi_sphere &s, const 
 }
 DEV bool SphereHitT(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMax, float *t) {
     V3 dObj, pHit; float phi;
-    return SphereRoots(s, ro, rd, tMax, &dObj, &pHit, &phi, t);
+    return SphereRoots<false>(s, ro, rd, tMax, &dObj, &pHit, &phi, t);
 }
 // Full Sphere::Intersect interaction (sphere.cpp:113-155 + transform.cpp:255-288); the
 // ray must be the one that produced the hit (tMax = value before the hit was recorded).
 DEV bool SphereInteraction(const mi_sphere &s, const V3 &ro, const V3 &rd, float tMax, SurfaceInteraction *si, float *tHit) {
     V3 dObj, pHit; float phi, t;
-    if (!SphereRoots(s, ro, rd, tMax, &dObj, &pHit, &phi, &t)) return false;
+    if (!SphereRoots<true>(s, ro, rd, tMax, &dObj, &pHit, &phi, &t)) return false;
     const float radius = s.radius, phiMax = s.phi_max, thetaMin = s.theta_min, thetaMax = s.theta_max;
     float theta = acosF(clampf(pHit.z / radius, -1, 1));
     float zRadius = __builtin_sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);

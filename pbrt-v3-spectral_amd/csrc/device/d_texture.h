@@ -259,7 +259,7 @@ DEV bool AlphaPass(const DScene &s, int tri, float b0, float b1, float b2, bool 
 // and the Weingarten dndu / dndv, taken to world space as Transform::operator()(SurfaceInteraction) does.
 DEV bool SphereTexCoords(const mi_sphere &sp, const V3 &ro, const V3 &rd, float *u, float *v, TriShading *ts) {
     V3 dObj, pHit; float phi, t;
-    if (!SphereRoots(sp, ro, rd, kInfinity, &dObj, &pHit, &phi, &t)) return false;
+    if (!SphereRoots<true>(sp, ro, rd, kInfinity, &dObj, &pHit, &phi, &t)) return false;
     const float radius = sp.radius, phiMax = sp.phi_max, thetaMin = sp.theta_min, thetaMax = sp.theta_max;
     *u = phi / phiMax;
     float theta = acosF(clampf(pHit.z / radius, -1, 1));
