@@ -117,7 +117,7 @@ def _device_trace(pt):
 
 def _device_trace_wavefront(pt):
     """Every ray query answered by the kernels a render launches (mi_pt_trace_wavefront): closest hits by k_trav<0> +
-    k_resolve_extend; occlusion by k_trav<1> + k_resolve_nee when the rays are NEE shadow rays (tMax = 1 - ShadowEpsilon,
+    k_resolve_extend; occlusion by k_trav<1> + k_resolve_shadow when the rays are NEE shadow rays (tMax = 1 - ShadowEpsilon,
     what SpawnRayTo makes), otherwise -- any other tMax -- as "k_trav<0> found a closest hit"."""
     import trace_check as tc
 
