@@ -114,7 +114,6 @@ enum : int { I_HITPRIM = 0, I_PIXEL, I_SAMPLE, I_IDXLO, I_IDXHI, I_DIM /* pixel 
              I_BAND,                                       // spectralpath: band (path number) of the camera sample
              I_HITINST,                                    // instance the hit primitive was reached through, -1 = none (scenes with instances)
              I_COUNT };
-constexpr uint32_t NEE_HAS_SHADOW = 0x80000000u, NEE_HAS_MIS = 0x40000000u, NEE_SLOT_MASK = 0x3fffffffu;   // (pools stay below 2^30 slots)
 constexpr int MAX_PEND = 4;
 constexpr int PEND_OVERFLOW = 0x100;  // more quadrics met than MAX_PEND: the resolve kernel re-traverses
 // ---- slot flags
@@ -180,10 +179,7 @@ struct Pool {
     float4 *q;   // spectral quad planes
     float4 *r;   // record planes
     int *i;
-    // ONE queue for the rays of the direct-lighting estimates: entry k = slot | NEE_HAS_SHADOW | NEE_HAS_MIS (a vertex's light
-    // sample and BSDF sample ride together: k_shade appends once, both traversals walk the same list -- a lane whose entry
-    // has no ray of its kind draws the next one -- and ONE resolve kernel reads and writes the state word once for both).
-    uint32_t *shadowQ, *misQ;  // shadowQ[k]: the entries (misQ[0..n) is unused). shadowQ[n + k]: the any-hit
+    uint32_t *shadowQ, *misQ;  // compacted slot indices of this iteration's shadow / MIS rays. shadowQ[n + k]: the any-hit
                                // traversal's answer for entry k (bit 31: occluded; below it the count of postponed quadrics |
                                // PEND_OVERFLOW) -- in queue order, so k_resolve_shadow reads it as whole lines where the
                                // hit words of the slot planes cost it a sector each. misQ[n + 2k], [n + 2k + 1]: hit
@@ -700,8 +696,8 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
     const unsigned nPrim = (MODE == 0) ? ctr->primCount.v : 0, nCont = (MODE == 0) ? ctr->contCount.v : 0;
-    const unsigned total = (MODE == 0) ? nPrim + nCont : ctr->shadowCount.v;   // (modes 1 and 2: the one direct-lighting queue)
-    const uint32_t *__restrict__ queue = (MODE == 0) ? pool.extQ : pool.shadowQ;
+    const unsigned total = (MODE == 0) ? nPrim + nCont : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
+    const uint32_t *__restrict__ queue = (MODE == 0) ? pool.extQ : ((MODE == 1) ? pool.shadowQ : pool.misQ);
     const unsigned travChunk = (total >= (1u << 23)) ? 2u * (unsigned)TRAV_CHUNK : (unsigned)TRAV_CHUNK;
     const float4 *__restrict__ primTri = s.primTri;
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
@@ -748,13 +744,8 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                     if (my < chunkEnd) {
                         if (MODE == 0) slot = queue[(my < nPrim) ? my : pool.n - nCont + (my - nPrim)];
                         else slot = queue[my];
-                        bool mine = true;
-                        if (MODE != 0) {   // the entry may hold no ray of this launch's kind: the lane stays idle and draws again
-                            myEntry = my;
-                            mine = (slot & (MODE == 1 ? NEE_HAS_SHADOW : NEE_HAS_MIS)) != 0u;
-                            slot &= NEE_SLOT_MASK;
-                        }
-                        if (mine) {
+                        if (MODE != 0) myEntry = my;
+                        {
                             const float4 r0 = pool.R((MODE == 0) ? R_RAY0 : ((MODE == 1) ? R_SH0 : R_MI0), slot);
                             const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
                             if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
@@ -1169,23 +1160,51 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_extend(DScene s, Pool pool, D
     }
 }
 
-// What a resolved NEE shadow ray does to its path's state word (integrator.cpp:138-150: `Ld += f * Li / lightPdf` if
-// unoccluded): the candidate line holds L + contribution already (F_CAND, written by k_shade), an unoccluded ray makes it
-// the path's L; an occluded one leaves L where it is. `zero` counts the direct-lighting estimates that end black.
-DEV int ShadowCommit(int flags, bool occluded, unsigned &zero) {
-    const bool added = !occluded && (flags & F_NEE_NZ);
-    if (!occluded) flags = (flags ^ F_L_IN_B) & ~F_L_ZERO;
-    flags &= ~(F_SHADOW | F_CAND | F_NEE_NZ);
-    if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // the MIS ray's commit closes the estimate
-    else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
-    return flags;
+template <bool INST>
+__global__ void __launch_bounds__(BLOCK) k_resolve_shadow(DScene s, Pool pool, DevCounters *ctr) {
+    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned zero = 0, nodes = 0, tris = 0;
+    int myFlags = 0;
+    uint32_t mySlot = 0;
+    bool valid = false, doAdd = false;
+    if (qi < ctr->shadowCount.v) {
+        const uint32_t slot = pool.shadowQ[qi];
+        int flags = pool.I(I_FLAGS, slot);
+        const unsigned verdict = pool.shadowQ[pool.n + qi];   // k_trav<1>'s answer, in queue order
+        bool occluded = (verdict >> 31) != 0u;
+        const int npend = occluded ? 0 : (int)(verdict & 0x7fffffffu);
+        if (npend & PEND_OVERFLOW) pool.ovfQ[(size_t)pool.n + atomicAdd(&ctr->ovfCount[1].v, 1u)] = slot;   // k_resolve_overflow commits this one
+        else {
+            if (npend != 0) {
+                const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
+                V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+                Hit h;
+                occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris, npend);
+            }
+            myFlags = flags; mySlot = slot; valid = true; doAdd = !occluded;
+        }
+    }
+    // L += contribution: the candidate line holds the sum already (F_CAND, written by k_shade), an unoccluded ray makes it the
+    // path's L; an occluded one leaves L where it is
+    if (valid) {
+        int flags = myFlags;
+        const bool added = doAdd && (flags & F_NEE_NZ);
+        if (doAdd) flags = (flags ^ F_L_IN_B) & ~F_L_ZERO;
+        flags &= ~(F_SHADOW | F_CAND | F_NEE_NZ);
+        if (flags & F_MIS) { if (added) flags |= F_A_ADDED; }   // k_resolve_mis closes the estimate
+        else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
+        pool.I(I_FLAGS, mySlot) = flags;
+    }
+    CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
 
-// One MIS ray's commit, on the caller's copy of the state word. OVF = false (k_resolve_nee): a ray whose quadric list
-// overflowed goes to k_resolve_overflow -- the state word is left as it is --, which runs this again with OVF = true.
+
+// One MIS ray's commit. OVF = false (k_resolve_mis): a ray whose quadric list overflowed goes to k_resolve_overflow, which
+// runs this again with OVF = true.
 template <bool INST, bool OVF>
-DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, int hitPrim, int npend, int &flags, unsigned &zero) {
+DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, int hitPrim, int npend, unsigned &zero) {
     unsigned nodes = 0, tris = 0;
+    int flags = pool.I(I_FLAGS, slot);
     // the ray and the hit record are fetched only by the few rays that need them: postponed quadrics, or a hit on the
     // sampled light whose facing has to be tested (most MIS rays hit something else: 48 B of scattered reads saved)
     V3 ro, rd;
@@ -1242,67 +1261,15 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
         }
     }
     if (!added && !(flags & F_A_ADDED)) ++zero;
-    flags &= ~(F_NEE | F_MIS | F_A_ADDED | F_MIS_DARK);
+    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_MIS_DARK);
 }
-// Scenes with quadrics, between the two traversals: the shadow rays' postponed quadrics are tested here, because the MIS
-// traversal of the same slot reuses the list planes (I_PEND*); the answer word becomes final (occluded or not, no list).
-// A ray whose list overflowed keeps its mark: k_resolve_overflow re-traverses it from the ray alone.
 template <bool INST>
-__global__ void __launch_bounds__(BLOCK) k_shadow_quadrics(DScene s, Pool pool, DevCounters *ctr) {
+__global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
-    if (qi >= ctr->shadowCount.v) return;
-    const uint32_t entry = pool.shadowQ[qi];
-    if (!(entry & NEE_HAS_SHADOW)) return;
-    const unsigned verdict = pool.shadowQ[pool.n + qi];
-    const int npend = (int)(verdict & 0x7fffffffu);
-    if ((verdict >> 31) || npend == 0 || (npend & PEND_OVERFLOW)) return;
-    const uint32_t slot = entry & NEE_SLOT_MASK;
-    const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
-    unsigned nodes = 0, tris = 0;
-    Hit h;
-    const bool occluded = ResolveQuadrics<true, INST>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r0.w, r1.x, r1.y), 1 - kShadowEpsilon, &h, false, nodes, tris, npend);
-    pool.shadowQ[pool.n + qi] = occluded ? 0x80000000u : 0u;
-}
-
-// The commit of a vertex's direct-lighting estimate: its shadow ray's, then its MIS ray's (integrator.cpp:138-213), one queue
-// entry per vertex, the state word read once and written once for both (two kernels, each with its own scattered read and
-// write of the word, until the end of round 3). The answers of the two traversals lie beside the queue, in queue order.
-template <bool INST>
-__global__ void __launch_bounds__(BLOCK) k_resolve_nee(DScene s, Pool pool, DevCounters *ctr) {
-    const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
-    unsigned zero = 0, nodes = 0, tris = 0;
-    if (qi < ctr->shadowCount.v) {
-        const uint32_t entry = pool.shadowQ[qi];
-        const uint32_t slot = entry & NEE_SLOT_MASK;
-        int flags = pool.I(I_FLAGS, slot);
-        bool shadowDeferred = false;
-        if (entry & NEE_HAS_SHADOW) {
-            const unsigned verdict = pool.shadowQ[pool.n + qi];   // k_trav<1>'s answer
-            bool occluded = (verdict >> 31) != 0u;
-            const int npend = occluded ? 0 : (int)(verdict & 0x7fffffffu);
-            if (npend & PEND_OVERFLOW) {   // k_resolve_overflow commits this one
-                pool.ovfQ[(size_t)pool.n + atomicAdd(&ctr->ovfCount[1].v, 1u)] = slot;
-                shadowDeferred = true;
-            } else {
-                if (npend != 0) {
-                    const float4 r0 = pool.R(R_SH0, slot), r1 = pool.R(R_SH1, slot);
-                    V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
-                    Hit h;
-                    occluded = ResolveQuadrics<true, INST>(s, pool, slot, ro, rd, 1 - kShadowEpsilon, &h, false, nodes, tris, npend);
-                }
-                flags = ShadowCommit(flags, occluded, zero);
-            }
-        }
-        if (entry & NEE_HAS_MIS) {
-            // (the MIS commit reads what the shadow commit left: behind a deferred shadow ray it is deferred too --
-            // k_resolve_overflow runs the shadow rays first and re-traverses this one)
-            if (shadowDeferred) pool.ovfQ[2 * (size_t)pool.n + atomicAdd(&ctr->ovfCount[2].v, 1u)] = slot;
-            else {
-                const uint2 v = *reinterpret_cast<const uint2 *>(pool.misQ + pool.n + 2 * (size_t)qi);   // k_trav<2>'s answer
-                ResolveMisSlot<INST, false>(s, pool, ctr, slot, (int)v.x, (int)v.y, flags, zero);
-            }
-        }
-        if (!shadowDeferred) pool.I(I_FLAGS, slot) = flags;
+    unsigned zero = 0;
+    if (qi < ctr->misCount.v) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(pool.misQ + pool.n + 2 * (size_t)qi);   // k_trav<2>'s answer, in queue order
+        ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], (int)v.x, (int)v.y, zero);
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
@@ -1341,11 +1308,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_overflow(DScene s, Pool pool,
             else { if (!added) ++zero; flags &= ~(F_NEE | F_A_ADDED); }
             pool.I(I_FLAGS, slot) = flags;
         } else
-        {
-            int flags = pool.I(I_FLAGS, slot);
-            ResolveMisSlot<INST, true>(s, pool, ctr, slot, -1, PEND_OVERFLOW, flags, zero);   // (re-traversed from scratch)
-            pool.I(I_FLAGS, slot) = flags;
-        }
+            ResolveMisSlot<INST, true>(s, pool, ctr, slot, -1, PEND_OVERFLOW, zero);   // (re-traversed from scratch)
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
@@ -2540,10 +2503,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
         }
     }
     STAMP(17);
-    __shared__ unsigned sAppend[5];
-    const bool wantNee = wantShadow || wantMis;
-    const unsigned posN = BlockReserve(&ctr->shadowCount.v, wantNee, sAppend);
-    if (wantNee) pool.shadowQ[posN] = slot | (wantShadow ? NEE_HAS_SHADOW : 0u) | (wantMis ? NEE_HAS_MIS : 0u);
+    __shared__ unsigned sAppend[10];
+    unsigned posS, posM;
+    BlockReserve2(&ctr->shadowCount.v, wantShadow, &ctr->misCount.v, wantMis, sAppend, &posS, &posM);
+    if (wantShadow) pool.shadowQ[posS] = slot;
+    if (wantMis) pool.misQ[posM] = slot;
     {   // the three statistics of a wave in one reduction: per lane at most one path, one black estimate and 255 bounces
         unsigned packed = totalPaths | (zeroNow << 8) | (pathLen << 16);
         for (int off = 32; off > 0; off >>= 1) packed += __shfl_down(packed, off, 64);
@@ -2737,7 +2701,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
     if (i == 0) {
         if (mode == 0) { ctr->primCount.v = n; ctr->contCount.v = 0; }
         else if (mode == 1) ctr->shadowCount.v = n;
-        else ctr->shadowCount.v = n;   // (modes 1 and 2: the one direct-lighting queue)
+        else ctr->misCount.v = n;
     }
     if (i >= pool.n) return;
     int flags = 0;
@@ -2751,7 +2715,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
         } else {
             pool.R(mode == 1 ? R_SH0 : R_MI0, i) = make_float4(r[0], r[1], r[2], r[3]);
             pool.R(mode == 1 ? R_SH1 : R_MI1, i) = make_float4(r[4], r[5], 0.f, 0.f);
-            pool.shadowQ[i] = i | (mode == 1 ? NEE_HAS_SHADOW : NEE_HAS_MIS);
+            (mode == 1 ? pool.shadowQ : pool.misQ)[i] = i;
             flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_CAND | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
         }
         pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
@@ -3633,7 +3597,7 @@ static void SortQueueExperiment(mi_pt *pt, SubRenderer &sub, int mode) {
     unsigned cnt[2] = {0, 0};
     uint32_t *queue;
     if (mode == 0) { hipMemcpyAsync(&cnt[0], &sub.ctr->contCount.v, 4, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); queue = sub.pool.extQ + (sub.pool.n - cnt[0]); }
-    else { hipMemcpyAsync(&cnt[0], &sub.ctr->shadowCount.v, 4, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); queue = sub.pool.shadowQ; }
+    else { hipMemcpyAsync(&cnt[0], mode == 1 ? &sub.ctr->shadowCount.v : &sub.ctr->misCount.v, 4, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); queue = mode == 1 ? sub.pool.shadowQ : sub.pool.misQ; }
     const unsigned n = cnt[0];
     if (n < 2) return;
     hipLaunchKernelGGL(k_sort_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, pt->scene, sub.pool, queue, n, mode, keys);
@@ -3833,18 +3797,17 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         SortQueueExperiment(pt, sub, 1);
 #endif
         LaunchTraversal(pt, sub, 1, travGrid);
-        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_shadow_quadrics<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
-            else hipLaunchKernelGGL((k_shadow_quadrics<false>), grid, block, 0, st, s, sub.pool, sub.ctr); }
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
+            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
         HIPCHK(hipEventRecord(ev[4], st));
 #ifdef MIPT_SORT_EXPERIMENT
         SortQueueExperiment(pt, sub, 2);
 #endif
         LaunchTraversal(pt, sub, 2, travGrid);
-        // the commit of both rays of each direct-lighting estimate, then the rays whose quadric lists overflowed (shadow rays first)
-        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_nee<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_resolve_nee<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
-        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
-            else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipEventRecord(ev[5], st));
@@ -4085,14 +4048,13 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         r[8] = ray1[0]; r[9] = ray1[1]; r[10] = ray1[2]; r[11] = ray1[3];
         LaunchShade(pt, sub, grid);
         LaunchTraversal(pt, sub, 1, travGrid);
-        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_shadow_quadrics<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
-            else hipLaunchKernelGGL((k_shadow_quadrics<false>), grid, block, 0, st, s, sub.pool, sub.ctr); }
-        LaunchTraversal(pt, sub, 2, travGrid);
-        // the commit of both rays of each direct-lighting estimate, then the rays whose quadric lists overflowed (shadow rays first)
-        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_nee<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
-        else hipLaunchKernelGGL((k_resolve_nee<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_shadow<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_shadow<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 1); }
+        LaunchTraversal(pt, sub, 2, travGrid);
+        if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
+        else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
         if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipStreamSynchronize(st));
@@ -4186,7 +4148,7 @@ int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, fl
     const bool inst = pt->hasInstances;
 #define MIPT_BY_INST(K, G, ...) do { if (inst) hipLaunchKernelGGL((K<true>), G, block, 0, st, __VA_ARGS__); else hipLaunchKernelGGL((K<false>), G, block, 0, st, __VA_ARGS__); } while (0)
     if (mode == 0) MIPT_BY_INST(k_resolve_extend, chunkGrid, s, sub.pool, sub.ctr);
-    else if (mode == 1) MIPT_BY_INST(k_resolve_nee, grid, s, sub.pool, sub.ctr);
+    else if (mode == 1) MIPT_BY_INST(k_resolve_shadow, grid, s, sub.pool, sub.ctr);
     if (mode != 2 && pt->hasQuadrics) MIPT_BY_INST(k_resolve_overflow, dim3(OVERFLOW_GRID), s, sub.pool, sub.ctr, mode);
     MIPT_BY_INST(k_trace_read, grid, s, sub.pool, n, mode, dh.as<float>(), dx.as<float>());
 #undef MIPT_BY_INST
