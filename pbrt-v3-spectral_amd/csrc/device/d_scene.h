@@ -438,6 +438,23 @@ __device__ __attribute__((noinline)) bool SphereRoots(const mi_sphere &s, const 
         }
     }
     const float rayTMax = tMaxIn;
+    {   // The misses that need no error bounds. An EFloat's value is the plain float result of the same operations, and its
+        // interval contains it: a negative discriminant (efloat.h:275), a nearer root whose VALUE lies beyond tMax
+        // (t0.UpperBound() >= t0) and a farther root whose value is <= 0 (t1.LowerBound() <= t1) are sphere.cpp:77's misses
+        // whatever the bounds are. A shadow ray towards a sphere light ends ShadowEpsilon short of the sampled point, so its
+        // nearer root is ~1 against tMax = 0.9999: every NEE shadow ray of the killeroo and Cornell frames leaves here,
+        // after ~40 instructions instead of the ~700 of the interval arithmetic.
+        const float av = d.x * d.x + d.y * d.y + d.z * d.z;
+        const float bv = 2.f * (d.x * o.x + d.y * o.y + d.z * o.z);
+        const float cv = o.x * o.x + o.y * o.y + o.z * o.z - s.radius * s.radius;
+        const double discrim = (double)bv * (double)bv - 4. * (double)av * (double)cv;
+        if (discrim < 0.) return false;
+        const float frd = (float)__builtin_sqrt(discrim);
+        const float qv = (bv < 0) ? -.5f * (bv - frd) : -.5f * (bv + frd);
+        float t0v = qv / av, t1v = cv / qv;
+        if (t0v > t1v) { const float tmp = t0v; t0v = t1v; t1v = tmp; }
+        if (t0v > rayTMax || t1v <= 0) return false;   // (a NaN compares false and goes on to the intervals)
+    }
     EFloat ox(o.x, oErr.x), oy(o.y, oErr.y), oz(o.z, oErr.z);
     EFloat dx(d.x, dErr.x), dy(d.y, dErr.y), dz(d.z, dErr.z);
     EFloat a = dx * dx + dy * dy + dz * dz;
