@@ -2096,8 +2096,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     // -- values are a pure function of (index, dimension) -- their digit loops run side by side
                     float u5[5];
                     if constexpr (FUSED_HALTON) { ScrambledDimensionsFused<5>(s.primes, s.primeSums, s.perms, s.primeMagic, ps.index, ps.dim, u5); ps.dim += 1; }
-                    else if (HALTON_ONLY && s.nLights == 1) { u5[0] = 0.f; ++ps.dim; }   // (one light: Distribution1D::SampleDiscrete returns it for every u; the
-                                                                                         // dimension is consumed, its radical inverse -- a pure function -- not formed)
                     else u5[0] = Get1D<HALTON_ONLY>(s, ps, pixelPlane, samplePlane, slot);
                     const int lightNum = SampleDiscrete(s.ldFunc + (size_t)di * s.nLights, s.ldCdf + (size_t)di * (s.nLights + 1),
                                                         s.ldFuncInt[di], (int)s.nLights, u5[0], &selPdf);
