@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define MI_NSPEC 31
-#define MI_ABI_VERSION 9
+#define MI_ABI_VERSION 10
 #define MI_MAX_BXDFS 8 /* BSDF::MaxBxDFs, src/core/reflection.h:196 */
 
 typedef enum mi_status {
@@ -151,7 +151,21 @@ typedef struct mi_bxdf {
 typedef enum mi_lobe_rule {
     MI_LOBE_IF_R = 0,      /* present iff the lobe's R (after the multiplier) is not black */
     MI_LOBE_IF_R_OR_S = 1, /* present iff R or S is not black (FresnelSpecular glass.cpp:70-72,78-80; FresnelBlend substrate.cpp:53) */
-    MI_LOBE_IF_TEX = 2     /* present iff the texture value itself is not black (translucent.cpp:59-60,68-69) */
+    MI_LOBE_IF_TEX = 2,    /* present iff the texture value itself is not black (translucent.cpp:59-60,68-69) */
+    /* ABI v10 -- "disney" with an image-textured "color" (disney.cpp:485-587). The material adds its lobes whatever the colour
+     * is, and three of their spectra are not linear in it. With c = the texture value (clamped), lum = c.y() and
+     * Ctint = lum > 0 ? c / lum : 1 (per bin), the lobe's textured channel is:
+     *   MI_LOBE_ALWAYS          R = c (or the constant R times c with MI_LOBE_TEX_MUL_R): the diffuse, retro, fake-subsurface and
+     *                           diffuse-transmission lobes, whose weights are the constant
+     *   MI_LOBE_DISNEY_SHEEN    R = Lerp(p[7], 1, Ctint) * p[6]            (Csheen * (diffuseWeight * sheenWeight))
+     *   MI_LOBE_DISNEY_SPEC     R = c, S = Lerp(p[2], Lerp(p[6], 1, Ctint) * p[7], c)   (Cspec0; p[2] = metallic, p[6] = specularTint,
+     *                           p[7] = SchlickR0FromEta(eta)) -- the microfacet lobe with the Disney Fresnel term
+     *   MI_LOBE_DISNEY_STRANS   R = sqrt(c) * p[6]                          (strans * Sqrt(c))
+     * where Lerp(t, a, b) = a * (1 - t) + b * t as Spectrum arithmetic does it (spectrum.h:577-580). */
+    MI_LOBE_ALWAYS = 3,
+    MI_LOBE_DISNEY_SHEEN = 4,
+    MI_LOBE_DISNEY_SPEC = 5,
+    MI_LOBE_DISNEY_STRANS = 6
 } mi_lobe_rule;
 typedef struct mi_lobe_tex {
     int32_t tex_R, tex_S; /* index into mi_scene_desc.textures, -1 = the constant in mi_bxdf */

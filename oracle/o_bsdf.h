@@ -11,6 +11,14 @@
 
 namespace orc {
 
+inline Float SpecY(const mi_scene_desc &d, const Spec &s) {  // SampledSpectrum::y(), spectrum.h:415-421
+    Float yy = 0.f;
+    for (int i = 0; i < NS; ++i) yy += d.cie_y[i] * s.c[i];
+    yy = (yy < 0) ? 0 : yy;
+    return yy * Float(705 - 395) / Float(106.856895f * NS);
+}
+
+
 // ---- local-frame trig, reflection.h:50-89
 inline Float CosTheta(const V3 &w) { return w.z; }
 inline Float Cos2Theta(const V3 &w) { return w.z * w.z; }
@@ -496,8 +504,20 @@ struct BSDF {
                     bx.texS = true;
                     bx.Stex = (lt.flags & MI_LOBE_TEX_MUL_S) ? Spec::From(bx.b->S) * T : T;
                 }
+                // "disney" with an image-textured colour (disney.cpp:485-587; mi_lobe_rule): the lobes are added whatever the
+                // colour is, three of their spectra are not linear in it
+                if (lt.rule >= MI_LOBE_DISNEY_SHEEN && lt.rule <= MI_LOBE_DISNEY_STRANS) {
+                    const Spec c = EvalImageTexture(*d, lt.tex_R, si, *td);
+                    const Float lum = SpecY(*d, c);
+                    const Spec Ctint = lum > 0 ? (c / lum) : Spec(1.);
+                    const Float *p = bx.b->p;
+                    if (lt.rule == MI_LOBE_DISNEY_SHEEN) bx.Rtex = p[6] * Lerp(p[7], Spec(1.), Ctint);
+                    else if (lt.rule == MI_LOBE_DISNEY_SPEC) { bx.Rtex = c; bx.texS = true; bx.Stex = Lerp(p[2], p[7] * Lerp(p[6], Spec(1.), Ctint), c); }
+                    else bx.Rtex = p[6] * Sqrt(c);
+                }
                 bool present;
-                if (lt.rule == MI_LOBE_IF_R_OR_S) present = !bx.R().IsBlack() || !bx.S().IsBlack();
+                if (lt.rule >= MI_LOBE_ALWAYS) present = true;
+                else if (lt.rule == MI_LOBE_IF_R_OR_S) present = !bx.R().IsBlack() || !bx.S().IsBlack();
                 else if (lt.rule == MI_LOBE_IF_TEX) present = !texBlack;
                 else present = !bx.R().IsBlack();
                 if (!present) continue;

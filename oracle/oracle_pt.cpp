@@ -507,12 +507,6 @@ struct Scene {
 };
 
 // ------------------------------------------------------------------ lights
-inline Float SpecY(const mi_scene_desc &d, const Spec &s) {  // SampledSpectrum::y(), spectrum.h:415-421
-    Float yy = 0.f;
-    for (int i = 0; i < NS; ++i) yy += d.cie_y[i] * s.c[i];
-    yy = (yy < 0) ? 0 : yy;
-    return yy * Float(705 - 395) / Float(106.856895f * NS);
-}
 
 struct LightSample {
     Spec Li;

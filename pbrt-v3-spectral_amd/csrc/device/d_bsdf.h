@@ -226,6 +226,8 @@ DEV IllumRGB MakeIllumRGB(const float rgb[3]) {
 template <int NL>
 struct LobeTexT {
     unsigned hasR, hasS, mulR, mulS;
+    unsigned rules;   // mi_lobe_rule of lobe i at bits 4i..4i+3 (the "disney" rules derive a lobe's spectrum from the colour)
+    float lum;        // "disney" with a textured colour: c.y() of the colour at this vertex
     IllumRGB r[NL], s[NL];
     const float *basis;     // rgbIllum2Spect{White..Blue}, [7][31]: FromRGB's default type is Illuminant (spectrum.h:428-429)
     const mi_texture *textures;   // for checkerboard values (i1 < 0: i2 = texture, w0 = weight of its spec2)
@@ -243,12 +245,25 @@ DEV float TexBin(const float *basis, const mi_texture *textures, const IllumRGB 
     r *= .86445f;
     return clampf(r, 0.f, kInfinity);
 }
+// "disney" with an image-textured colour (disney.cpp:485-587; mi_lobe_rule in mi_pt.h): the channel of a lobe whose spectrum is
+// not linear in the colour, from the colour's bin c and luminance lum. Spectrum arithmetic's order: Lerp(t, a, b) = a * (1 - t)
+// + b * t (spectrum.h:577-580), Float * Spectrum = the bin times the float.
+DEV float DisneyTexBin(int rule, int which, const float *p, float c, float lum) {
+    const float ctint = lum > 0 ? c / lum : 1.f;                                  // Ctint = lum > 0 ? c / lum : Spectrum(1.)
+    if (rule == MI_LOBE_DISNEY_SHEEN) return ((1 - p[7]) + ctint * p[7]) * p[6];  // Lerp(sheenTint, 1, Ctint) * (diffuseWeight * sheenWeight)
+    if (rule == MI_LOBE_DISNEY_STRANS) return __builtin_sqrtf(c) * p[6];          // Sqrt(c) * strans
+    if (which == 0) return c;                                                      // MI_LOBE_DISNEY_SPEC: R = c,
+    const float x = ((1 - p[6]) + ctint * p[6]) * p[7];                            //   S = Lerp(metallic, Lerp(specTint, 1, Ctint) * R0, c)
+    return x * (1 - p[2]) + c * p[2];
+}
 // R (which = 0) or S (which = 1) of material lobe li at a bin, with the texture applied
 template <int NL>
 DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int bin) {
     const float c = which ? b.S[bin] : b.R[bin];
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return c;
     const float T = TexBin(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], bin);
+    const int rule = (int)((lt.rules >> (4 * li)) & 15u);
+    if (rule >= MI_LOBE_DISNEY_SHEEN) return DisneyTexBin(rule, which, b.p, T, lt.lum);
     return (((which ? lt.mulS : lt.mulR) >> li) & 1u) ? c * T : T;
 }
 
@@ -632,6 +647,10 @@ DEV float4 TexturedQuad(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int wh
     const float4 k = LoadSpec4(which ? b.S : b.R, c);
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return k;
     const float4 T = TexQuad(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], c);
+    const int rule = (int)((lt.rules >> (4 * li)) & 15u);
+    if (rule >= MI_LOBE_DISNEY_SHEEN)
+        return make_float4(DisneyTexBin(rule, which, b.p, T.x, lt.lum), DisneyTexBin(rule, which, b.p, T.y, lt.lum),
+                           DisneyTexBin(rule, which, b.p, T.z, lt.lum), DisneyTexBin(rule, which, b.p, T.w, lt.lum));
     if (((which ? lt.mulS : lt.mulR) >> li) & 1u) return make_float4(k.x * T.x, k.y * T.y, k.z * T.z, k.w * T.w);
     return T;
 }

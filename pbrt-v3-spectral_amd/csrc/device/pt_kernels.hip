@@ -1993,6 +1993,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 // Material::ComputeScatteringFunctions with image textures: evaluate them at the hit, keep the lobes
                 // whose tested spectrum is not black (matte.cpp:55-63, plastic.cpp:52-68, uber.cpp:60-100, ...)
                 lt.hasR = lt.hasS = lt.mulR = lt.mulS = 0u;
+                lt.rules = 0u; lt.lum = 0.f;
                 lt.basis = s.rgbIllum; lt.textures = s.textures;
                 ltp = &lt;
                 float u = 0.f, v = 0.f;
@@ -2052,6 +2053,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             lt.s[i] = EvalImageTexture(s, ltx.tex_S, u, v, td);
                             lt.hasS |= 1u << i;
                             if (ltx.flags & MI_LOBE_TEX_MUL_S) lt.mulS |= 1u << i;
+                        }
+                        lt.rules |= (unsigned)(ltx.rule & 15) << (4 * i);
+                        if (ltx.rule >= MI_LOBE_ALWAYS) {   // "disney": lobes are added whatever the colour is
+                            if (ltx.rule >= MI_LOBE_DISNEY_SHEEN && lt.lum == 0.f) {   // lum = c.y(), once per vertex (every lobe has the same colour)
+                                float yy = 0.f;
+                                for (int b = 0; b < MI_NSPEC; ++b) yy += SpecYBinAccum(s, b, TexBin(lt.basis, lt.textures, lt.r[i], b));
+                                lt.lum = YScale(yy);
+                            }
+                            mask |= 1u << i;
+                            continue;
                         }
                         // (the spectrum the material tests with IsBlack(), a quad of bins at a time; only what the lobe's rule reads)
                         unsigned rNZ = 0u, sNZ = 0u, texNZ = 0u;

@@ -302,7 +302,12 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     }
     if (type == "disney") {  // src/materials/disney.cpp:474-587,589-624
         m->kind = 4;
-        Spectrum c = mp.GetSpectrum("color", Spectrum(0.5f)).Clamp();
+        // (an image-textured "color": the lobes keep their weights as constants -- c = 1 below -- and take the colour at
+        // the hit, each by its rule: mi_lobe_rule, MI_LOBE_ALWAYS ... MI_LOBE_DISNEY_STRANS)
+        const SpectrumParam pc = mp.GetSpectrumParam("color", Spectrum(0.5f));
+        const int ctex = pc.tex;
+        if (ctex >= 0 && pc.scaled) { errs->push_back("disney \"color\" bound to a `scale` of an image texture is outside the hot-path scope"); return false; }
+        Spectrum c = ctex >= 0 ? Spectrum(1.f) : pc.s.Clamp();
         float metallicWeight = mp.GetFloat("metallic", 0.f);
         float e = mp.GetFloat("eta", 1.5f);
         float rough = mp.GetFloat("roughness", .5f);
@@ -328,13 +333,16 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         if (diffuseWeight > 0) {
             if (thin) {
                 Add(m, MakeBxDF(MI_BXDF_DISNEY_DIFFUSE, diffFlags, diffuseWeight * (1 - flat) * (1 - dt) * c), errs);
+                Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
                 mi_bxdf ss = MakeBxDF(MI_BXDF_DISNEY_FAKE_SS, diffFlags, diffuseWeight * flat * (1 - dt) * c);
                 ss.p[0] = rough;
                 Add(m, ss, errs);
+                Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
             } else {
-                if (sd.IsBlack())
+                if (sd.IsBlack()) {
                     Add(m, MakeBxDF(MI_BXDF_DISNEY_DIFFUSE, diffFlags, diffuseWeight * c), errs);
-                else {
+                    Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
+                } else {
                     errs->push_back("disney \"scatterdistance\" (BSSRDF) is outside the hot-path scope (SURVEY 2 row 6)");
                     return false;
                 }
@@ -342,8 +350,13 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             mi_bxdf retro = MakeBxDF(MI_BXDF_DISNEY_RETRO, diffFlags, diffuseWeight * c);
             retro.p[0] = rough;
             Add(m, retro, errs);
-            if (sheenWeight > 0)
-                Add(m, MakeBxDF(MI_BXDF_DISNEY_SHEEN, diffFlags, diffuseWeight * sheenWeight * Csheen), errs);
+            Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
+            if (sheenWeight > 0) {
+                mi_bxdf sh = MakeBxDF(MI_BXDF_DISNEY_SHEEN, diffFlags, diffuseWeight * sheenWeight * Csheen);
+                sh.p[6] = diffuseWeight * sheenWeight; sh.p[7] = stint;
+                Add(m, sh, errs);
+                Bind(m, ctex, false, -1, false, MI_LOBE_DISNEY_SHEEN);
+            }
         }
         // "1 - anisotropic * .9" is evaluated in double, then sqrt(double) -> Float
         float aspect = (float)std::sqrt(1 - (double)anisotropic * .9);
@@ -356,7 +369,9 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             b.fresnel = MI_FRESNEL_DISNEY;
             SetS(b, Cspec0);
             b.p[0] = ax; b.p[1] = ay; b.p[2] = metallicWeight; b.p[3] = e; b.p[5] = 1.f;
+            b.p[6] = specTint; b.p[7] = r0;
             Add(m, b, errs);
+            Bind(m, ctex, false, ctex, false, MI_LOBE_DISNEY_SPEC);
         }
         if (cc > 0) {
             mi_bxdf b = MakeBxDF(MI_BXDF_DISNEY_CLEARCOAT, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, Spectrum(0.f));
@@ -367,16 +382,22 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         }
         if (strans > 0) {
             Spectrum T = strans * Sqrt(c);
+            mi_bxdf tb;
             if (thin) {
                 float rscaled = (0.65f * e - 0.35f) * rough;
                 float ax2 = std::max(float(.001), sqr(rscaled) / aspect);
                 float ay2 = std::max(float(.001), sqr(rscaled) * aspect);
-                Add(m, MicrofacetTransmission(T, ax2, ay2, 1.f, e, false), errs);
+                tb = MicrofacetTransmission(T, ax2, ay2, 1.f, e, false);
             } else
-                Add(m, MicrofacetTransmission(T, ax, ay, 1.f, e, true), errs);
+                tb = MicrofacetTransmission(T, ax, ay, 1.f, e, true);
+            tb.p[6] = strans;
+            Add(m, tb, errs);
+            Bind(m, ctex, false, -1, false, MI_LOBE_DISNEY_STRANS);
         }
-        if (thin)
+        if (thin) {
             Add(m, MakeBxDF(MI_BXDF_LAMBERTIAN_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_DIFFUSE, dt * c), errs);
+            Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
+        }
         return errs->empty() || m->n_bxdfs <= MI_MAX_BXDFS;
     }
     errs->push_back("material \"" + type + "\" is outside the PathIntegrator hot-path scope (SURVEY 2 row 18)");

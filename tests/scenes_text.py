@@ -591,6 +591,64 @@ def roughness_scene(res=64, spp=16, depth=4, lens=False):
                                   lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
 
 
+DISNEY_TEXTURED_SCENE = """
+LookAt 0 2.2 -7  0 0.6 0  0 1 0
+Camera "perspective" "float fov" [42] %(lens)s
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [16 15 13]
+  Translate 0 5 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.5 0 -1.5  1.5 0 -1.5  1.5 0 1.5  -1.5 0 1.5]
+AttributeEnd
+LightSource "point" "rgb I" [10 10 12] "point from" [-3 3 -4]
+Texture "ewa_png" "spectrum" "imagemap" "string filename" "tex_a.png" "float uscale" [4] "float vscale" [4]
+Texture "tri_tga" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"] "float udelta" [.25]
+Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string wrap" "clamp" "float uscale" [2] "float vscale" [2]
+Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2]
+# ground: every diffuse-side lobe (diffuse, retro, sheen) and the specular lobe take the colour from the map
+AttributeBegin
+  Material "disney" "texture color" "ewa_png" "float roughness" [.4] "float sheen" [.7] "float sheentint" [.3] "float speculartint" [.6]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# back wall: metallic with clearcoat and anisotropy
+AttributeBegin
+  Material "disney" "texture color" "tri_tga" "float metallic" [.6] "float roughness" [.3] "float clearcoat" [.5] "float anisotropic" [.4] "float speculartint" [.2]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
+AttributeEnd
+# a thin sheet: fake subsurface, specular and diffuse transmission (strans * Sqrt(c), dt * c)
+AttributeBegin
+  Material "disney" "texture color" "pfm_clamp" "bool thin" ["true"] "float spectrans" [.5] "float flatness" [.4] "float difftrans" [.8] "float roughness" [.25] "float eta" [1.4]
+  Translate -2.2 1 0
+  Rotate 35 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.9 0  1 -.9 0  1 .9 0  -1 .9 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# a solid: specular transmission through the Disney microfacet distribution; black texels outside the map (wrap "black")
+AttributeBegin
+  Material "disney" "texture color" "png_black" "float spectrans" [.7] "float roughness" [.2] "float sheen" [1] "float metallic" [.2]
+  Translate 2.2 1 0
+  Rotate -30 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.9 0  1 -.9 0  1 .9 0  -1 .9 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# a curved, bumpy-normal patch
+AttributeBegin
+  Material "disney" "texture color" "ewa_png" "float roughness" [.6] "float sheen" [.4] "float clearcoat" [1] "float clearcoatgloss" [.3]
+  Translate 0 .2 -1.5
+%(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def disney_textured_scene(res=64, spp=16, depth=5, lens=False):
+    """"disney" with an image-textured "color" (disney.cpp:485-587): thick and thin, metallic, sheen, clearcoat, specular and
+    diffuse transmission, a map with black texels. Needs write_texture_files()."""
+    return DISNEY_TEXTURED_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                        lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
 INSTANCED_SCENE = """
 LookAt 0 2.2 -8  0 0.9 0  0 1 0
 Camera "perspective" "float fov" [42] %(lens)s
@@ -757,7 +815,14 @@ def random_scene(seed, res=32, spp=8):
         if k == 5: return 'Material "metal" "float roughness" [%.3f]' % r(.005, .2)
         if k == 6: return 'Material "substrate" "rgb Kd" %s "rgb Ks" %s "float uroughness" [%.3f] "float vroughness" [%.3f]' % (rgb(), rgb(.05, .5), r(.02, .3), r(.02, .3))
         if k == 7: return 'Material "translucent" "rgb Kd" %s "rgb Ks" %s "rgb reflect" %s "rgb transmit" %s' % (rgb(), rgb(.05, .4), rgb(.2, .7), rgb(.2, .7))
-        if k == 8: return 'Material "disney" "rgb color" %s "float metallic" [%.2f] "float roughness" [%.2f] "float clearcoat" [%.2f] "float sheen" [%.2f]' % (rgb(), r(0, 1), r(.1, .8), r(0, 1), r(0, 1))
+        if k == 8:
+            base = 'Material "disney" "rgb color" %s "float metallic" [%.2f] "float roughness" [%.2f] "float clearcoat" [%.2f] "float sheen" [%.2f]' % (rgb(), r(0, 1), r(.1, .8), r(0, 1), r(0, 1))
+            if rng2.random() < .5:   # (round 3: an image-textured colour, thick or thin, with specular transmission and the tints)
+                base = base.replace('"rgb color" ' + base.split('"rgb color" ')[1].split(']')[0] + ']', '"texture color" "%s"' % rng2.choice(["img_a", "img_b"]))
+                base += ' "float speculartint" [%.2f] "float sheentint" [%.2f]' % (float(rng2.uniform(0, 1)), float(rng2.uniform(0, 1)))
+                if rng2.random() < .5: base += ' "float spectrans" [%.2f]' % float(rng2.uniform(.1, .9))
+                if rng2.random() < .4: base += ' "bool thin" ["true"] "float flatness" [%.2f] "float difftrans" [%.2f]' % (float(rng2.uniform(0, 1)), float(rng2.uniform(0, 1.6)))
+            return base
         if k == 9: return 'Material "matte" "texture Kd" "img_a"%s' % bump
         if k == 10: return 'Material "plastic" "texture Kd" "img_s" "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(.05, .4), r(.02, .3), bump)
         if k == 11: return 'Material "uber" "texture Kd" "img_b" "texture Ks" "img_a" "rgb Kr" %s "float roughness" [%.3f]' % (rgb(0, .2), r(.05, .3))

@@ -674,6 +674,30 @@ def test_roughness_textures_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(ff, ofilm) > 0.02
 
 
+def test_disney_with_a_textured_colour_against_oracle(pt, ob, tmp_path):
+    """DisneyMaterial::ComputeScatteringFunctions with `color` an image texture (disney.cpp:485-587): the lobes are added
+    whatever the colour is, their weights stay constants, and the sheen, specular and specular-transmission spectra are
+    formed at the hit from the colour and its luminance (Csheen, Cspec0, strans * Sqrt(c): mi_lobe_rule). Exact mode."""
+    st.write_texture_files(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.disney_textured_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == []
+        mats = [s.desc.materials[i] for i in range(s.desc.n_materials)]
+        disney = [m for m in mats if m.kind == 4]
+        assert len(disney) == 5 and all(m.textured for m in disney)
+        rules = sorted({m.tex[i].rule for m in disney for i in range(m.n_bxdfs) if m.tex[i].tex_R >= 0})
+        assert rules == [3, 4, 5, 6]   # MI_LOBE_ALWAYS, _DISNEY_SHEEN, _DISNEY_SPEC, _DISNEY_STRANS
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "disney textured colour lens=%s" % lens)
+    # the maps matter: with a constant colour in their place the picture differs visibly
+    flat = st.disney_textured_scene(lens=True)
+    for name in ("ewa_png", "tri_tga", "pfm_clamp", "png_black"):
+        flat = flat.replace('"texture color" "%s"' % name, '"rgb color" [.5 .5 .5]')
+    fs = pt.Scene(text=flat, base_dir=str(tmp_path))
+    assert fs.errors == []
+    ff, _, _, _ = ob.render(fs)
+    assert _rel_l2(ff, ofilm) > 0.02
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
