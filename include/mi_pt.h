@@ -165,7 +165,10 @@ typedef enum mi_lobe_rule {
     MI_LOBE_ALWAYS = 3,
     MI_LOBE_DISNEY_SHEEN = 4,
     MI_LOBE_DISNEY_SPEC = 5,
-    MI_LOBE_DISNEY_STRANS = 6
+    MI_LOBE_DISNEY_STRANS = 6,
+    /* "metal" with image-textured `eta` / `k` (metal.cpp:119-122: FresnelConductor(1, eta->Evaluate(si), k->Evaluate(si))):
+     * tex_S = eta's texture, tex_R = k's -- the lobe's R stays the constant 1 -- either may be -1; always present */
+    MI_LOBE_METAL = 7
 } mi_lobe_rule;
 typedef struct mi_lobe_tex {
     int32_t tex_R, tex_S; /* index into mi_scene_desc.textures, -1 = the constant in mi_bxdf */

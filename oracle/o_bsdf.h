@@ -191,11 +191,11 @@ inline Float RoughnessToAlphaF(Float roughness) {
 
 struct BxDF {
     const mi_bxdf *b;
-    bool texR = false, texS = false;   // the spectrum of this hit comes from an image texture (mi_lobe_tex)
-    Spec Rtex, Stex;
+    bool texR = false, texS = false, texK = false;   // the spectrum of this hit comes from an image texture (mi_lobe_tex)
+    Spec Rtex, Stex, Ktex;
     Spec R() const { return texR ? Rtex : Spec::From(b->R); }
     Spec S() const { return texS ? Stex : Spec::From(b->S); }
-    Spec K() const { return Spec::From(b->K); }
+    Spec K() const { return texK ? Ktex : Spec::From(b->K); }
     Spec Scale() const { return Spec::From(b->scale); }
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
     // roughness from float textures (mi_material.rough_tex): the alphas of this hit in place of b->p[0] / p[1]
@@ -490,6 +490,10 @@ struct BSDF {
             bx.b = &m.bxdf[i];
             bx.ovU = ov[0]; bx.ovV = ov[1]; bx.alphaU = alpha[0]; bx.alphaV = alpha[1];
             const mi_lobe_tex &lt = m.tex[i];
+            if (m.textured && d && td && lt.rule == MI_LOBE_METAL) {   // metal.cpp:119-122: eta and k from their textures, R = 1
+                if (lt.tex_S >= 0) { bx.texS = true; bx.Stex = EvalImageTexture(*d, lt.tex_S, si, *td); }
+                if (lt.tex_R >= 0) { bx.texK = true; bx.Ktex = EvalImageTexture(*d, lt.tex_R, si, *td); }
+            } else
             if (m.textured && d && td && (lt.tex_R >= 0 || lt.tex_S >= 0)) {
                 bool texBlack = true;
                 if (lt.tex_R >= 0) {

@@ -261,10 +261,17 @@ template <int NL>
 DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int bin) {
     const float c = which ? b.S[bin] : b.R[bin];
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return c;
-    const float T = TexBin(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], bin);
     const int rule = (int)((lt.rules >> (4 * li)) & 15u);
-    if (rule >= MI_LOBE_DISNEY_SHEEN) return DisneyTexBin(rule, which, b.p, T, lt.lum);
+    if (rule == MI_LOBE_METAL && which == 0) return c;   // (the R slot carries k's texture: TexturedK)
+    const float T = TexBin(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], bin);
+    if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS) return DisneyTexBin(rule, which, b.p, T, lt.lum);
     return (((which ? lt.mulS : lt.mulR) >> li) & 1u) ? c * T : T;
+}
+// The conductor's absorption k at a bin: "metal" with an image-textured k keeps that texture in the lobe's R slot (MI_LOBE_METAL)
+template <int NL>
+DEV float TexturedK(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int bin) {
+    if (((lt.rules >> (4 * li)) & 15u) == (unsigned)MI_LOBE_METAL && ((lt.hasR >> li) & 1u)) return TexBin(lt.basis, lt.textures, lt.r[li], bin);
+    return b.K[bin];
 }
 
 // Lobe-type masks: the shading kernel is instantiated for sets of BxDF types (bit = mi_bxdf_type, bits 16.. =
@@ -342,7 +349,10 @@ DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin, const L
         R = (le.lobe & 0x100) ? bx[li].S[bin] : bx[li].R[bin];
         if constexpr (TM_NEEDS_S(TM)) Sv = bx[li].S[bin];
     }
-    if constexpr (TM_NEEDS_K(TM)) Kv = bx[li].K[bin];
+    if constexpr (TM_NEEDS_K(TM)) {
+        if constexpr ((TM & TM_TEXTURED) != 0) Kv = TexturedK(*lt, bx[li], li, bin);
+        else Kv = bx[li].K[bin];
+    }
     return LobeValueCore<TM>(le, R, Sv, Kv);
 }
 // bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
@@ -646,9 +656,10 @@ template <int NL>
 DEV float4 TexturedQuad(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int c) {
     const float4 k = LoadSpec4(which ? b.S : b.R, c);
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return k;
-    const float4 T = TexQuad(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], c);
     const int rule = (int)((lt.rules >> (4 * li)) & 15u);
-    if (rule >= MI_LOBE_DISNEY_SHEEN)
+    if (rule == MI_LOBE_METAL && which == 0) return k;   // (the R slot carries k's texture)
+    const float4 T = TexQuad(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], c);
+    if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS)
         return make_float4(DisneyTexBin(rule, which, b.p, T.x, lt.lum), DisneyTexBin(rule, which, b.p, T.y, lt.lum),
                            DisneyTexBin(rule, which, b.p, T.z, lt.lum), DisneyTexBin(rule, which, b.p, T.w, lt.lum));
     if (((which ? lt.mulS : lt.mulR) >> li) & 1u) return make_float4(k.x * T.x, k.y * T.y, k.z * T.z, k.w * T.w);
@@ -821,7 +832,13 @@ DEV int AccumulateLobe(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL>
             R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w;
             if constexpr (TM_NEEDS_S(TM)) { const float4 s4 = LoadSpec4(b.S, c); Sv[0] = s4.x; Sv[1] = s4.y; Sv[2] = s4.z; Sv[3] = s4.w; }
         }
-        if constexpr (TM_NEEDS_K(TM)) { const float4 k4 = LoadSpec4(b.K, c); Kv[0] = k4.x; Kv[1] = k4.y; Kv[2] = k4.z; Kv[3] = k4.w; }
+        if constexpr (TM_NEEDS_K(TM)) {
+            float4 k4 = LoadSpec4(b.K, c);
+            if constexpr ((TM & TM_TEXTURED) != 0) {   // "metal" with an image-textured k: its texture sits in the lobe's R slot
+                if (((lt->rules >> (4 * li)) & 15u) == (unsigned)MI_LOBE_METAL && ((lt->hasR >> li) & 1u)) k4 = TexQuad(lt->basis, lt->textures, lt->r[li], c);
+            }
+            Kv[0] = k4.x; Kv[1] = k4.y; Kv[2] = k4.z; Kv[3] = k4.w;
+        }
         const bool scaled = (TM & TM_SCALED) != 0 && (le.lobe & 0x200);
         if (scaled) { const float4 c4 = LoadSpec4(b.scale, c); Sc[0] = c4.x; Sc[1] = c4.y; Sc[2] = c4.z; Sc[3] = c4.w; }
         float v[4];

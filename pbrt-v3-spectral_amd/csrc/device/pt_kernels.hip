@@ -2056,7 +2056,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         }
                         lt.rules |= (unsigned)(ltx.rule & 15) << (4 * i);
                         if (ltx.rule >= MI_LOBE_ALWAYS) {   // "disney": lobes are added whatever the colour is
-                            if (ltx.rule >= MI_LOBE_DISNEY_SHEEN && lt.lum == 0.f) {   // lum = c.y(), once per vertex (every lobe has the same colour)
+                            if (ltx.rule >= MI_LOBE_DISNEY_SHEEN && ltx.rule <= MI_LOBE_DISNEY_STRANS && lt.lum == 0.f) {   // lum = c.y(), once per vertex (every lobe has the same colour)
                                 float yy = 0.f;
                                 for (int b = 0; b < MI_NSPEC; ++b) yy += SpecYBinAccum(s, b, TexBin(lt.basis, lt.textures, lt.r[i], b));
                                 lt.lum = YScale(yy);

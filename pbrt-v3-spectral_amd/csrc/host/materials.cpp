@@ -171,8 +171,10 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         m->kind = 6;
         Spectrum copperN, copperK;
         for (int i = 0; i < MI_NSPEC; ++i) { copperN.c[i] = kCopperN[i]; copperK.c[i] = kCopperK[i]; }
-        Spectrum eta = mp.GetSpectrum("eta", copperN);
-        Spectrum k = mp.GetSpectrum("k", copperK);
+        const SpectrumParam pEta = mp.GetSpectrumParam("eta", copperN), pK = mp.GetSpectrumParam("k", copperK);
+        if ((pEta.tex >= 0 && pEta.scaled) || (pK.tex >= 0 && pK.scaled)) { errs->push_back("metal \"eta\" / \"k\" bound to a `scale` of an image texture is outside the hot-path scope"); return false; }
+        Spectrum eta = pEta.s;
+        Spectrum k = pK.s;
         const RoughSrc rough = Rough(mp, "roughness", .01f), ru = Rough(mp, "uroughness", 0.f), rv = Rough(mp, "vroughness", 0.f);
         mi_bxdf b = MakeBxDF(MI_BXDF_MICROFACET_REFLECTION, MI_BSDF_REFLECTION | MI_BSDF_GLOSSY, Spectrum(1.f));
         b.fresnel = MI_FRESNEL_CONDUCTOR;
@@ -180,6 +182,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         SetS(b, eta);
         for (int i = 0; i < MI_NSPEC; ++i) b.K[i] = k.c[i];
         Add(m, b, errs);
+        Bind(m, pK.tex, false, pEta.tex, false, MI_LOBE_METAL);   // (tex_R carries k's texture: mi_lobe_rule)
         return true;
     }
     if (type == "substrate") {  // src/materials/substrate.cpp:45-64,66-81: FresnelBlend(Kd, Ks, TR)

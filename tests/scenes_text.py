@@ -642,6 +642,38 @@ WorldEnd
 """
 
 
+METAL_TEXTURED_SCENE = DISNEY_TEXTURED_SCENE.split("# ground:")[0] + """# ground: both spectra of the conductor from maps
+AttributeBegin
+  Material "metal" "texture eta" "ewa_png" "texture k" "tri_tga" "float roughness" [.08]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# back wall: eta from a map, k the copper default; anisotropic roughness
+AttributeBegin
+  Material "metal" "texture eta" "pfm_clamp" "float uroughness" [.05] "float vroughness" [.2]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
+AttributeEnd
+# a panel: k from a map with black texels, eta a constant spectrum
+AttributeBegin
+  Material "metal" "rgb eta" [.2 .9 1.1] "texture k" "png_black" "float roughness" [.02] "bool remaproughness" ["false"]
+  Translate -2.2 1 0
+  Rotate 35 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.9 0  1 -.9 0  1 .9 0  -1 .9 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+  Material "metal" "texture eta" "tri_tga" "texture k" "ewa_png" "float roughness" [.15]
+  Translate 0 .2 -1.5
+%(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def metal_textured_scene(res=64, spp=16, depth=5, lens=False):
+    """"metal" with image-textured eta / k (metal.cpp:119-122): both, one of them, with black texels. Needs write_texture_files()."""
+    return METAL_TEXTURED_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                       lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
 def disney_textured_scene(res=64, spp=16, depth=5, lens=False):
     """"disney" with an image-textured "color" (disney.cpp:485-587): thick and thin, metallic, sheen, clearcoat, specular and
     diffuse transmission, a map with black texels. Needs write_texture_files()."""
@@ -812,7 +844,13 @@ def random_scene(seed, res=32, spp=8):
         if k == 3: return 'Material "mirror" "rgb Kr" %s' % rgb(.5, .95)
         if k == 4: return ('Material "uber" "rgb Kd" %s "rgb Ks" %s "rgb Kr" %s "rgb Kt" %s "float roughness" [%.3f] "rgb opacity" %s%s'
                            % (rgb(), rgb(.05, .4), rgb(0, .3), rgb(0, .3), r(.02, .4), rgb(.6, 1) if rng.random() < .4 else "[1 1 1]", bump))
-        if k == 5: return 'Material "metal" "float roughness" [%.3f]' % r(.005, .2)
+        if k == 5:
+            base = 'Material "metal" "float roughness" [%.3f]' % r(.005, .2)
+            if rng2.random() < .4:   # (round 3: eta and / or k from image maps)
+                pick = int(rng2.integers(0, 3))
+                if pick != 1: base += ' "texture eta" "%s"' % rng2.choice(["img_a", "img_b"])
+                if pick != 0: base += ' "texture k" "%s"' % rng2.choice(["img_a", "img_b"])
+            return base
         if k == 6: return 'Material "substrate" "rgb Kd" %s "rgb Ks" %s "float uroughness" [%.3f] "float vroughness" [%.3f]' % (rgb(), rgb(.05, .5), r(.02, .3), r(.02, .3))
         if k == 7: return 'Material "translucent" "rgb Kd" %s "rgb Ks" %s "rgb reflect" %s "rgb transmit" %s' % (rgb(), rgb(.05, .4), rgb(.2, .7), rgb(.2, .7))
         if k == 8:

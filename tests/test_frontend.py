@@ -531,6 +531,7 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
         'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "matte" "texture sigma" "f"\n' + tri: "Float image texture",
         'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
         'Texture "sc" "spectrum" "scale" "texture tex1" "t" "rgb tex2" [.5 .5 .5]\nMaterial "disney" "texture color" "sc"\n' + tri: "scale",
+        'Texture "sc" "spectrum" "scale" "texture tex1" "t" "rgb tex2" [.5 .5 .5]\nMaterial "metal" "texture k" "sc"\n' + tri: "scale",
         'Material "glass" "texture Kr" "t" "float uroughness" [.1] "float vroughness" [.1]\n' + tri: "rough",
         'Texture "m" "spectrum" "imagemap" "string filename" "missing.png"\nMaterial "matte" "texture Kd" "m"\n' + tri: "missing.png",
         'Texture "e" "spectrum" "imagemap" "string filename" "a.exr"\nMaterial "matte" "texture Kd" "e"\n' + tri: "exr",

@@ -698,6 +698,26 @@ def test_disney_with_a_textured_colour_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(ff, ofilm) > 0.02
 
 
+def test_metal_with_textured_eta_and_k_against_oracle(pt, ob, tmp_path):
+    """MetalMaterial with `eta` / `k` image textures (metal.cpp:119-122): FresnelConductor(1, eta->Evaluate(si), k->Evaluate(si))
+    at the hit -- both maps, one of them, a map with black texels (k = 0: a dielectric-like Fresnel term). Exact mode."""
+    st.write_texture_files(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.metal_textured_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == []
+        metals = [s.desc.materials[i] for i in range(s.desc.n_materials) if s.desc.materials[i].kind == 6]
+        assert len(metals) == 4 and all(m.textured and m.n_bxdfs == 1 and m.tex[0].rule == 7 for m in metals)   # MI_LOBE_METAL
+        assert sorted((m.tex[0].tex_S >= 0, m.tex[0].tex_R >= 0) for m in metals) == [(False, True), (True, False), (True, True), (True, True)]
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "metal textured eta k lens=%s" % lens)
+    flat = st.metal_textured_scene(lens=True)
+    for name in ("ewa_png", "tri_tga", "pfm_clamp", "png_black"):
+        flat = flat.replace('"texture eta" "%s"' % name, '').replace('"texture k" "%s"' % name, '')
+    fs = pt.Scene(text=flat, base_dir=str(tmp_path))
+    assert fs.errors == []
+    ff, _, _, _ = ob.render(fs)
+    assert _rel_l2(ff, ofilm) > 0.02
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
