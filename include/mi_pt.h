@@ -190,6 +190,10 @@ typedef struct mi_material {
      * MI_ROUGH_REMAP is set, replaces that constant in every microfacet / FresnelBlend lobe of the material. */
     int32_t rough_tex[2];
     uint32_t rough_flags;
+    /* ABI v10 -- "matte" with `sigma` a float image texture (matte.cpp:55-62): at the hit sig = Clamp(value, 0, 90), and the
+     * material's diffuse lobe (compiled as MI_BXDF_OREN_NAYAR) is a LambertianReflection where sig == 0 and an OrenNayar with
+     * the A, B of that sig elsewhere (reflection.h:414-420). -1 = the constants of the lobe. */
+    int32_t sigma_tex;
 } mi_material;
 #define MI_ROUGH_REMAP 1u
 

@@ -200,6 +200,8 @@ struct BxDF {
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
     // roughness from float textures (mi_material.rough_tex): the alphas of this hit in place of b->p[0] / p[1]
     bool ovU = false, ovV = false;
+    int sigMode = 0;          // "matte" with a sigma map: 1 = OrenNayar with sigA / sigB, 2 = LambertianReflection (sig == 0)
+    Float sigA = 0, sigB = 0;
     Float alphaU = 0, alphaV = 0;
     TRDist Dist() const { return TRDist{ovU ? alphaU : b->p[0], ovV ? alphaV : b->p[1], b->p[5] != 0.f}; }
 
@@ -239,6 +241,7 @@ struct BxDF {
         case MI_BXDF_LAMBERTIAN_REFLECTION: return R() * InvPi;
         case MI_BXDF_LAMBERTIAN_TRANSMISSION: return R() * InvPi;
         case MI_BXDF_OREN_NAYAR: {  // reflection.cpp:178-200
+            if (sigMode == 2) return R() * InvPi;   // (matte.cpp:59-60: sig == 0 at this hit)
             Float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
             Float maxCos = 0;
             if (sinThetaI > 1e-4 && sinThetaO > 1e-4) {
@@ -250,7 +253,7 @@ struct BxDF {
             Float sinAlpha, tanBeta;
             if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / AbsCosTheta(wi); }
             else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
-            return R() * InvPi * (b->p[0] + b->p[1] * maxCos * sinAlpha * tanBeta);
+            return R() * InvPi * ((sigMode ? sigA : b->p[0]) + (sigMode ? sigB : b->p[1]) * maxCos * sinAlpha * tanBeta);
         }
         case MI_BXDF_MICROFACET_REFLECTION: {  // reflection.cpp:207-217
             Float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
@@ -485,10 +488,24 @@ struct BSDF {
                 else alpha[a] = (m.rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlphaF(r) : r;
                 ov[a] = true;
             }
+        // `Float sig = Clamp(sigma->Evaluate(*si), 0, 90)`, matte.cpp:57; OrenNayar's constructor, reflection.h:414-420
+        int sigMode = 0;
+        Float sigA = 0, sigB = 0;
+        if (d && td && m.sigma_tex >= 0) {
+            const Float sig = Clamp(EvalFloatImageTexture(*d, m.sigma_tex, si.uv[0], si.uv[1], *td), 0, 90);
+            if (sig == 0) sigMode = 2;
+            else {
+                const Float sigma = (Pi / 180) * sig, sigma2 = sigma * sigma;   // Radians(), pbrt.h:252
+                sigMode = 1;
+                sigA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                sigB = 0.45f * sigma2 / (sigma2 + 0.09f);
+            }
+        }
         for (int i = 0; i < m.n_bxdfs; ++i) {
             BxDF bx;
             bx.b = &m.bxdf[i];
             bx.ovU = ov[0]; bx.ovV = ov[1]; bx.alphaU = alpha[0]; bx.alphaV = alpha[1];
+            bx.sigMode = sigMode; bx.sigA = sigA; bx.sigB = sigB;
             const mi_lobe_tex &lt = m.tex[i];
             if (m.textured && d && td && lt.rule == MI_LOBE_METAL) {   // metal.cpp:119-122: eta and k from their textures, R = 1
                 if (lt.tex_S >= 0) { bx.texS = true; bx.Stex = EvalImageTexture(*d, lt.tex_S, si, *td); }

@@ -60,7 +60,7 @@ class LobeTex(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("n_bxdfs", C.c_int32), ("eta", C.c_float), ("kind", C.c_int32), ("textured", C.c_int32),
-                ("bxdf", Bxdf * MAX_BXDFS), ("tex", LobeTex * MAX_BXDFS), ("bump_tex", C.c_int32), ("rough_tex", C.c_int32 * 2), ("rough_flags", C.c_uint32)]
+                ("bxdf", Bxdf * MAX_BXDFS), ("tex", LobeTex * MAX_BXDFS), ("bump_tex", C.c_int32), ("rough_tex", C.c_int32 * 2), ("rough_flags", C.c_uint32), ("sigma_tex", C.c_int32)]
 
 
 MAX_MIP_LEVELS = 16

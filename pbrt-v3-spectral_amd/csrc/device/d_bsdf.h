@@ -369,6 +369,10 @@ DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin, const LobeTe
 struct AlphaOv {
     float u, v;
     bool onU, onV;
+    // "matte" with `sigma` a float image texture (mi_material.sigma_tex; matte.cpp:55-62): 0 = the lobe's constants, 1 = OrenNayar
+    // with sigA / sigB (the A, B of the sigma at this vertex, reflection.h:414-420), 2 = sigma is 0 here: LambertianReflection
+    int sigMode;
+    float sigA, sigB;
 };
 // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:140-145
 DEV float RoughnessToAlpha(float roughness) {
@@ -424,6 +428,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const Al
     case MI_BXDF_LAMBERTIAN_TRANSMISSION:
         le.kind = LK_MUL1; le.a = kInvPi; break;
     case MI_BXDF_OREN_NAYAR: if constexpr (TM_HAS(TM, MI_BXDF_OREN_NAYAR)) {
+        if constexpr ((TM & TM_TEXTURED) != 0) { if (ov.sigMode == 2) { le.kind = LK_MUL1; le.a = kInvPi; break; } }
         float sinThetaI = SinTheta(wi), sinThetaO = SinTheta(wo);
         float maxCos = 0;
         if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
@@ -435,7 +440,9 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const Al
         float sinAlpha, tanBeta;
         if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / AbsCosTheta(wi); }
         else { sinAlpha = sinThetaI; tanBeta = sinThetaO / AbsCosTheta(wo); }
-        le.kind = LK_MUL2; le.a = kInvPi; le.b = (b.p[0] + b.p[1] * maxCos * sinAlpha * tanBeta);
+        float oA = b.p[0], oB = b.p[1];
+        if constexpr ((TM & TM_TEXTURED) != 0) { if (ov.sigMode == 1) { oA = ov.sigA; oB = ov.sigB; } }
+        le.kind = LK_MUL2; le.a = kInvPi; le.b = (oA + oB * maxCos * sinAlpha * tanBeta);
         break;
     } break;
     case MI_BXDF_MICROFACET_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_MICROFACET_REFLECTION)) {

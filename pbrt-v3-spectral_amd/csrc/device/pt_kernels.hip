@@ -1987,6 +1987,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             fr.m = mat;
             fr.mask = 0xffu;
             fr.ov.u = fr.ov.v = 0.f; fr.ov.onU = fr.ov.onV = false;
+            fr.ov.sigMode = 0; fr.ov.sigA = fr.ov.sigB = 0.f;
             LobeTexT<NL> lt;
             const LobeTexT<NL> *ltp = nullptr;
             if constexpr ((TM & TM_TEXTURED) != 0) {
@@ -2038,6 +2039,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                             fr.ov.v = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;
                         }
                         fr.ov.onV = true;
+                    }
+                    if (mat->sigma_tex >= 0) {   // `Float sig = Clamp(sigma->Evaluate(*si), 0, 90)`, matte.cpp:57; OrenNayar's constructor
+                        const float sig = clampf(EvalFloatImageTexture(s, mat->sigma_tex, u, v, td), 0.f, 90.f);
+                        if (sig == 0) fr.ov.sigMode = 2;
+                        else {
+                            const float sigma = (kPi / 180) * sig, sigma2 = sigma * sigma;
+                            fr.ov.sigMode = 1;
+                            fr.ov.sigA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                            fr.ov.sigB = 0.45f * sigma2 / (sigma2 + 0.09f);
+                        }
                     }
                     unsigned mask = 0u;
                     for (int i = 0; i < mat->n_bxdfs; ++i) {

@@ -117,6 +117,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
     m->eta = 1.f;
     for (int i = 0; i < MI_MAX_BXDFS; ++i) m->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     m->rough_tex[0] = m->rough_tex[1] = -1;
+    m->sigma_tex = -1;
     m->bump_tex = mp.GetFloatImageTexture("bumpmap");   // `if (bumpMap) Bump(bumpMap, si)`, first line of every ComputeScatteringFunctions
     if (m->bump_tex >= 0) {
         if (type == "mix" || type == "disney" || type == "metal") { errs->push_back("\"bumpmap\" on a \"" + type + "\" material is outside the hot-path scope"); return false; }
@@ -130,9 +131,11 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         m->kind = 0;
         const SpectrumParam Kd = mp.GetSpectrumParam("Kd", Spectrum(0.5f));
         Spectrum r = Kd.s.Clamp();
-        float sig = Clamp(mp.GetFloat("sigma", 0.f), 0, 90);
+        const int sigTex = mp.GetFloatImageTexture("sigma");   // (a float map: Lambertian or Oren-Nayar is decided at the hit, mi_material.sigma_tex)
+        float sig = sigTex >= 0 ? 0.f : Clamp(mp.GetFloat("sigma", 0.f), 0, 90);
         if (MayBeNonBlack(Kd, r)) {
-            if (sig == 0) Add(m, Lambertian(r), errs);
+            if (sigTex >= 0) { Add(m, OrenNayar(r, 0.f), errs); m->sigma_tex = sigTex; m->textured = 1; }
+            else if (sig == 0) Add(m, Lambertian(r), errs);
             else Add(m, OrenNayar(r, sig), errs);
             Bind(m, Kd.tex, Kd.scaled);
         }
@@ -416,6 +419,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
     for (int i = 0; i < MI_MAX_BXDFS; ++i) out->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
     out->bump_tex = -1;
     out->rough_tex[0] = out->rough_tex[1] = -1;
+    out->sigma_tex = -1;
     out->kind = 9;
     out->eta = m1.eta;
     const Spectrum s1 = amount.Clamp();
@@ -427,7 +431,7 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
             mi_bxdf b = src[k]->bxdf[i];
             // (each sub-material runs its own ComputeScatteringFunctions, mixmat.cpp:52-56: its textured lobes keep their
             // bindings and presence rules; a bump or roughness map would act on one sub-material's copy of the interaction)
-            if (src[k]->bump_tex >= 0 || src[k]->rough_tex[0] >= 0 || src[k]->rough_tex[1] >= 0) {
+            if (src[k]->bump_tex >= 0 || src[k]->rough_tex[0] >= 0 || src[k]->rough_tex[1] >= 0 || src[k]->sigma_tex >= 0) {
                 errs->push_back("a \"mix\" of bump-mapped or roughness-mapped materials is outside the hot-path scope");
                 return false;
             }

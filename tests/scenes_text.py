@@ -674,6 +674,45 @@ def metal_textured_scene(res=64, spp=16, depth=5, lens=False):
                                        lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
 
 
+SIGMA_TEXTURED_SCENE = DISNEY_TEXTURED_SCENE.split("# ground:")[0] + """Texture "sig_png" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [3] "float vscale" [3]
+Texture "sig_deg" "float" "scale" "texture tex1" "sig_png" "float tex2" [60]
+Texture "sig_tga" "float" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"]
+Texture "sig_big" "float" "scale" "texture tex1" "sig_tga" "float tex2" [200]
+Texture "sig_black" "float" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2]
+Texture "sig_b40" "float" "scale" "texture tex1" "sig_black" "float tex2" [40]
+# ground: sigma 0..60 degrees from a map (black texels: Lambertian there)
+AttributeBegin
+  Material "matte" "rgb Kd" [.7 .6 .5] "texture sigma" "sig_deg"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# back wall: values beyond 90 (clamped), and a textured Kd as well
+AttributeBegin
+  Material "matte" "texture Kd" "ewa_png" "texture sigma" "sig_big"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
+AttributeEnd
+# a panel whose map is black outside [0,1]^2 (wrap "black": sigma = 0, the Lambertian lobe)
+AttributeBegin
+  Material "matte" "rgb Kd" [.3 .5 .8] "texture sigma" "sig_b40"
+  Translate -2.2 1 0
+  Rotate 35 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.9 0  1 -.9 0  1 .9 0  -1 .9 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+  Material "matte" "rgb Kd" [.8 .8 .8] "texture sigma" "sig_deg"
+  Translate 0 .2 -1.5
+%(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def sigma_textured_scene(res=64, spp=16, depth=5, lens=False):
+    """"matte" with `sigma` a float image texture (matte.cpp:55-62): Lambertian where the map is 0, Oren-Nayar with the A, B
+    of the clamped value elsewhere. Needs write_texture_files()."""
+    return SIGMA_TEXTURED_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                       lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
 def disney_textured_scene(res=64, spp=16, depth=5, lens=False):
     """"disney" with an image-textured "color" (disney.cpp:485-587): thick and thin, metallic, sheen, clearcoat, specular and
     diffuse transmission, a map with black texels. Needs write_texture_files()."""
@@ -832,13 +871,19 @@ def random_scene(seed, res=32, spp=8):
     out.append('Texture "bump_raw" "float" "imagemap" "string filename" "tex_a.png" "float uscale" [2] "float vscale" [2]')
     out.append('Texture "bump" "float" "scale" "texture tex1" "bump_raw" "float tex2" [%.3f]' % r(.01, .1))
     out.append('Texture "mask" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [%.1f]' % r(1, 3))
+    out.append('Texture "sig_raw" "float" "imagemap" "string filename" "tex_b.tga" "string wrap" "black"')
+    out.append('Texture "sig_map" "float" "scale" "texture tex1" "sig_raw" "float tex2" [60]')
     out.append('Texture "chk" "spectrum" "checkerboard" "float uscale" [%.1f] "float vscale" [%.1f] "rgb tex1" %s "rgb tex2" %s %s'
                % (r(1, 9), r(1, 9), rgb(), rgb(0, .3), '"string aamode" "none"' if rng.random() < .3 else ""))
 
     def material():
         k = int(rng.integers(0, 15))
         bump = ' "texture bumpmap" "bump"' if rng.random() < .25 else ""
-        if k == 0: return 'Material "matte" "rgb Kd" %s "float sigma" [%.1f]%s' % (rgb(), r(0, 40) if rng.random() < .5 else 0, bump)
+        if k == 0:
+            base = 'Material "matte" "rgb Kd" %s "float sigma" [%.1f]%s' % (rgb(), r(0, 40) if rng.random() < .5 else 0, bump)
+            if rng2.random() < .3:   # (round 3: sigma from a float map, 0 .. 60 degrees)
+                base = 'Material "matte" "rgb Kd" %s "texture sigma" "sig_map"%s' % (rgb(), bump)
+            return base
         if k == 1: return 'Material "plastic" "rgb Kd" %s "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(), rgb(.05, .5), r(.01, .4), bump)
         if k == 2: return 'Material "glass" "rgb Kr" %s "rgb Kt" %s "float index" [%.2f]' % (rgb(.5, 1), rgb(.5, 1), r(1.2, 1.8))
         if k == 3: return 'Material "mirror" "rgb Kr" %s' % rgb(.5, .95)

@@ -718,6 +718,25 @@ def test_metal_with_textured_eta_and_k_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(ff, ofilm) > 0.02
 
 
+def test_matte_with_a_sigma_map_against_oracle(pt, ob, tmp_path):
+    """MatteMaterial with `sigma` a float image texture (matte.cpp:55-62): `sig = Clamp(sigma->Evaluate(si), 0, 90)` at the hit,
+    LambertianReflection where it is 0 and OrenNayar(r, sig) elsewhere (A, B of reflection.h:414-420). Exact mode."""
+    st.write_texture_files(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.sigma_textured_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == []
+        mats = [s.desc.materials[i] for i in range(s.desc.n_materials)]
+        assert sum(1 for m in mats if m.sigma_tex >= 0) == 4 and all(m.textured and m.bxdf[0].type == 1 for m in mats if m.sigma_tex >= 0)
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "matte sigma map lens=%s" % lens)
+    flat = st.sigma_textured_scene(lens=True)
+    for name in ("sig_deg", "sig_big", "sig_b40"):
+        flat = flat.replace('"texture sigma" "%s"' % name, '"float sigma" [0]')
+    fs = pt.Scene(text=flat, base_dir=str(tmp_path))
+    assert fs.errors == [] and all(fs.desc.materials[i].sigma_tex < 0 for i in range(fs.desc.n_materials))
+    ff, _, _, _ = ob.render(fs)
+    assert _rel_l2(ff, ofilm) > 0.01
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
