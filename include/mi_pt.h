@@ -196,6 +196,11 @@ typedef struct mi_material {
     int32_t sigma_tex;
 } mi_material;
 #define MI_ROUGH_REMAP 1u
+/* ABI v10 -- "glass" with `uroughness` / `vroughness` float image textures (glass.cpp:60-92): the material holds the lobes of both
+ * branches -- lobe 0 the FresnelSpecular one, after it the microfacet reflection / transmission lobes -- and the hit decides:
+ * `isSpecular = urough == 0 && vrough == 0` on the values before the remap (a constant axis keeps its raw value in lobe 0's
+ * p[6] (u) / p[7] (v)); lobe 0 is part of the BSDF where isSpecular holds, the others where it does not. */
+#define MI_ROUGH_GLASS 2u
 
 /* ImageTexture<RGBSpectrum, Spectrum> with UVMapping2D (src/textures/imagemap.h, src/core/texture.cpp:91-99) over a
  * MIPMap<RGBSpectrum> (src/core/mipmap.h). The pyramid is built on the host exactly as the reference builds it (y flip,

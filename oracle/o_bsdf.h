@@ -481,13 +481,17 @@ struct BSDF {
         // `rough = roughness->Evaluate(*si); if (remapRoughness) rough = RoughnessToAlpha(rough)`, plastic.cpp:57-62 etc.
         bool ov[2] = {false, false};
         Float alpha[2] = {0, 0};
+        Float raw[2] = {m.n_bxdfs > 0 ? m.bxdf[0].p[6] : 0, m.n_bxdfs > 0 ? m.bxdf[0].p[7] : 0};   // (MI_ROUGH_GLASS: the values before the remap)
         for (int a = 0; a < 2; ++a)
             if (d && td && m.rough_tex[a] >= 0) {
                 Float r = (a == 1 && m.rough_tex[1] == m.rough_tex[0]) ? -1.f : EvalFloatImageTexture(*d, m.rough_tex[a], si.uv[0], si.uv[1], *td);
-                if (a == 1 && m.rough_tex[1] == m.rough_tex[0]) alpha[1] = alpha[0];
-                else alpha[a] = (m.rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlphaF(r) : r;
+                if (a == 1 && m.rough_tex[1] == m.rough_tex[0]) { alpha[1] = alpha[0]; raw[1] = raw[0]; }
+                else { alpha[a] = (m.rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlphaF(r) : r; raw[a] = r; }
                 ov[a] = true;
             }
+        // glass.cpp:66: `bool isSpecular = urough == 0 && vrough == 0` at this hit
+        const bool glassSwitch = d && td && (m.rough_flags & MI_ROUGH_GLASS) != 0;
+        const bool glassSpecular = raw[0] == 0 && raw[1] == 0;
         // `Float sig = Clamp(sigma->Evaluate(*si), 0, 90)`, matte.cpp:57; OrenNayar's constructor, reflection.h:414-420
         int sigMode = 0;
         Float sigA = 0, sigB = 0;
@@ -506,6 +510,7 @@ struct BSDF {
             bx.b = &m.bxdf[i];
             bx.ovU = ov[0]; bx.ovV = ov[1]; bx.alphaU = alpha[0]; bx.alphaV = alpha[1];
             bx.sigMode = sigMode; bx.sigA = sigA; bx.sigB = sigB;
+            if (glassSwitch && ((bx.b->type == MI_BXDF_FRESNEL_SPECULAR) != glassSpecular)) continue;
             const mi_lobe_tex &lt = m.tex[i];
             if (m.textured && d && td && lt.rule == MI_LOBE_METAL) {   // metal.cpp:119-122: eta and k from their textures, R = 1
                 if (lt.tex_S >= 0) { bx.texS = true; bx.Stex = EvalImageTexture(*d, lt.tex_S, si, *td); }

@@ -2027,16 +2027,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     }
                     if (mat->bump_tex >= 0) Bump(s, mat->bump_tex, u, v, td, tsh, &isect);   // `if (bumpMap) Bump(bumpMap, si)`
                     // `rough = roughness->Evaluate(*si); if (remapRoughness) rough = RoughnessToAlpha(rough)` (plastic.cpp:57-62 ...)
+                    float rawU = mat->bxdf[0].p[6], rawV = mat->bxdf[0].p[7];   // (MI_ROUGH_GLASS: the values before the remap)
                     if (mat->rough_tex[0] >= 0) {
                         const float rv = EvalFloatImageTexture(s, mat->rough_tex[0], u, v, td);
                         fr.ov.u = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;
                         fr.ov.onU = true;
+                        rawU = rv;
                     }
                     if (mat->rough_tex[1] >= 0) {
-                        if (mat->rough_tex[1] == mat->rough_tex[0]) fr.ov.v = fr.ov.u;
+                        if (mat->rough_tex[1] == mat->rough_tex[0]) { fr.ov.v = fr.ov.u; rawV = rawU; }
                         else {
                             const float rv = EvalFloatImageTexture(s, mat->rough_tex[1], u, v, td);
                             fr.ov.v = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;
+                            rawV = rv;
                         }
                         fr.ov.onV = true;
                     }
@@ -2093,6 +2096,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         const bool rNonBlack = rNZ != 0u, sNonBlack = sNZ != 0u, texNonBlack = texNZ != 0u;
                         const bool present = ltx.rule == MI_LOBE_IF_R_OR_S ? (rNonBlack || sNonBlack) : (ltx.rule == MI_LOBE_IF_TEX ? texNonBlack : rNonBlack);
                         if (present) mask |= 1u << i;
+                    }
+                    if (mat->rough_flags & MI_ROUGH_GLASS) {   // glass.cpp:66: `isSpecular = urough == 0 && vrough == 0` at this hit
+                        const bool spec = rawU == 0 && rawV == 0;
+                        mask &= spec ? 1u : ~1u;   // lobe 0 is the FresnelSpecular one
                     }
                     fr.mask = mask;
                 }

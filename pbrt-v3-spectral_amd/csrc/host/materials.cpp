@@ -245,11 +245,26 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         Spectrum T = Kt.s.Clamp();
         float eta;
         if (!mp.GetFloatOrNull("eta", &eta)) eta = mp.GetFloat("index", 1.5f);
-        float urough = mp.GetFloat("uroughness", 0.f);
-        float vrough = mp.GetFloat("vroughness", 0.f);
+        const RoughSrc ruSrc = Rough(mp, "uroughness", 0.f), rvSrc = Rough(mp, "vroughness", 0.f);
+        float urough = ruSrc.value;
+        float vrough = rvSrc.value;
         bool remap = mp.FindBool("remaproughness", true);
         m->eta = eta;
         if (!MayBeNonBlack(Kr, R) && !MayBeNonBlack(Kt, T)) return true;
+        if (ruSrc.tex >= 0 || rvSrc.tex >= 0) {
+            // a roughness map: whether the surface is the specular or the rough glass is decided at the hit (MI_ROUGH_GLASS)
+            if (Kr.tex >= 0 || Kt.tex >= 0) { errs->push_back("\"glass\" with a roughness map and image-textured Kr / Kt is outside the hot-path scope"); return false; }
+            mi_bxdf sp = MakeBxDF(MI_BXDF_FRESNEL_SPECULAR, MI_BSDF_REFLECTION | MI_BSDF_TRANSMISSION | MI_BSDF_SPECULAR, R);
+            SetS(sp, T);
+            sp.p[0] = 1.f; sp.p[1] = eta;
+            sp.p[6] = ruSrc.value; sp.p[7] = rvSrc.value;
+            Add(m, sp, errs);
+            if (!R.IsBlack()) { mi_bxdf b = MicrofacetReflectionDielectric(R, 0.f, 0.f, 1.f, eta); SetRough(m, &b, ruSrc, rvSrc, remap); Add(m, b, errs); }
+            if (!T.IsBlack()) { mi_bxdf b = MicrofacetTransmission(T, 0.f, 0.f, 1.f, eta, false); SetRough(m, &b, ruSrc, rvSrc, remap); Add(m, b, errs); }
+            m->rough_flags |= MI_ROUGH_GLASS;
+            m->textured = 1;
+            return true;
+        }
         bool isSpecular = urough == 0 && vrough == 0;
         if (isSpecular) {
             mi_bxdf b = MakeBxDF(MI_BXDF_FRESNEL_SPECULAR,

@@ -713,6 +713,50 @@ def sigma_textured_scene(res=64, spp=16, depth=5, lens=False):
                                        lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
 
 
+GLASS_ROUGH_SCENE = DISNEY_TEXTURED_SCENE.split("# ground:")[0] + """Texture "r_black" "float" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2]
+Texture "r_b3" "float" "scale" "texture tex1" "r_black" "float tex2" [.3]
+Texture "r_tga" "float" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"]
+Texture "r_t2" "float" "scale" "texture tex1" "r_tga" "float tex2" [.2]
+Material "matte" "rgb Kd" [.6 .6 .6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4]
+# a pane whose roughness map is black outside [0,1]^2: specular glass there, rough glass inside
+AttributeBegin
+  Material "glass" "rgb Kr" [.9 .9 .9] "rgb Kt" [.9 .8 .7] "texture uroughness" "r_b3" "texture vroughness" "r_b3"
+  Translate -2 1.1 0
+  Rotate 25 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.2 -1 0  1.2 -1 0  1.2 1 0  -1.2 1 0] "float uv" [0 0 1.6 0 1.6 1 0 1]
+AttributeEnd
+# one axis from a map, the other constant 0; no reflection lobe (Kr black). (Not remapped, a map value of 0 on one axis alone is
+# an alpha of 0 and NaNs in the reference as well: the maps here go through RoughnessToAlpha, which stops at 1e-3)
+AttributeBegin
+  Material "glass" "rgb Kr" [0 0 0] "rgb Kt" [.8 .9 1] "texture uroughness" "r_t2" "float index" [1.3]
+  Translate 2 1.1 0
+  Rotate -25 0 1 0
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1.2 -1 0  1.2 -1 0  1.2 1 0  -1.2 1 0] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+# a solid ball of map-roughened glass, and a curved patch with different maps on the two axes
+AttributeBegin
+  Material "glass" "texture uroughness" "r_t2" "texture vroughness" "r_b3"
+  Translate 0 .9 1.2
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  Material "glass" "rgb Kt" [0 0 0] "texture vroughness" "r_b3" "float uroughness" [.05]
+  Translate 0 .2 -1.5
+%(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def glass_rough_scene(res=64, spp=16, depth=6, lens=False):
+    """"glass" with `uroughness` / `vroughness` float image textures (glass.cpp:60-92): FresnelSpecular where both are 0 at the hit,
+    the microfacet reflection / transmission lobes elsewhere. Needs write_texture_files()."""
+    return GLASS_ROUGH_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                    lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
 def disney_textured_scene(res=64, spp=16, depth=5, lens=False):
     """"disney" with an image-textured "color" (disney.cpp:485-587): thick and thin, metallic, sheen, clearcoat, specular and
     diffuse transmission, a map with black texels. Needs write_texture_files()."""
@@ -873,6 +917,7 @@ def random_scene(seed, res=32, spp=8):
     out.append('Texture "mask" "float" "imagemap" "string filename" "alpha.png" "bool gamma" ["false"] "float uscale" [%.1f]' % r(1, 3))
     out.append('Texture "sig_raw" "float" "imagemap" "string filename" "tex_b.tga" "string wrap" "black"')
     out.append('Texture "sig_map" "float" "scale" "texture tex1" "sig_raw" "float tex2" [60]')
+    out.append('Texture "gl_rough" "float" "scale" "texture tex1" "sig_raw" "float tex2" [.3]')
     out.append('Texture "chk" "spectrum" "checkerboard" "float uscale" [%.1f] "float vscale" [%.1f] "rgb tex1" %s "rgb tex2" %s %s'
                % (r(1, 9), r(1, 9), rgb(), rgb(0, .3), '"string aamode" "none"' if rng.random() < .3 else ""))
 
@@ -885,7 +930,13 @@ def random_scene(seed, res=32, spp=8):
                 base = 'Material "matte" "rgb Kd" %s "texture sigma" "sig_map"%s' % (rgb(), bump)
             return base
         if k == 1: return 'Material "plastic" "rgb Kd" %s "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(), rgb(.05, .5), r(.01, .4), bump)
-        if k == 2: return 'Material "glass" "rgb Kr" %s "rgb Kt" %s "float index" [%.2f]' % (rgb(.5, 1), rgb(.5, 1), r(1.2, 1.8))
+        if k == 2:
+            base = 'Material "glass" "rgb Kr" %s "rgb Kt" %s "float index" [%.2f]' % (rgb(.5, 1), rgb(.5, 1), r(1.2, 1.8))
+            if rng2.random() < .3:   # (round 3: roughness from a float map that is 0 outside [0,1]^2: specular there, rough inside)
+                pick = int(rng2.integers(0, 3))
+                if pick != 1: base += ' "texture uroughness" "gl_rough"'
+                if pick != 0: base += ' "texture vroughness" "gl_rough"'
+            return base
         if k == 3: return 'Material "mirror" "rgb Kr" %s' % rgb(.5, .95)
         if k == 4: return ('Material "uber" "rgb Kd" %s "rgb Ks" %s "rgb Kr" %s "rgb Kt" %s "float roughness" [%.3f] "rgb opacity" %s%s'
                            % (rgb(), rgb(.05, .4), rgb(0, .3), rgb(0, .3), r(.02, .4), rgb(.6, 1) if rng.random() < .4 else "[1 1 1]", bump))

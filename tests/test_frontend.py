@@ -527,7 +527,7 @@ def test_image_texture_scope_is_reported(pt, tmp_path):
     head = 'Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "a.png"\n'
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
     cases = {
-        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "glass" "texture uroughness" "f"\n' + tri: "Float image texture",
+        'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "glass" "texture uroughness" "f" "texture Kr" "t"\n' + tri: "roughness map",
         'Texture "f" "float" "imagemap" "string filename" "a.png"\nMaterial "disney" "texture metallic" "f"\n' + tri: "Float image texture",
         'Texture "p" "spectrum" "imagemap" "string filename" "a.png" "string mapping" "planar"\n' + tri: "mapping",
         'Texture "sc" "spectrum" "scale" "texture tex1" "t" "rgb tex2" [.5 .5 .5]\nMaterial "disney" "texture color" "sc"\n' + tri: "scale",

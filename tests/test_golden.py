@@ -160,7 +160,7 @@ def _procedural_scene(pt, tmp_path, z):
     return pt.Scene(mg.procedural_scene(str(tmp_path)))
 
 
-def _full_frame_against_tiles(pt, s, z, counters, exact, tol, frac_over, max_over):
+def _full_frame_against_tiles(pt, s, z, counters, exact, tol, frac_over, max_over, exact_rel=None):
     """Full frame on the device: exact camera-ray count, no bad samples; shard 0 of 64 (every 64th 16x16 tile, the
     multi-GPU decomposition) against the oracle's film of those tiles in both libm modes; the same tiles inside the
     full frame; three shards adding up to the full frame."""
@@ -189,7 +189,7 @@ def _full_frame_against_tiles(pt, s, z, counters, exact, tol, frac_over, max_ove
     mask[ys, xs] = True
     assert not w0[~mask].any() and not f0[~mask].any()
     zz = {"film": z["film"], "film_exact": z["film_exact"], "weight": z["weight"]}
-    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, tol, frac_over, max_over)
+    _check_against_fixture(f0[ys, xs], w0[ys, xs], zz, spp, tol, frac_over, max_over, exact_rel=exact_rel)
     # the same tiles inside the full frame, away from the pixels that a neighbouring tile's border samples also reach
     inner = (w0[ys, xs] == spp) & (wfull[ys, xs] == spp)
     assert inner.mean() > 0.9
@@ -231,7 +231,9 @@ def test_gpu_procedural_10M_triangles_256spp_full_frame(pt, tmp_path):
     z, counters, exact = _load("procedural_10M_256spp.npz")
     s = _procedural_scene(pt, tmp_path, z)
     assert s.stats["n_triangles"] == 10_000_002 and s.film_size == (700, 700)
-    _full_frame_against_tiles(pt, s, z, counters, exact, 1e-4, 2e-3, 0.05)
+    # (exact-libm image bar 2e-6: on this scene the reference's sequential float sum of a pixel's samples drifts by ~1.07e-6 at 256
+    # spp -- 8.6e-6 measured at 2048 spp, DESIGN 2 -- so the device's film, summed in another order, sits at 0.99e-6 .. 1.0003e-6)
+    _full_frame_against_tiles(pt, s, z, counters, exact, 1e-4, 2e-3, 0.05, exact_rel=2e-6)
 
 
 @pytest.mark.gpu

@@ -737,6 +737,27 @@ def test_matte_with_a_sigma_map_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(ff, ofilm) > 0.01
 
 
+def test_glass_with_roughness_maps_against_oracle(pt, ob, tmp_path):
+    """GlassMaterial with `uroughness` / `vroughness` float image textures (glass.cpp:60-92): `isSpecular = urough == 0 && vrough ==
+    0` is decided at the hit on the values before the remap -- FresnelSpecular there, MicrofacetReflection / MicrofacetTransmission
+    with the hit's alphas elsewhere; one axis or both, remapped and not, a black Kr or Kt. Exact mode."""
+    st.write_texture_files(str(tmp_path))
+    for lens in (False, True):
+        s = pt.Scene(text=st.glass_rough_scene(lens=lens), base_dir=str(tmp_path))
+        assert s.errors == []
+        glass = [s.desc.materials[i] for i in range(s.desc.n_materials) if s.desc.materials[i].kind == 2]
+        assert len(glass) == 4 and all(m.textured and (m.rough_flags & 2) and m.bxdf[0].type == 4 for m in glass)   # MI_ROUGH_GLASS; lobe 0 = FresnelSpecular
+        assert sorted(m.n_bxdfs for m in glass) == [2, 2, 3, 3]
+        film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "glass roughness maps lens=%s" % lens)
+    flat = st.glass_rough_scene(lens=True)
+    for name in ("r_b3", "r_t2"):
+        flat = flat.replace('"texture uroughness" "%s"' % name, '').replace('"texture vroughness" "%s"' % name, '')
+    fs = pt.Scene(text=flat, base_dir=str(tmp_path))
+    assert fs.errors == []
+    ff, _, _, _ = ob.render(fs)
+    assert _rel_l2(ff, ofilm) > 0.01
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
