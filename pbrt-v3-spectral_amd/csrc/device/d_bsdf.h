@@ -226,7 +226,10 @@ DEV IllumRGB MakeIllumRGB(const float rgb[3]) {
 template <int NL>
 struct LobeTexT {
     unsigned hasR, hasS, mulR, mulS;
-    unsigned rules;   // mi_lobe_rule of lobe i at bits 4i..4i+3 (the "disney" rules derive a lobe's spectrum from the colour)
+    unsigned hasK;    // bit i: lobe i ("metal", MI_LOBE_METAL) takes its k from the texture value kept in r[i] -- its R stays the constant
+    unsigned rules;   // mi_lobe_rule of lobe i at bits 4i..4i+3 (the "disney" rules derive a lobe's spectrum from the colour; read by
+                      // the eight-lobe instances only: a Disney material has more than four lobes, and inlined into every spectral
+                      // access of the two- and four-lobe instances the rule test cost the textured zoo 3.5 % of its shading time)
     float lum;        // "disney" with a textured colour: c.y() of the colour at this vertex
     IllumRGB r[NL], s[NL];
     const float *basis;     // rgbIllum2Spect{White..Blue}, [7][31]: FromRGB's default type is Illuminant (spectrum.h:428-429)
@@ -261,16 +264,17 @@ template <int NL>
 DEV float TexturedSpec(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int bin) {
     const float c = which ? b.S[bin] : b.R[bin];
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return c;
-    const int rule = (int)((lt.rules >> (4 * li)) & 15u);
-    if (rule == MI_LOBE_METAL && which == 0) return c;   // (the R slot carries k's texture: TexturedK)
     const float T = TexBin(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], bin);
-    if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS) return DisneyTexBin(rule, which, b.p, T, lt.lum);
+    if constexpr (NL == MI_MAX_BXDFS) {
+        const int rule = (int)((lt.rules >> (4 * li)) & 15u);
+        if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS) return DisneyTexBin(rule, which, b.p, T, lt.lum);
+    }
     return (((which ? lt.mulS : lt.mulR) >> li) & 1u) ? c * T : T;
 }
 // The conductor's absorption k at a bin: "metal" with an image-textured k keeps that texture in the lobe's R slot (MI_LOBE_METAL)
 template <int NL>
 DEV float TexturedK(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int bin) {
-    if (((lt.rules >> (4 * li)) & 15u) == (unsigned)MI_LOBE_METAL && ((lt.hasR >> li) & 1u)) return TexBin(lt.basis, lt.textures, lt.r[li], bin);
+    if ((lt.hasK >> li) & 1u) return TexBin(lt.basis, lt.textures, lt.r[li], bin);
     return b.K[bin];
 }
 
@@ -663,12 +667,13 @@ template <int NL>
 DEV float4 TexturedQuad(const LobeTexT<NL> &lt, const mi_bxdf &b, int li, int which, int c) {
     const float4 k = LoadSpec4(which ? b.S : b.R, c);
     if (!(((which ? lt.hasS : lt.hasR) >> li) & 1u)) return k;
-    const int rule = (int)((lt.rules >> (4 * li)) & 15u);
-    if (rule == MI_LOBE_METAL && which == 0) return k;   // (the R slot carries k's texture)
     const float4 T = TexQuad(lt.basis, lt.textures, which ? lt.s[li] : lt.r[li], c);
-    if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS)
-        return make_float4(DisneyTexBin(rule, which, b.p, T.x, lt.lum), DisneyTexBin(rule, which, b.p, T.y, lt.lum),
-                           DisneyTexBin(rule, which, b.p, T.z, lt.lum), DisneyTexBin(rule, which, b.p, T.w, lt.lum));
+    if constexpr (NL == MI_MAX_BXDFS) {
+        const int rule = (int)((lt.rules >> (4 * li)) & 15u);
+        if (rule >= MI_LOBE_DISNEY_SHEEN && rule <= MI_LOBE_DISNEY_STRANS)
+            return make_float4(DisneyTexBin(rule, which, b.p, T.x, lt.lum), DisneyTexBin(rule, which, b.p, T.y, lt.lum),
+                               DisneyTexBin(rule, which, b.p, T.z, lt.lum), DisneyTexBin(rule, which, b.p, T.w, lt.lum));
+    }
     if (((which ? lt.mulS : lt.mulR) >> li) & 1u) return make_float4(k.x * T.x, k.y * T.y, k.z * T.z, k.w * T.w);
     return T;
 }
@@ -842,7 +847,7 @@ DEV int AccumulateLobe(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL>
         if constexpr (TM_NEEDS_K(TM)) {
             float4 k4 = LoadSpec4(b.K, c);
             if constexpr ((TM & TM_TEXTURED) != 0) {   // "metal" with an image-textured k: its texture sits in the lobe's R slot
-                if (((lt->rules >> (4 * li)) & 15u) == (unsigned)MI_LOBE_METAL && ((lt->hasR >> li) & 1u)) k4 = TexQuad(lt->basis, lt->textures, lt->r[li], c);
+                if ((lt->hasK >> li) & 1u) k4 = TexQuad(lt->basis, lt->textures, lt->r[li], c);
             }
             Kv[0] = k4.x; Kv[1] = k4.y; Kv[2] = k4.z; Kv[3] = k4.w;
         }

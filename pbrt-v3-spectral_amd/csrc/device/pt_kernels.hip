@@ -1994,7 +1994,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                 // Material::ComputeScatteringFunctions with image textures: evaluate them at the hit, keep the lobes
                 // whose tested spectrum is not black (matte.cpp:55-63, plastic.cpp:52-68, uber.cpp:60-100, ...)
                 lt.hasR = lt.hasS = lt.mulR = lt.mulS = 0u;
-                lt.rules = 0u; lt.lum = 0.f;
+                lt.rules = 0u; lt.lum = 0.f; lt.hasK = 0u;
                 lt.basis = s.rgbIllum; lt.textures = s.textures;
                 ltp = &lt;
                 float u = 0.f, v = 0.f;
@@ -2060,7 +2060,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                         if (i >= NL) continue;
                         if (ltx.tex_R >= 0) {
                             lt.r[i] = EvalImageTexture(s, ltx.tex_R, u, v, td);
-                            lt.hasR |= 1u << i;
+                            if (ltx.rule == MI_LOBE_METAL) lt.hasK |= 1u << i;   // (k's texture: the lobe's R stays the constant)
+                            else lt.hasR |= 1u << i;
                             if (ltx.flags & MI_LOBE_TEX_MUL_R) lt.mulR |= 1u << i;
                         }
                         if (ltx.tex_S >= 0) {
@@ -3269,11 +3270,20 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         if (getenv("MIPT_NO_SPECIALISE")) pt->diffuseClasses = pt->plasticClasses = pt->glassClasses = 0;
         if (getenv("MIPT_ALL_LIGHTS")) pt->hasInfiniteLight = true;
         pt->smallClasses &= ~(pt->diffuseClasses | pt->plasticClasses | pt->glassClasses);
+        unsigned disneyTextured = 0u;
         for (int c = 0; c < MISS_CLASS; ++c)
             if (classTypes[c] & TM_TEXTURED) {
                 if (((pt->smallClasses >> c) & 1u) && !getenv("MIPT_NO_SPECIALISE")) {
                     if ((classTypes[c] & ~(TM_DIFFUSE | TM_TEXTURED)) == 0) { pt->texturedDiffuse |= 1u << c; pt->smallClasses &= ~(1u << c); }
                     else if ((classTypes[c] & ~(TM_PLASTIC | TM_TEXTURED)) == 0) { pt->texturedPlastic |= 1u << c; pt->smallClasses &= ~(1u << c); }
+                }
+                // (textured "disney" classes go to the eight-lobe instance whatever their lobe count: only that one reads the
+                // rules that form their spectra from the colour -- LobeTexT::rules, d_bsdf.h)
+                const unsigned disneyBits = (1u << MI_BXDF_DISNEY_DIFFUSE) | (1u << MI_BXDF_DISNEY_FAKE_SS) | (1u << MI_BXDF_DISNEY_RETRO) |
+                                            (1u << MI_BXDF_DISNEY_SHEEN) | (1u << MI_BXDF_DISNEY_CLEARCOAT) | (1u << (16 + MI_FRESNEL_DISNEY));
+                if (classTypes[c] & disneyBits) {
+                    if ((pt->smallClasses >> c) & 1u) { pt->smallClasses &= ~(1u << c); pt->largeClasses |= 1u << c; }
+                    disneyTextured |= 1u << c;
                 }
                 if ((pt->smallClasses >> c) & 1u) { pt->texturedSmall |= 1u << c; pt->smallClasses &= ~(1u << c); }
                 if ((pt->largeClasses >> c) & 1u) { pt->texturedLarge |= 1u << c; pt->largeClasses &= ~(1u << c); }
@@ -3288,7 +3298,7 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             for (int c = 0; c < MISS_CLASS; ++c)
                 if (classLobes[c] <= 4) {
                     if ((pt->largeClasses >> c) & 1u) { pt->mediumClasses |= 1u << c; pt->largeClasses &= ~(1u << c); }
-                    if ((pt->texturedLarge >> c) & 1u) { pt->texturedMedium |= 1u << c; pt->texturedLarge &= ~(1u << c); }
+                    if (((pt->texturedLarge & ~disneyTextured) >> c) & 1u) { pt->texturedMedium |= 1u << c; pt->texturedLarge &= ~(1u << c); }
                 }
     }
     // pre-gathered leaf records: positions of each BVH-ordered primitive + flags
