@@ -3003,6 +3003,22 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
                 g_err = "mi_material.rough_tex must name an image texture with a mipmap"; return MI_ERR_INVALID;
             }
         }
+        {   // (ABI v10) the sigma map, the lobe rules and the glass switch: what the shading kernels index with them
+            const mi_material &m = d->materials[i];
+            if (m.sigma_tex < -1 || m.sigma_tex >= (int)d->n_textures ||
+                (m.sigma_tex >= 0 && (d->textures[m.sigma_tex].type != MI_TEX_IMAGEMAP || (uint32_t)d->textures[m.sigma_tex].mipmap >= d->n_mipmaps))) {
+                g_err = "mi_material.sigma_tex must be -1 or name an image texture with a mipmap"; return MI_ERR_INVALID;
+            }
+            for (int k = 0; k < m.n_bxdfs; ++k) {
+                const mi_lobe_tex &lt = m.tex[k];
+                if (lt.rule < MI_LOBE_IF_R || lt.rule > MI_LOBE_METAL) { g_err = "mi_lobe_tex.rule is not a mi_lobe_rule"; return MI_ERR_INVALID; }
+                if (lt.tex_R < -1 || lt.tex_R >= (int)d->n_textures || lt.tex_S < -1 || lt.tex_S >= (int)d->n_textures) { g_err = "mi_lobe_tex texture index out of range"; return MI_ERR_INVALID; }
+                if (lt.rule >= MI_LOBE_DISNEY_SHEEN && lt.rule <= MI_LOBE_DISNEY_STRANS && lt.tex_R < 0) { g_err = "a \"disney\" lobe rule needs the colour's texture in tex_R"; return MI_ERR_INVALID; }
+            }
+            if ((m.rough_flags & MI_ROUGH_GLASS) && (m.n_bxdfs < 1 || m.bxdf[0].type != MI_BXDF_FRESNEL_SPECULAR)) {
+                g_err = "MI_ROUGH_GLASS: lobe 0 must be the FresnelSpecular one"; return MI_ERR_INVALID;
+            }
+        }
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const mi_light &l = d->lights[i];

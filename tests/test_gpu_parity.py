@@ -347,6 +347,19 @@ def test_create_rejects_malformed_descriptions(pt):
     assert pt.hip_lib().mi_pt_create(C.byref(d), 0, C.byref(h)) == -1
     assert b"ABI" in pt.hip_lib().mi_pt_last_error()
     assert pt.hip_lib().mi_pt_create(s.desc_ptr, 12345, C.byref(h)) == -2
+    # ABI v10 fields the shading kernels index with: a lobe rule that is none, a sigma map that is no texture, the glass switch on
+    # a material whose lobe 0 is not the FresnelSpecular one -- refused, and the scene still renders once they are put back
+    mats = (pt.Material * s.desc.n_materials).from_address(C.addressof(s.desc.materials.contents))
+    m = next(x for x in mats if x.n_bxdfs > 0)
+    for set_bad, undo, needle in ((lambda: setattr(m.tex[0], "rule", 42), lambda: setattr(m.tex[0], "rule", 0), b"mi_lobe_rule"),
+                                  (lambda: setattr(m, "sigma_tex", 7), lambda: setattr(m, "sigma_tex", -1), b"sigma_tex"),
+                                  (lambda: setattr(m, "rough_flags", 2), lambda: setattr(m, "rough_flags", 0), b"MI_ROUGH_GLASS")):
+        set_bad()
+        assert pt.hip_lib().mi_pt_create(s.desc_ptr, 0, C.byref(h)) == -1 and needle in pt.hip_lib().mi_pt_last_error()
+        undo()
+    integ = pt.CreatePathIntegrator(s)
+    film, weight = integ.Render()
+    assert np.isfinite(film).all() and weight.sum() > 0
 
 
 def test_killeroo_64spp_full_frame_reproduces_the_reference_counters(pt):
