@@ -228,7 +228,7 @@ bool ReadPNG(const std::string &filename, int *xres, int *yres, std::vector<RGB>
 }
 
 // ---- OpenEXR, the subset the reference's scenes use: single-part scan-line files, channels R / G / B (HALF or
-// FLOAT, sampling 1), compression NONE, RLE, ZIPS or ZIP. The reference reads through Imf::RgbaInputFile
+// FLOAT, sampling 1), compression NONE, RLE, ZIPS, ZIP or PIZ. The reference reads through Imf::RgbaInputFile
 // (imageio.cpp:121-160), whose frame buffer is HALF: FLOAT channels are rounded to half on the way in, missing colour
 // channels read as 0. Layout: OpenEXR file layout document ("Structure of a scan-line file", "Predictor and
 // reordering" for the zip / rle codecs).
@@ -269,6 +269,176 @@ inline uint16_t FloatToHalf(float f) {   // round to nearest even, as half(float
     if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;    // a carry runs into the exponent, up to infinity
     return (uint16_t)(sign | h);
 }
+
+// ---- PIZ (compression 4): a 16-bit wavelet transform of each channel of a 32-line block, the values first mapped onto a dense range
+// through a bitmap of the values that occur, then Huffman-coded. Written from the published description of the format (OpenEXR
+// technical introduction, "PIZ"; the reference reads it through the OpenEXR library, which this image does not hold -- there is no
+// PIZ file from another writer here, so this reader is pinned by a round trip with the test suite's own writer only).
+namespace piz {
+constexpr int kEncSize = (1 << 16) + 1;   // symbols 0..65535 and the run-length marker
+struct BitReader {
+    const unsigned char *p, *end;
+    uint64_t c = 0;
+    int lc = 0;
+    bool ok = true;
+    unsigned Get(int n) {   // most significant bit first
+        while (lc < n) { if (p >= end) { ok = false; return 0; } c = (c << 8) | *p++; lc += 8; }
+        lc -= n;
+        return (unsigned)((c >> lc) & ((1ull << n) - 1));
+    }
+};
+// code lengths -> canonical codes: the longest codes are numbered from 0, each shorter length starts at half of where the longer
+// one ended; codes of one length go to the symbols in increasing order
+inline void CanonicalCodes(const std::vector<unsigned char> &len, uint64_t base[59], unsigned count[59]) {
+    for (int i = 0; i < 59; ++i) { base[i] = 0; count[i] = 0; }
+    for (unsigned char l : len) ++count[l];
+    uint64_t c = 0;
+    for (int i = 58; i > 0; --i) { const uint64_t nc = (c + count[i]) >> 1; base[i] = c; c = nc; }
+}
+// Huffman-coded 16-bit values. Layout: im, iM (first and last symbol with a code), table length, number of data bits, a reserved
+// word (five little-endian 32-bit words), the code lengths of symbols im..iM in 6 bits each (59..62: a run of 2..5 zero lengths;
+// 63: a run of 6 + the next 8 bits), then the data. The symbol iM is the run-length marker: the 8 bits behind it repeat the
+// previous value that many times.
+inline bool HufDecode(const unsigned char *in, size_t nIn, uint16_t *out, size_t nOut) {
+    if (nIn == 0) return nOut == 0;
+    if (nIn < 20) return false;
+    auto u32 = [&](size_t o) { return (uint32_t)in[o] | ((uint32_t)in[o + 1] << 8) | ((uint32_t)in[o + 2] << 16) | ((uint32_t)in[o + 3] << 24); };
+    const uint32_t im = u32(0), iM = u32(4), nBits = u32(12);
+    if (im >= (uint32_t)kEncSize || iM >= (uint32_t)kEncSize || im > iM) return false;
+    std::vector<unsigned char> len(kEncSize, 0);
+    BitReader tr{in + 20, in + nIn};
+    for (uint32_t i = im; i <= iM; ++i) {
+        const unsigned l = tr.Get(6);
+        if (!tr.ok) return false;
+        if (l == 63 || l >= 59) {
+            const unsigned run = l == 63 ? tr.Get(8) + 6 : l - 59 + 2;
+            if (!tr.ok || i + run > iM + 1) return false;
+            i += run - 1;   // (the lengths stay 0)
+        } else len[i] = (unsigned char)l;
+    }
+    const unsigned char *data = tr.p;   // (the table ends on a byte boundary: what is left in the reader's last byte is padding)
+    if ((uint64_t)nBits > 8ull * (uint64_t)(in + nIn - data)) return false;
+    uint64_t base[59];
+    unsigned count[59];
+    CanonicalCodes(len, base, count);
+    std::vector<uint32_t> first(60, 0);            // symbols by length, in increasing order
+    for (int l = 1; l < 59; ++l) first[l + 1] = first[l] + count[l];
+    std::vector<uint32_t> syms(first[59]), fill(first.begin(), first.end());
+    for (uint32_t i = im; i <= iM; ++i) if (len[i]) syms[fill[len[i]]++] = i;
+    BitReader br{data, in + nIn};
+    uint64_t left = nBits;
+    size_t o = 0;
+    while (left > 0) {
+        uint64_t code = 0;
+        int l = 0;
+        uint32_t sym = 0;
+        bool found = false;
+        while (l < 58 && left > 0) {
+            code = (code << 1) | br.Get(1);
+            --left; ++l;
+            if (!br.ok) return false;
+            if (count[l] && code >= base[l] && code - base[l] < count[l]) { sym = syms[first[l] + (uint32_t)(code - base[l])]; found = true; break; }
+        }
+        if (!found) return false;
+        if (sym == iM) {   // run-length marker
+            if (left < 8 || o == 0) return false;
+            const unsigned run = br.Get(8);
+            left -= 8;
+            if (!br.ok || o + run > nOut) return false;
+            for (unsigned k = 0; k < run; ++k, ++o) out[o] = out[o - 1];
+        } else {
+            if (o >= nOut) return false;
+            out[o++] = (uint16_t)sym;
+        }
+    }
+    return o == nOut;
+}
+// the inverse of the two-value lifting step, for data below 2^14 (wdec14) and for the full 16-bit range (wdec16, modulo arithmetic)
+inline void Wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int16_t ls = (int16_t)l, hs = (int16_t)h;
+    const int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t)(int16_t)ai; b = (uint16_t)(int16_t)(ai - hi);
+}
+inline void Wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    const int aa = (d + bb - 0x8000) & 0xffff;
+    b = (uint16_t)bb; a = (uint16_t)aa;
+}
+// 2D wavelet decoding of nx x ny values at strides ox, oy, from the coarsest level down
+inline void Wav2Decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { if (w14) Wdec14(l, h, a, b); else Wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) { uint16_t *p10 = px + oy1; dec(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1; dec(*px, *p01, i00, *p01); *px = i00; }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+// One block: `raw` receives the scan lines as an uncompressed file stores them (per line, per channel, its pixels).
+// chSize[c]: 16-bit words per pixel of channel c (HALF 1, FLOAT / UINT 2).
+inline bool Decompress(const unsigned char *in, size_t nIn, const std::vector<int> &chSize, int w, int nLines, unsigned char *raw) {
+    size_t total = 0;
+    for (int sz : chSize) total += (size_t)w * nLines * sz;
+    if (nIn < 4) return false;
+    const unsigned minNonZero = in[0] | (in[1] << 8), maxNonZero = in[2] | (in[3] << 8);
+    if (maxNonZero >= 8192) return false;
+    std::vector<unsigned char> bitmap(8192, 0);
+    size_t pos = 4;
+    if (minNonZero <= maxNonZero) {
+        const size_t nb = maxNonZero - minNonZero + 1;
+        if (pos + nb > nIn) return false;
+        memcpy(&bitmap[minNonZero], in + pos, nb);
+        pos += nb;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    unsigned k = 0;
+    for (unsigned i = 0; i < 65536; ++i) if (i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t maxValue = (uint16_t)(k - 1);
+    if (pos + 4 > nIn) return false;
+    const uint32_t length = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+    pos += 4;
+    if ((size_t)length > nIn - pos) return false;
+    std::vector<uint16_t> tmp(total);
+    if (!HufDecode(in + pos, length, tmp.data(), total)) return false;
+    std::vector<size_t> start(chSize.size());
+    size_t o = 0;
+    for (size_t c = 0; c < chSize.size(); ++c) {
+        start[c] = o;
+        for (int j = 0; j < chSize[c]; ++j) Wav2Decode(&tmp[o + j], w, chSize[c], nLines, w * chSize[c], maxValue);
+        o += (size_t)w * nLines * chSize[c];
+    }
+    for (uint16_t &v : tmp) v = lut[v];
+    unsigned char *dst = raw;
+    for (int y = 0; y < nLines; ++y)
+        for (size_t c = 0; c < chSize.size(); ++c) {
+            const size_t n = (size_t)w * chSize[c];
+            const uint16_t *src = &tmp[start[c] + (size_t)y * n];
+            for (size_t i = 0; i < n; ++i) { dst[0] = (unsigned char)(src[i] & 0xff); dst[1] = (unsigned char)(src[i] >> 8); dst += 2; }
+        }
+    return true;
+}
+}  // namespace piz
 
 bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB> *out, std::string *err) {
     std::vector<unsigned char> f;
@@ -319,8 +489,8 @@ bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB>
     if (wl <= 0 || hl <= 0 || wl > 65536 || hl > 65536 || channels.empty() || channels.size() > 64) return fail("bad header");
     const int w = (int)wl, h = (int)hl;
     int linesPerBlock;
-    switch (compression) { case 0: case 1: case 2: linesPerBlock = 1; break; case 3: linesPerBlock = 16; break;
-                           default: return fail("compression method " + std::to_string(compression) + " (PIZ, PXR24, B44, DWA) is not read by this build"); }
+    switch (compression) { case 0: case 1: case 2: linesPerBlock = 1; break; case 3: linesPerBlock = 16; break; case 4: linesPerBlock = 32; break;
+                           default: return fail("compression method " + std::to_string(compression) + " (PXR24, B44, DWA) is not read by this build"); }
     size_t lineBytes = 0;
     std::vector<size_t> chOffset(channels.size());
     for (size_t c = 0; c < channels.size(); ++c) {
@@ -352,7 +522,11 @@ bool ReadEXR(const std::string &filename, int *xres, int *yres, std::vector<RGB>
         const unsigned char *data = &f[off + 8];
         if (compression == 0 && (size_t)dataSize != rawSize) return fail("truncated chunk");
         if (compression == 0 || (size_t)dataSize == rawSize) memcpy(raw.data(), data, rawSize);
-        else {
+        else if (compression == 4) {
+            std::vector<int> chSize(channels.size());
+            for (size_t c = 0; c < channels.size(); ++c) chSize[c] = channels[c].type == 1 ? 1 : 2;
+            if (!piz::Decompress(data, (size_t)dataSize, chSize, w, nLines, raw.data())) return fail("bad PIZ data");
+        } else {
             tmp.resize(rawSize);
             if (compression == 1) {   // run-length
                 size_t o = 0, i = 0;

@@ -999,7 +999,167 @@ def random_scene(seed, res=32, spp=8):
     return "\n".join(out) + "\n"
 
 
-def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0, 0)):
+def _piz_wav2_encode(a, nx, ox, ny, oy, mx):
+    """2D wavelet encoding in place (list of ints), finest level first: the inverse of the reader's Wav2Decode."""
+    w14 = mx < (1 << 14)
+
+    def s16(v):
+        v &= 0xffff
+        return v - 0x10000 if v & 0x8000 else v
+
+    def enc(x, y):
+        if w14:
+            a_, b_ = s16(x), s16(y)
+            return ((a_ + b_) >> 1) & 0xffff, (a_ - b_) & 0xffff
+        ao = (x + 0x8000) & 0xffff
+        m = (ao + y) >> 1
+        d = ao - y
+        if d < 0:
+            m = (m + 0x8000) & 0xffff
+        return m & 0xffff, d & 0xffff
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        py, ey = 0, oy * (ny - p2)
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        while py <= ey:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01, p10, p11 = px + ox1, px + oy1, px + oy1 + ox1
+                i00, i01 = enc(a[px], a[p01])
+                i10, i11 = enc(a[p10], a[p11])
+                a[px], a[p10] = enc(i00, i10)
+                a[p01], a[p11] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                p10 = px + oy1
+                i00, a[p10] = enc(a[px], a[p10])
+                a[px] = i00
+            py += oy2
+        if ny & p:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01 = px + ox1
+                i00, a[p01] = enc(a[px], a[p01])
+                a[px] = i00
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def _piz_huf_compress(vals):
+    """Huffman coding of 16-bit values in the layout the reader's HufDecode takes: canonical codes from code lengths, a run-length
+    marker symbol one past the largest value, the table of 6-bit lengths with zero runs."""
+    import heapq, struct
+    from collections import Counter
+    freq = Counter(vals)
+    im, iM = min(freq), max(freq) + 1
+    freq[iM] = 1   # the run-length marker
+    heap = [(f, s, (s,)) for s, f in freq.items()]
+    heapq.heapify(heap)
+    length = {s: 0 for s in freq}
+    if len(heap) == 1:
+        length[heap[0][1]] = 1
+    while len(heap) > 1:
+        f1, s1, g1 = heapq.heappop(heap)
+        f2, s2, g2 = heapq.heappop(heap)
+        for s_ in g1 + g2:
+            length[s_] += 1
+        heapq.heappush(heap, (f1 + f2, min(s1, s2), g1 + g2))
+    assert max(length.values()) <= 58
+    count = [0] * 59
+    for l in length.values():
+        count[l] += 1
+    base, c = [0] * 59, 0
+    for i in range(58, 0, -1):
+        nc = (c + count[i]) >> 1
+        base[i] = c
+        c = nc
+    code, nxt = {}, list(base)
+    for s_ in sorted(length):
+        l = length[s_]
+        code[s_] = (nxt[l], l)
+        nxt[l] += 1
+    bits = []   # (value, width) pairs, most significant bit first
+
+    def flush(pairs):
+        acc, n, out = 0, 0, bytearray()
+        for v, wdt in pairs:
+            acc = (acc << wdt) | v
+            n += wdt
+            while n >= 8:
+                out.append((acc >> (n - 8)) & 0xff)
+                n -= 8
+            acc &= (1 << n) - 1
+        if n:
+            out.append((acc << (8 - n)) & 0xff)
+        return bytes(out), sum(wdt for _, wdt in pairs)
+    table, i = [], im
+    while i <= iM:
+        l = length.get(i, 0)
+        if l == 0:
+            run = 1
+            while i + run <= iM and length.get(i + run, 0) == 0 and run < 261:
+                run += 1
+            if run >= 6:
+                table += [(63, 6), (run - 6, 8)]
+            elif run >= 2:
+                table.append((59 + run - 2, 6))
+            else:
+                table.append((0, 6))
+            i += run
+        else:
+            table.append((l, 6))
+            i += 1
+    tbytes, _ = flush(table)
+    i = 0
+    while i < len(vals):
+        run = 1
+        while i + run < len(vals) and vals[i + run] == vals[i] and run < 256:
+            run += 1
+        bits.append(code[vals[i]])
+        if run >= 4:
+            bits += [code[iM], (run - 1, 8)]
+            i += run
+        else:
+            i += 1
+    dbytes, nbits = flush(bits)
+    return struct.pack("<IIIII", im, iM, len(tbytes), nbits, 0) + tbytes + dbytes
+
+
+def _piz_compress(planes, nx, ny, size):
+    """planes: per channel the block's 16-bit words (numpy uint16, [ny][nx * size]); size = words per pixel."""
+    import struct
+    import numpy as np
+    allv = np.concatenate(planes)
+    bitmap = np.zeros(8192, np.uint8)
+    present = np.unique(allv)
+    for v in present:
+        bitmap[v >> 3] |= 1 << (v & 7)
+    bitmap[0] &= 0xfe   # (zero is always there)
+    nz = np.nonzero(bitmap)[0]
+    lo, hi = (int(nz[0]), int(nz[-1])) if len(nz) else (8191, 0)
+    lut = np.zeros(65536, np.int64)
+    k = 0
+    for i in range(65536):
+        if i == 0 or (bitmap[i >> 3] & (1 << (i & 7))):
+            lut[i] = k
+            k += 1
+    maxv = k - 1
+    vals = []
+    for pl in planes:
+        a = [int(lut[v]) for v in pl]
+        for j in range(size):
+            sub = a[j::size] if size > 1 else a
+            _piz_wav2_encode(sub, nx, 1, ny, nx, maxv)
+            if size > 1:
+                a[j::size] = sub
+        vals += a
+    huf = _piz_huf_compress(vals)
+    head = struct.pack("<HH", lo, hi) + (bitmap[lo:hi + 1].tobytes() if lo <= hi else b"")
+    return head + struct.pack("<i", len(huf)) + huf
+
+
+def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0, 0), keep_larger=False):
     """Minimal scan-line OpenEXR writer for tests: img [h, w, 3] float; channels B, G, R (alphabetical, as the format wants)
     as HALF or FLOAT; compression "none", "zips" (1 line per chunk) or "zip" (16 lines per chunk)."""
     import struct, zlib
@@ -1007,8 +1167,8 @@ def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0,
     h, w, _ = img.shape
     px = img.astype(np.float16 if dtype == "half" else np.float32)
     ptype = 1 if dtype == "half" else 2
-    comp = {"none": 0, "zips": 2, "zip": 3}[compression]
-    lines_per = 16 if comp == 3 else 1
+    comp = {"none": 0, "zips": 2, "zip": 3, "piz": 4}[compression]
+    lines_per = 32 if comp == 4 else (16 if comp == 3 else 1)
     x0, y0 = data_window_origin
 
     def attr(name, typ, data):
@@ -1022,7 +1182,14 @@ def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0,
     for c0 in range(0, h, lines_per):
         raw = b"".join(px[y, :, k].tobytes() for y in range(c0, min(c0 + lines_per, h)) for k in (2, 1, 0))
         data = raw
-        if comp:
+        if comp == 4:
+            nl = min(c0 + lines_per, h) - c0
+            size = 1 if dtype == "half" else 2
+            # the block as PIZ wants it: channel by channel, its lines, 16-bit words
+            planes = [np.frombuffer(b"".join(px[y, :, k].tobytes() for y in range(c0, c0 + nl)), np.uint16).copy() for k in (2, 1, 0)]
+            z = _piz_compress(planes, w, nl, size)
+            data = z if (len(z) < len(raw) or (keep_larger and len(z) != len(raw))) else raw   # (keep_larger: tests of the decoder on data that does not shrink)
+        elif comp:
             t = np.frombuffer(raw, np.uint8)
             re = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)
             d = re.copy()

@@ -700,7 +700,7 @@ def test_parallel_bvh_build_is_the_serial_tree(pt, tmp_path, monkeypatch):
 
 def test_exr_images_are_read_like_rgba_input_file(pt, tmp_path):
     """ReadImageEXR (imageio.cpp:121-160) goes through Imf::RgbaInputFile: HALF frame buffer, so FLOAT channels are rounded to
-    half; scan-line files with no / ZIPS / ZIP compression, a data window that does not start at 0; PIZ is reported."""
+    half; scan-line files with no / ZIPS / ZIP compression, a data window that does not start at 0; PXR24 is reported."""
     rng = np.random.default_rng(4)
     img = (rng.random((20, 16, 3)) ** 3 * 50).astype(np.float32)
     img[3, 5] = [1e-6, 65000.0, 7e4]     # a subnormal half, near the top of the range, beyond it (-> inf)
@@ -732,10 +732,47 @@ def test_exr_images_are_read_like_rgba_input_file(pt, tmp_path):
     assert s.errors == [] and (s.desc.envmaps[0].width, s.desc.envmaps[0].height) == (16, 32)
     # unsupported compression is an error, not garbage
     raw = bytearray(open(tmp_path / "t0.exr", "rb").read())
-    raw[raw.index(b"compression\0compression\0") + 28] = 4   # PIZ
-    open(tmp_path / "piz.exr", "wb").write(bytes(raw))
-    s = pt.Scene(text=head + 'Texture "z" "spectrum" "imagemap" "string filename" "piz.exr"\nWorldEnd\n', base_dir=str(tmp_path))
-    assert any("compression method 4" in e for e in s.errors)
+    raw[raw.index(b"compression\0compression\0") + 28] = 5   # PXR24
+    open(tmp_path / "pxr.exr", "wb").write(bytes(raw))
+    s = pt.Scene(text=head + 'Texture "z" "spectrum" "imagemap" "string filename" "pxr.exr"\nWorldEnd\n', base_dir=str(tmp_path))
+    assert any("compression method 5" in e for e in s.errors)
+
+
+def test_piz_exr_round_trip_with_the_tests_own_writer(pt, tmp_path):
+    """PIZ-compressed scan-line files (imageio.cpp:126-197 reads them through the OpenEXR library): value bitmap + look-up table,
+    2D wavelet (the 14-bit and the 16-bit lifting steps), canonical Huffman codes with zero runs in the table and run-length
+    marks in the data. No PIZ file from another writer exists in this image: the reader is checked against tests/scenes_text.py's
+    writer (written from the same description of the format) -- the pixels that come back are the ZIP file's, bit for bit."""
+    rng = np.random.default_rng(11)
+    head = 'Camera "perspective"\nWorldBegin\n'
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+
+    def level0(fn):
+        s = pt.Scene(text=head + 'Texture "p" "spectrum" "imagemap" "string filename" "%s"\nMaterial "matte" "texture Kd" "p"\n' % fn + tri + "WorldEnd\n",
+                     base_dir=str(tmp_path))
+        assert s.errors == [], s.errors
+        m = s.desc.mipmaps[0]
+        return np.ctypeslib.as_array(m.texels, (m.width * m.height * 3,)).copy(), (m.width, m.height)
+    y, x = np.mgrid[0:45, 0:29]
+    smooth = np.stack([np.sin(x / 5.) + 1.2 + y * .01, (x + y) / 60., np.where((x // 4 + y // 4) % 2 == 0, .7, .1)], -1).astype(np.float32)
+    smooth[5:9, 3:20] = .25                                        # runs of equal values (run-length marks), odd sizes, two blocks
+    noisy = (10.0 ** rng.uniform(-4, 4, (36, 600, 3))).astype(np.float32)   # > 2^14 distinct values in a block: the 16-bit lifting step
+    assert len(np.unique(noisy[:32].astype(np.float16).view(np.uint16))) > (1 << 14)
+    cases = [("smooth", smooth, "half"), ("noisy", noisy, "half"), ("floats", smooth[:33, :17], "float")]
+    for name, img, dt in cases:
+        st.write_exr(str(tmp_path / (name + "_piz.exr")), img, compression="piz", dtype=dt, keep_larger=True)
+        st.write_exr(str(tmp_path / (name + "_zip.exr")), img, compression="zip", dtype=dt)
+        assert open(tmp_path / (name + "_piz.exr"), "rb").read(4096).count(b"compression\0compression\0\x01\0\0\0\x04") == 1
+        a, sa = level0(name + "_piz.exr")
+        b, sb = level0(name + "_zip.exr")
+        assert sa == sb and np.array_equal(a, b), name
+    # a damaged stream is an error, not garbage
+    raw = bytearray(open(tmp_path / "smooth_piz.exr", "rb").read())
+    raw[-40] ^= 0x5a
+    open(tmp_path / "bad.exr", "wb").write(bytes(raw))
+    s = pt.Scene(text=head + 'Texture "z" "spectrum" "imagemap" "string filename" "bad.exr"\nWorldEnd\n', base_dir=str(tmp_path))
+    a_bad = s.errors
+    assert a_bad == [] or any("PIZ" in e for e in a_bad)   # (a flipped bit may still decode to the right number of values)
 
 
 def test_exr_float_channels_round_to_half_like_numpy(pt, tmp_path):

@@ -9,12 +9,15 @@ st.write_tga(os.path.join(d,'a.tga'), img, rle=True)
 st.write_tga(os.path.join(d,'b.tga'), img, rle=False)
 st.write_exr(os.path.join(d,'a.exr'), img.astype(np.float32)/255, compression='zip', dtype='half')
 st.write_exr(os.path.join(d,'b.exr'), img.astype(np.float32)/255, compression='none', dtype='float')
+big=np.tile(img.astype(np.float32)/255, (5,1,1))[:37,:15]   # two PIZ blocks, odd sizes
+st.write_exr(os.path.join(d,'c.exr'), big, compression='piz', dtype='half', keep_larger=True)
+st.write_exr(os.path.join(d,'d.exr'), big[:9], compression='piz', dtype='float', keep_larger=True)
 with open(os.path.join(d,'a.pfm'),'wb') as f:
     f.write(b"PF\n16 8\n-1.0\n"); f.write((img.astype(np.float32)/255).tobytes())
 rnd=random.Random(1)
 scene='Camera "perspective"\nWorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "%s"\nLightSource "infinite" "string mapname" "%s"\nWorldEnd\n'
 n=0
-for name in ('a.png','a.tga','b.tga','a.exr','b.exr','a.pfm'):
+for name in ('a.png','a.tga','b.tga','a.exr','b.exr','c.exr','d.exr','a.pfm'):
     data=open(os.path.join(d,name),'rb').read()
     ext=name.split('.')[-1]
     for it in range(400):
@@ -23,7 +26,7 @@ for name in ('a.png','a.tga','b.tga','a.exr','b.exr','a.pfm'):
         if mode<0.3: b=b[:rnd.randrange(0,len(b))]
         else:
             for _ in range(rnd.randrange(1,6)):
-                i=rnd.randrange(0,min(len(b), 120 if rnd.random()<0.6 else len(b)))
+                i=rnd.randrange(0,min(len(b), 120 if rnd.random()<0.4 else len(b)))
                 b[i]=rnd.randrange(256)
         fn='m.'+ext
         open(os.path.join(d,fn),'wb').write(bytes(b))
