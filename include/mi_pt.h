@@ -132,12 +132,14 @@ typedef struct mi_bxdf {
     int32_t type;    /* mi_bxdf_type */
     int32_t flags;   /* BxDFType bits */
     int32_t fresnel; /* mi_fresnel_type (reflection lobes) */
-    int32_t scaled;  /* != 0: the lobe is wrapped in a ScaledBxDF (mix material): f = scale * f (reflection.cpp:96-107) */
+    int32_t scaled;  /* the number of ScaledBxDF wrappers around the lobe (mix materials, reflection.cpp:96-107): 1: f = scale * f;
+                        2 (ABI v10, a "mix" of a "mix"): f = scale2 * (scale * f) */
     float p[8];
     float R[MI_NSPEC];
     float S[MI_NSPEC];
     float K[MI_NSPEC];     /* conductor absorption k */
     float scale[MI_NSPEC]; /* ScaledBxDF::scale */
+    float scale2[MI_NSPEC]; /* the outer ScaledBxDF's scale when scaled == 2 */
 } mi_bxdf;
 
 /* A lobe whose spectrum comes from an image texture (ABI v5). The lobe list of a material stays fixed; at a hit the

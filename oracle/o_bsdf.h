@@ -217,11 +217,15 @@ struct BxDF {
     }
 
     // ScaledBxDF (mix material), reflection.cpp:96-111
-    Spec f(const V3 &wo, const V3 &wi) const { return b->scaled ? Scale() * fInner(wo, wi) : fInner(wo, wi); }
+    // (scaled == 2: a "mix" of a "mix", ScaledBxDF(ScaledBxDF(lobe, scale), scale2))
+    Spec Scaled(const Spec &v) const {
+        if (!b->scaled) return v;
+        const Spec v1 = Scale() * v;
+        return b->scaled >= 2 ? Spec::From(b->scale2) * v1 : v1;
+    }
+    Spec f(const V3 &wo, const V3 &wi) const { return Scaled(fInner(wo, wi)); }
     Spec Sample_f(const V3 &wo, V3 *wi, const Float u[2], Float *pdf, int *sampledType) const {
-        if (!b->scaled) return Sample_fInner(wo, wi, u, pdf, sampledType);
-        Spec v = Sample_fInner(wo, wi, u, pdf, sampledType);
-        return Scale() * v;
+        return Scaled(Sample_fInner(wo, wi, u, pdf, sampledType));
     }
 
     Spec fInner(const V3 &wo, const V3 &wi) const {

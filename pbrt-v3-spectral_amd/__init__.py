@@ -51,7 +51,7 @@ class Sphere(C.Structure):
 class Bxdf(C.Structure):
     _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("fresnel", C.c_int32), ("scaled", C.c_int32),
                 ("p", C.c_float * 8), ("R", C.c_float * NSPEC), ("S", C.c_float * NSPEC),
-                ("K", C.c_float * NSPEC), ("scale", C.c_float * NSPEC)]
+                ("K", C.c_float * NSPEC), ("scale", C.c_float * NSPEC), ("scale2", C.c_float * NSPEC)]
 
 
 class LobeTex(C.Structure):

@@ -359,12 +359,15 @@ DEV float LobeValueInner(const LobeEval &le, const mi_bxdf *bx, int bin, const L
     }
     return LobeValueCore<TM>(le, R, Sv, Kv);
 }
-// bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107)
+// bit 9 of le.lobe: the lobe is wrapped in a ScaledBxDF (mix material), f = scale * f (reflection.cpp:96-107); bit 10: in two of
+// them (a "mix" of a "mix"), f = scale2 * (scale * f)
 template <int NL, unsigned TM>
 DEV float LobeValue(const LobeEval &le, const mi_bxdf *bx, int bin, const LobeTexT<NL> *lt) {
     const float v = LobeValueInner<NL, TM>(le, bx, bin, lt);
     if constexpr ((TM & TM_SCALED) == 0) return v;
-    return (le.lobe & 0x200) ? bx[le.lobe & 0xff].scale[bin] * v : v;
+    if (!(le.lobe & 0x200)) return v;
+    const float v1 = bx[le.lobe & 0xff].scale[bin] * v;
+    return (le.lobe & 0x400) ? bx[le.lobe & 0xff].scale2[bin] * v1 : v1;
 }
 
 // Microfacet roughness from float textures ("texture roughness" / "uroughness" / "vroughness": plastic.cpp:57-62,
@@ -413,7 +416,7 @@ DEV TRDist DistOf(const mi_bxdf &b, const AlphaOv &ov) {
 template <unsigned TM>
 DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const AlphaOv &ov) {
     LobeEval le;
-    le.kind = LK_NONE; le.lobe = i | (b.scaled ? 0x200 : 0); le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
+    le.kind = LK_NONE; le.lobe = i | (b.scaled ? 0x200 : 0) | (b.scaled >= 2 ? 0x400 : 0); le.a = le.b = le.c = le.d = le.e = le.f = le.r = 0;
     switch (b.type) {
     case MI_BXDF_FRESNEL_BLEND: if constexpr (TM_HAS(TM, MI_BXDF_FRESNEL_BLEND)) {  // reflection.cpp:285-298
         V3 wh = wi + wo;
@@ -684,16 +687,16 @@ DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c, const Lob
         return make_float4(EvalBin<NL, TM>(ev, bx, b, lt), EvalBin<NL, TM>(ev, bx, b + 1, lt), EvalBin<NL, TM>(ev, bx, b + 2, lt),
                            (b + 3 < MI_NSPEC) ? EvalBin<NL, TM>(ev, bx, b + 3, lt) : 0.f);
     }
-    float4 R[NL], Sv[NL], Kv[NL], Sc[NL];
+    float4 R[NL], Sv[NL], Kv[NL], Sc[NL], Sc2[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        R[i] = Sv[i] = Kv[i] = Sc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        R[i] = Sv[i] = Kv[i] = Sc[i] = Sc2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < ev.n) {
             const int lobe = ev.lobes[i].lobe, li = lobe & 0xff;
             R[i] = LoadSpec4((lobe & 0x100) ? bx[li].S : bx[li].R, c);
             if constexpr (TM_NEEDS_S(TM)) Sv[i] = LoadSpec4(bx[li].S, c);
             if constexpr (TM_NEEDS_K(TM)) Kv[i] = LoadSpec4(bx[li].K, c);
-            if constexpr ((TM & TM_SCALED) != 0) { if (lobe & 0x200) Sc[i] = LoadSpec4(bx[li].scale, c); }
+            if constexpr ((TM & TM_SCALED) != 0) { if (lobe & 0x200) Sc[i] = LoadSpec4(bx[li].scale, c); if (lobe & 0x400) Sc2[i] = LoadSpec4(bx[li].scale2, c); }
         }
     }
     float f[4];
@@ -704,7 +707,7 @@ DEV float4 EvalQuad(const BSDFEvalT<NL> &ev, const mi_bxdf *bx, int c, const Lob
         for (int i = 0; i < NL; ++i)
             if (i < ev.n) {
                 float v = LobeValueCore<TM>(ev.lobes[i], Quad(R[i], k), Quad(Sv[i], k), Quad(Kv[i], k));
-                if constexpr ((TM & TM_SCALED) != 0) { if (ev.lobes[i].lobe & 0x200) v = Quad(Sc[i], k) * v; }
+                if constexpr ((TM & TM_SCALED) != 0) { if (ev.lobes[i].lobe & 0x200) v = Quad(Sc[i], k) * v; if (ev.lobes[i].lobe & 0x400) v = Quad(Sc2[i], k) * v; }
                 f[k] += v;
             }
     }
@@ -852,12 +855,16 @@ DEV int AccumulateLobe(const LobeEval &le, const mi_bxdf *bx, const LobeTexT<NL>
             Kv[0] = k4.x; Kv[1] = k4.y; Kv[2] = k4.z; Kv[3] = k4.w;
         }
         const bool scaled = (TM & TM_SCALED) != 0 && (le.lobe & 0x200);
+        const bool scaled2 = scaled && (le.lobe & 0x400);
+        float Sc2[4] = {1.f, 1.f, 1.f, 1.f};
         if (scaled) { const float4 c4 = LoadSpec4(b.scale, c); Sc[0] = c4.x; Sc[1] = c4.y; Sc[2] = c4.z; Sc[3] = c4.w; }
+        if (scaled2) { const float4 c4 = LoadSpec4(b.scale2, c); Sc2[0] = c4.x; Sc2[1] = c4.y; Sc2[2] = c4.z; Sc2[3] = c4.w; }
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[k] = LobeValueCore<TM>(le, R[k], Sv[k], Kv[k]);
             if (scaled) v[k] = Sc[k] * v[k];
+            if (scaled2) v[k] = Sc2[k] * v[k];
         }
         if (c == 7) v[3] = 0.f;   // bin 31 does not exist
         acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
@@ -920,7 +927,7 @@ DEV bool BSDF_Sample_f(const BSDFFrame &fr, const V3 &woWorld, V3 *wiWorld, floa
     *pdf = 0;
     *sampledType = b.flags;
     LobeEval spec;
-    spec.kind = LK_NONE; spec.lobe = bi | (b.scaled ? 0x200 : 0); spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
+    spec.kind = LK_NONE; spec.lobe = bi | (b.scaled ? 0x200 : 0) | (b.scaled >= 2 ? 0x400 : 0); spec.a = spec.b = spec.c = spec.d = spec.e = spec.f = spec.r = 0;
     bool isSpecular = (b.flags & MI_BSDF_SPECULAR) != 0;
     switch (b.type) {
     case MI_BXDF_SPECULAR_REFLECTION: if constexpr (TM_HAS(TM, MI_BXDF_SPECULAR_REFLECTION)) {  // (F*R)/|cos|

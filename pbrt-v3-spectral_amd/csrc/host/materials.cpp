@@ -450,9 +450,9 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
                 errs->push_back("a \"mix\" of bump-mapped or roughness-mapped materials is outside the hot-path scope");
                 return false;
             }
-            if (b.scaled) { errs->push_back("a \"mix\" of \"mix\" materials (nested ScaledBxDF) is not built on this path"); return false; }
-            b.scaled = 1;
-            for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j];
+            if (b.scaled >= 2) { errs->push_back("a \"mix\" of a \"mix\" of \"mix\" materials (three nested ScaledBxDFs) is not built on this path"); return false; }
+            if (b.scaled == 1) { b.scaled = 2; for (int j = 0; j < MI_NSPEC; ++j) b.scale2[j] = sc[k]->c[j]; }   // ScaledBxDF(ScaledBxDF(lobe, inner), outer)
+            else { b.scaled = 1; for (int j = 0; j < MI_NSPEC; ++j) b.scale[j] = sc[k]->c[j]; }
             if (!Add(out, b, errs)) return false;
             out->tex[out->n_bxdfs - 1] = src[k]->tex[i];
             if (src[k]->tex[i].tex_R >= 0 || src[k]->tex[i].tex_S >= 0) out->textured = 1;

@@ -757,6 +757,41 @@ def glass_rough_scene(res=64, spp=16, depth=6, lens=False):
                                     lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
 
 
+NESTED_MIX_SCENE = DISNEY_TEXTURED_SCENE.split("# ground:")[0] + """MakeNamedMaterial "nmA" "string type" "plastic" "rgb Kd" [.7 .1 .1] "rgb Ks" [.3 .3 .3] "float roughness" [.1]
+MakeNamedMaterial "nmB" "string type" "mirror" "rgb Kr" [.9 .9 .9]
+MakeNamedMaterial "nmC" "string type" "mix" "string namedmaterial1" "nmA" "string namedmaterial2" "nmB" "rgb amount" [.7 .5 .3]
+MakeNamedMaterial "nmD" "string type" "matte" "texture Kd" "ewa_png"
+MakeNamedMaterial "nmE" "string type" "mix" "string namedmaterial1" "nmC" "string namedmaterial2" "nmD" "rgb amount" [.4 .6 .5]
+MakeNamedMaterial "nmF" "string type" "mix" "string namedmaterial1" "nmD" "string namedmaterial2" "nmC" "rgb amount" [.2 .3 .8]
+AttributeBegin
+  NamedMaterial "nmE"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+AttributeBegin
+  NamedMaterial "nmF"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
+AttributeEnd
+AttributeBegin
+  NamedMaterial "nmC"
+  Translate -2 .9 0
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  NamedMaterial "nmE"
+  Translate 0 .2 -1.5
+%(patch)s
+AttributeEnd
+WorldEnd
+"""
+
+
+def nested_mix_scene(res=64, spp=16, depth=5, lens=False):
+    """A "mix" of a "mix" (mixmat.cpp:46-64 applied twice: ScaledBxDF(ScaledBxDF(lobe, inner), outer)), either way round, with an
+    image-textured sub-material. Needs write_texture_files()."""
+    return NESTED_MIX_SCENE % dict(res=res, spp=spp, depth=depth, patch=_curved_patch(),
+                                   lens='"float lensradius" [.05] "float focaldistance" [7]' if lens else "")
+
+
 def disney_textured_scene(res=64, spp=16, depth=5, lens=False):
     """"disney" with an image-textured "color" (disney.cpp:485-587): thick and thin, metallic, sheen, clearcoat, specular and
     diffuse transmission, a map with black texels. Needs write_texture_files()."""

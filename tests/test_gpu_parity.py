@@ -771,6 +771,22 @@ def test_glass_with_roughness_maps_against_oracle(pt, ob, tmp_path):
     assert _rel_l2(ff, ofilm) > 0.01
 
 
+def test_a_mix_of_a_mix_against_oracle(pt, ob, tmp_path):
+    """MixMaterial whose sub-material is a MixMaterial (mixmat.cpp:46-64 twice): every lobe of the inner mix is wrapped in a second
+    ScaledBxDF, f = outer * (inner * f) -- two scale spectra per lobe (mi_bxdf.scaled == 2). Exact mode; a third level is reported."""
+    st.write_texture_files(str(tmp_path))
+    s = pt.Scene(text=st.nested_mix_scene(), base_dir=str(tmp_path))
+    assert s.errors == []
+    mixes = [s.desc.materials[i] for i in range(s.desc.n_materials) if s.desc.materials[i].kind == 9]
+    assert sorted(max(m.bxdf[i].scaled for i in range(m.n_bxdfs)) for m in mixes) == [1, 2, 2]
+    e = next(m for m in mixes if m.n_bxdfs == 4 and m.bxdf[0].scaled == 2)   # nmE: plastic (2 lobes) + mirror under two scales, matte under one
+    assert [e.bxdf[i].scaled for i in range(4)] == [2, 2, 2, 1] and e.textured
+    film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "a mix of a mix")
+    deep = st.nested_mix_scene().replace('WorldEnd', 'MakeNamedMaterial "nmG" "string type" "mix" "string namedmaterial1" "nmE" "string namedmaterial2" "nmA"\n'
+                                         'NamedMaterial "nmG"\nShape "sphere"\nWorldEnd')
+    assert any("three nested" in x for x in pt.Scene(text=deep, base_dir=str(tmp_path)).errors)
+
+
 def test_object_instances_against_oracle(pt, ob, tmp_path, monkeypatch):
     """ObjectInstance as the reference's TransformedPrimitive (primitive.cpp:78-99): the ray goes to the instance's space,
     walks the object's own tree, and the interaction comes back through InstanceToWorld (transform.cpp:262-297) -- with
