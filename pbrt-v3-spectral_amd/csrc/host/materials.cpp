@@ -432,7 +432,9 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
                         std::vector<std::string> *errs) {
     *out = mi_material{};
     for (int i = 0; i < MI_MAX_BXDFS; ++i) out->tex[i] = mi_lobe_tex{-1, -1, 0u, MI_LOBE_IF_R};
-    out->bump_tex = -1;
+    // Bump maps (mixmat.cpp:52-56): m1 bumps the interaction in place and builds the BSDF -- whose frame the mixed lobes share --, m2 gets
+    // a copy of that interaction and its BSDF's lobes only: m1's bump map shapes the shading frame, m2's has no effect on anything.
+    out->bump_tex = m1.bump_tex;
     out->rough_tex[0] = out->rough_tex[1] = -1;
     out->sigma_tex = -1;
     out->kind = 9;
@@ -446,8 +448,9 @@ bool CompileMixMaterial(const mi_material &m1, const mi_material &m2, const Spec
             mi_bxdf b = src[k]->bxdf[i];
             // (each sub-material runs its own ComputeScatteringFunctions, mixmat.cpp:52-56: its textured lobes keep their
             // bindings and presence rules; a bump or roughness map would act on one sub-material's copy of the interaction)
-            if (src[k]->bump_tex >= 0 || src[k]->rough_tex[0] >= 0 || src[k]->rough_tex[1] >= 0 || src[k]->sigma_tex >= 0) {
-                errs->push_back("a \"mix\" of bump-mapped or roughness-mapped materials is outside the hot-path scope");
+            // a roughness or sigma map acts on one sub-material's lobes only, which the per-material overrides do not express
+            if (src[k]->rough_tex[0] >= 0 || src[k]->rough_tex[1] >= 0 || src[k]->sigma_tex >= 0) {
+                errs->push_back("a \"mix\" of roughness-mapped or sigma-mapped materials is outside the hot-path scope");
                 return false;
             }
             if (b.scaled >= 2) { errs->push_back("a \"mix\" of a \"mix\" of \"mix\" materials (three nested ScaledBxDFs) is not built on this path"); return false; }

@@ -763,6 +763,22 @@ MakeNamedMaterial "nmC" "string type" "mix" "string namedmaterial1" "nmA" "strin
 MakeNamedMaterial "nmD" "string type" "matte" "texture Kd" "ewa_png"
 MakeNamedMaterial "nmE" "string type" "mix" "string namedmaterial1" "nmC" "string namedmaterial2" "nmD" "rgb amount" [.4 .6 .5]
 MakeNamedMaterial "nmF" "string type" "mix" "string namedmaterial1" "nmD" "string namedmaterial2" "nmC" "rgb amount" [.2 .3 .8]
+Texture "nm_bump_raw" "float" "imagemap" "string filename" "tex_b.tga" "float uscale" [3] "float vscale" [2]
+Texture "nm_bump" "float" "scale" "texture tex1" "nm_bump_raw" "float tex2" [.05]
+MakeNamedMaterial "nmH" "string type" "plastic" "rgb Kd" [.2 .5 .7] "rgb Ks" [.4 .4 .4] "float roughness" [.05] "texture bumpmap" "nm_bump"
+MakeNamedMaterial "nmI" "string type" "mix" "string namedmaterial1" "nmH" "string namedmaterial2" "nmB" "rgb amount" [.6 .6 .6]
+MakeNamedMaterial "nmJ" "string type" "mix" "string namedmaterial1" "nmB" "string namedmaterial2" "nmH" "rgb amount" [.5 .5 .5]
+# m1's bump map shapes the frame of the whole mix (mixmat.cpp:52-56); as m2 it has no effect
+AttributeBegin
+  NamedMaterial "nmI"
+  Translate 2 .9 .3
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  NamedMaterial "nmJ"
+  Translate 2.4 .5 -1.6
+  Shape "sphere" "float radius" [.5]
+AttributeEnd
 AttributeBegin
   NamedMaterial "nmE"
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 6  -6 0 6] "float uv" [0 0 1 0 1 1 0 1]

@@ -773,12 +773,15 @@ def test_glass_with_roughness_maps_against_oracle(pt, ob, tmp_path):
 
 def test_a_mix_of_a_mix_against_oracle(pt, ob, tmp_path):
     """MixMaterial whose sub-material is a MixMaterial (mixmat.cpp:46-64 twice): every lobe of the inner mix is wrapped in a second
-    ScaledBxDF, f = outer * (inner * f) -- two scale spectra per lobe (mi_bxdf.scaled == 2). Exact mode; a third level is reported."""
+    ScaledBxDF, f = outer * (inner * f) -- two scale spectra per lobe (mi_bxdf.scaled == 2). And a mix of a bump-mapped material: as
+    m1 its map bumps the interaction the mix's BSDF is built on, as m2 it acts on a copy nobody reads. Exact mode; a third level is
+    reported."""
     st.write_texture_files(str(tmp_path))
     s = pt.Scene(text=st.nested_mix_scene(), base_dir=str(tmp_path))
     assert s.errors == []
     mixes = [s.desc.materials[i] for i in range(s.desc.n_materials) if s.desc.materials[i].kind == 9]
-    assert sorted(max(m.bxdf[i].scaled for i in range(m.n_bxdfs)) for m in mixes) == [1, 2, 2]
+    assert sorted(max(m.bxdf[i].scaled for i in range(m.n_bxdfs)) for m in mixes) == [1, 1, 1, 2, 2]
+    assert sorted(m.bump_tex >= 0 for m in mixes) == [False, False, False, False, True]   # (a bump map counts as m1's only: mixmat.cpp:52-56)
     e = next(m for m in mixes if m.n_bxdfs == 4 and m.bxdf[0].scaled == 2)   # nmE: plastic (2 lobes) + mirror under two scales, matte under one
     assert [e.bxdf[i].scaled for i in range(4)] == [2, 2, 2, 1] and e.textured
     film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "a mix of a mix")
