@@ -3748,7 +3748,8 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
     wd.spp = rp->spp_override > 0 ? rp->spp_override : pt->spp;
     wd.sampleBegin = rp->sample_begin;
     wd.totalWork = (unsigned long long)wd.nTilesShard * 256ull * (unsigned long long)wd.spp;
-    int runCap = 64;   // (same-box A/B at the end of round 2: 16 -> 64 takes 4 % off k_generate and 1 % off the camera-ray
+    int runCap = 256;  // (round 3, with the dense film flush: 64 -> 256 takes 5 % off k_generate, killeroo +0.9 %, the 10M-triangle scene
+                       // +0.7 %, cornell-glass the same; 1024 measures as 256. Same-box A/B at the end of round 2: 16 -> 64 took 4 % off k_generate and 1 % off the camera-ray
                        // traversal, the other kernels unchanged -- 3596 -> 3620 Mray/s; 128 ... 1024 measure the same as 64.
                        // Earlier in the round longer runs cost the shading kernels 2-5 % and 16 was the optimum.)
     if (const char *e = getenv("MIPT_WORK_RUN")) runCap = std::max(1, atoi(e));

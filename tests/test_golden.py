@@ -193,7 +193,7 @@ def _full_frame_against_tiles(pt, s, z, counters, exact, tol, frac_over, max_ove
     # the same tiles inside the full frame, away from the pixels that a neighbouring tile's border samples also reach
     inner = (w0[ys, xs] == spp) & (wfull[ys, xs] == spp)
     assert inner.mean() > 0.9
-    assert _rel_l2(full[ys, xs][inner], z["film_exact"][inner]) < 1e-6 * max(1.0, (spp / 256.0) ** 0.5)
+    assert _rel_l2(full[ys, xs][inner], z["film_exact"][inner]) < (exact_rel or 1e-6 * max(1.0, (spp / 256.0) ** 0.5))
     acc, accw, cams = np.zeros_like(full), np.zeros_like(wfull), 0
     for r in range(3):
         f, wt = integ.Render(shard_index=r, shard_count=3)
