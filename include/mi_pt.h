@@ -457,8 +457,9 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  *   mode 2: BSDF-sampled MIS rays -- k_trav<2>, then the quadric step of k_resolve_mis (the same device function; that
  *           kernel consumes the hit in place); closest hit, tMax must be +infinity (Interaction::SpawnRay).
  * hits: as mi_pt_trace. extra (may be NULL): n x 4 words {b2 (float), instance of the hit (int32 bits, -1 = none),
- * I_NPEND as the traversal kernel left it (int32 bits: count of postponed quadrics | 0x100 on overflow),
- * I_HITPRIM as the traversal kernel left it, before the quadric step (int32 bits)}. Host pointers; n <= 2^24. */
+ * the count of postponed quadrics as the traversal kernel left it (int32 bits: count | 0x100 on overflow),
+ * the hit primitive as the traversal kernel left it, before the quadric step (int32 bits; -2 = the ray was never answered;
+ * mode 1, whose kernel keeps one answer word per queue entry: 0 = occluded, -1 = not)}. Host pointers; n <= 2^24. */
 int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra);
 
 /* Parity tool for the scalar helpers under the shape and sampling code, each run on the device for n inputs (x, y: 2 floats per
