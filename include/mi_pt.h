@@ -203,6 +203,11 @@ typedef struct mi_material {
  * `isSpecular = urough == 0 && vrough == 0` on the values before the remap (a constant axis keeps its raw value in lobe 0's
  * p[6] (u) / p[7] (v)); lobe 0 is part of the BSDF where isSpecular holds, the others where it does not. */
 #define MI_ROUGH_GLASS 2u
+/* ABI v10 -- "disney" with `roughness` a float image texture (disney.cpp:491, 538-541, 568-573): rough_tex[0] is the map and the
+ * value at the hit, rough, replaces p[0] of the DISNEY_FAKE_SS / DISNEY_RETRO lobes and gives the microfacet lobes their alphas:
+ * max(.001, sqr(r) / p[4]), max(.001, sqr(r) * p[4]) with p[4] = aspect (from "anisotropic") and r = rough -- or p[7] * rough for the
+ * thin surface's transmission lobe, whose p[7] = 0.65 eta - 0.35 (0 elsewhere). */
+#define MI_ROUGH_DISNEY 4u
 
 /* ImageTexture<RGBSpectrum, Spectrum> with UVMapping2D (src/textures/imagemap.h, src/core/texture.cpp:91-99) over a
  * MIPMap<RGBSpectrum> (src/core/mipmap.h). The pyramid is built on the host exactly as the reference builds it (y flip,

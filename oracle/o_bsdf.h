@@ -200,6 +200,8 @@ struct BxDF {
     bool MatchesFlags(int t) const { return (b->flags & t) == b->flags; }
     // roughness from float textures (mi_material.rough_tex): the alphas of this hit in place of b->p[0] / p[1]
     bool ovU = false, ovV = false;
+    bool roughOv = false;     // "disney" with a roughness map (MI_ROUGH_DISNEY): the roughness of this hit in place of p[0] (FakeSS, Retro)
+    Float roughHit = 0;
     int sigMode = 0;          // "matte" with a sigma map: 1 = OrenNayar with sigA / sigB, 2 = LambertianReflection (sig == 0)
     Float sigA = 0, sigB = 0;
     Float alphaU = 0, alphaV = 0;
@@ -294,7 +296,7 @@ struct BxDF {
             if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.);
             wh = Normalize(wh);
             Float cosThetaD = Dot(wi, wh);
-            Float Fss90 = cosThetaD * cosThetaD * b->p[0];
+            Float Fss90 = cosThetaD * cosThetaD * (roughOv ? roughHit : b->p[0]);
             Float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
             Float Fss = Lerp(Fo, 1.0, Fss90) * Lerp(Fi, 1.0, Fss90);
             Float ss = 1.25f * (Fss * (1 / (AbsCosTheta(wo) + AbsCosTheta(wi)) - .5f) + .5f);
@@ -306,7 +308,7 @@ struct BxDF {
             wh = Normalize(wh);
             Float cosThetaD = Dot(wi, wh);
             Float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
-            Float Rr = 2 * b->p[0] * cosThetaD * cosThetaD;
+            Float Rr = 2 * (roughOv ? roughHit : b->p[0]) * cosThetaD * cosThetaD;
             return R() * InvPi * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
         }
         case MI_BXDF_DISNEY_SHEEN: {  // disney.cpp:217-224
@@ -486,8 +488,10 @@ struct BSDF {
         bool ov[2] = {false, false};
         Float alpha[2] = {0, 0};
         Float raw[2] = {m.n_bxdfs > 0 ? m.bxdf[0].p[6] : 0, m.n_bxdfs > 0 ? m.bxdf[0].p[7] : 0};   // (MI_ROUGH_GLASS: the values before the remap)
+        const bool disneyRough = d && td && (m.rough_flags & MI_ROUGH_DISNEY) != 0;
+        const Float roughHit = disneyRough ? EvalFloatImageTexture(*d, m.rough_tex[0], si.uv[0], si.uv[1], *td) : 0;   // disney.cpp:491
         for (int a = 0; a < 2; ++a)
-            if (d && td && m.rough_tex[a] >= 0) {
+            if (d && td && m.rough_tex[a] >= 0 && !disneyRough) {
                 Float r = (a == 1 && m.rough_tex[1] == m.rough_tex[0]) ? -1.f : EvalFloatImageTexture(*d, m.rough_tex[a], si.uv[0], si.uv[1], *td);
                 if (a == 1 && m.rough_tex[1] == m.rough_tex[0]) { alpha[1] = alpha[0]; raw[1] = raw[0]; }
                 else { alpha[a] = (m.rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlphaF(r) : r; raw[a] = r; }
@@ -514,6 +518,16 @@ struct BSDF {
             bx.b = &m.bxdf[i];
             bx.ovU = ov[0]; bx.ovV = ov[1]; bx.alphaU = alpha[0]; bx.alphaV = alpha[1];
             bx.sigMode = sigMode; bx.sigA = sigA; bx.sigB = sigB;
+            if (disneyRough) {   // disney.cpp:538-541, 568-573
+                const int t = bx.b->type;
+                if (t == MI_BXDF_DISNEY_FAKE_SS || t == MI_BXDF_DISNEY_RETRO) { bx.roughOv = true; bx.roughHit = roughHit; }
+                else if (t == MI_BXDF_MICROFACET_REFLECTION || t == MI_BXDF_MICROFACET_TRANSMISSION) {
+                    const Float r = (t == MI_BXDF_MICROFACET_TRANSMISSION && bx.b->p[7] != 0) ? bx.b->p[7] * roughHit : roughHit;
+                    bx.ovU = bx.ovV = true;
+                    bx.alphaU = std::max(Float(.001), (r * r) / bx.b->p[4]);
+                    bx.alphaV = std::max(Float(.001), (r * r) * bx.b->p[4]);
+                }
+            }
             if (glassSwitch && ((bx.b->type == MI_BXDF_FRESNEL_SPECULAR) != glassSpecular)) continue;
             const mi_lobe_tex &lt = m.tex[i];
             if (m.textured && d && td && lt.rule == MI_LOBE_METAL) {   // metal.cpp:119-122: eta and k from their textures, R = 1

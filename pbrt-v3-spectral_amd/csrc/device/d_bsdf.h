@@ -380,6 +380,10 @@ struct AlphaOv {
     // with sigA / sigB (the A, B of the sigma at this vertex, reflection.h:414-420), 2 = sigma is 0 here: LambertianReflection
     int sigMode;
     float sigA, sigB;
+    // "disney" with `roughness` a float image texture (MI_ROUGH_DISNEY): the value at this vertex -- p[0] of the FakeSS / Retro lobes,
+    // and the source of the microfacet lobes' alphas (DistOf)
+    bool disney;
+    float rough;
 };
 // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:140-145
 DEV float RoughnessToAlpha(float roughness) {
@@ -408,7 +412,13 @@ DEV int NumComponents(const BSDFFrame &fr, int flags) {
 }
 template <unsigned TM>
 DEV TRDist DistOf(const mi_bxdf &b, const AlphaOv &ov) {
-    if constexpr ((TM & TM_TEXTURED) != 0) return TRDist{ov.onU ? ov.u : b.p[0], ov.onV ? ov.v : b.p[1], b.p[5] != 0.f};
+    if constexpr ((TM & TM_TEXTURED) != 0) {
+        if (ov.disney) {   // disney.cpp:538-541, 568-573: p[4] = aspect, p[7] = 0.65 eta - 0.35 on the thin surface's transmission lobe
+            const float r = (b.type == MI_BXDF_MICROFACET_TRANSMISSION && b.p[7] != 0.f) ? b.p[7] * ov.rough : ov.rough;
+            return TRDist{maxf(.001f, (r * r) / b.p[4]), maxf(.001f, (r * r) * b.p[4]), b.p[5] != 0.f};
+        }
+        return TRDist{ov.onU ? ov.u : b.p[0], ov.onV ? ov.v : b.p[1], b.p[5] != 0.f};
+    }
     return TRDist{b.p[0], b.p[1], b.p[5] != 0.f};
 }
 
@@ -508,7 +518,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const Al
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) break;
         wh = Normalize(wh);
         float cosThetaD = Dot(wi, wh);
-        float Fss90 = cosThetaD * cosThetaD * b.p[0];
+        float Fss90 = cosThetaD * cosThetaD * (((TM & TM_TEXTURED) != 0 && ov.disney) ? ov.rough : b.p[0]);
         float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
         float Fss = lerpf(Fo, 1.0f, Fss90) * lerpf(Fi, 1.0f, Fss90);
         float ss = 1.25f * (Fss * (1 / (AbsCosTheta(wo) + AbsCosTheta(wi)) - .5f) + .5f);
@@ -521,7 +531,7 @@ DEV LobeEval LobeF(const mi_bxdf &b, int i, const V3 &wo, const V3 &wi, const Al
         wh = Normalize(wh);
         float cosThetaD = Dot(wi, wh);
         float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
-        float Rr = 2 * b.p[0] * cosThetaD * cosThetaD;
+        float Rr = 2 * (((TM & TM_TEXTURED) != 0 && ov.disney) ? ov.rough : b.p[0]) * cosThetaD * cosThetaD;
         le.kind = LK_MUL3; le.a = kInvPi; le.b = Rr; le.c = (Fo + Fi + Fo * Fi * (Rr - 1));
         break;
     } break;

@@ -1988,6 +1988,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
             fr.mask = 0xffu;
             fr.ov.u = fr.ov.v = 0.f; fr.ov.onU = fr.ov.onV = false;
             fr.ov.sigMode = 0; fr.ov.sigA = fr.ov.sigB = 0.f;
+            fr.ov.disney = false; fr.ov.rough = 0.f;
             LobeTexT<NL> lt;
             const LobeTexT<NL> *ltp = nullptr;
             if constexpr ((TM & TM_TEXTURED) != 0) {
@@ -2028,6 +2029,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                     if (mat->bump_tex >= 0) Bump(s, mat->bump_tex, u, v, td, tsh, &isect);   // `if (bumpMap) Bump(bumpMap, si)`
                     // `rough = roughness->Evaluate(*si); if (remapRoughness) rough = RoughnessToAlpha(rough)` (plastic.cpp:57-62 ...)
                     float rawU = mat->bxdf[0].p[6], rawV = mat->bxdf[0].p[7];   // (MI_ROUGH_GLASS: the values before the remap)
+                    if (mat->rough_flags & MI_ROUGH_DISNEY) {   // `Float rough = roughness->Evaluate(*si)`, disney.cpp:491
+                        fr.ov.disney = true;
+                        fr.ov.rough = EvalFloatImageTexture(s, mat->rough_tex[0], u, v, td);
+                    } else
                     if (mat->rough_tex[0] >= 0) {
                         const float rv = EvalFloatImageTexture(s, mat->rough_tex[0], u, v, td);
                         fr.ov.u = (mat->rough_flags & MI_ROUGH_REMAP) ? RoughnessToAlpha(rv) : rv;

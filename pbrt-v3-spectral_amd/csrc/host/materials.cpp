@@ -331,7 +331,8 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
         Spectrum c = ctex >= 0 ? Spectrum(1.f) : pc.s.Clamp();
         float metallicWeight = mp.GetFloat("metallic", 0.f);
         float e = mp.GetFloat("eta", 1.5f);
-        float rough = mp.GetFloat("roughness", .5f);
+        const RoughSrc roughSrc = Rough(mp, "roughness", .5f);   // (a float map: MI_ROUGH_DISNEY)
+        float rough = roughSrc.value;
         float specTint = mp.GetFloat("speculartint", 0.f);
         float anisotropic = mp.GetFloat("anisotropic", 0.f);
         float sheenWeight = mp.GetFloat("sheen", 0.f);
@@ -390,7 +391,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             b.fresnel = MI_FRESNEL_DISNEY;
             SetS(b, Cspec0);
             b.p[0] = ax; b.p[1] = ay; b.p[2] = metallicWeight; b.p[3] = e; b.p[5] = 1.f;
-            b.p[6] = specTint; b.p[7] = r0;
+            b.p[4] = aspect; b.p[6] = specTint; b.p[7] = r0;
             Add(m, b, errs);
             Bind(m, ctex, false, ctex, false, MI_LOBE_DISNEY_SPEC);
         }
@@ -409,9 +410,10 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
                 float ax2 = std::max(float(.001), sqr(rscaled) / aspect);
                 float ay2 = std::max(float(.001), sqr(rscaled) * aspect);
                 tb = MicrofacetTransmission(T, ax2, ay2, 1.f, e, false);
+                tb.p[7] = 0.65f * e - 0.35f;
             } else
                 tb = MicrofacetTransmission(T, ax, ay, 1.f, e, true);
-            tb.p[6] = strans;
+            tb.p[4] = aspect; tb.p[6] = strans;
             Add(m, tb, errs);
             Bind(m, ctex, false, -1, false, MI_LOBE_DISNEY_STRANS);
         }
@@ -419,6 +421,7 @@ bool CompileMaterial(const std::string &type, const TextureParams &mp, mi_materi
             Add(m, MakeBxDF(MI_BXDF_LAMBERTIAN_TRANSMISSION, MI_BSDF_TRANSMISSION | MI_BSDF_DIFFUSE, dt * c), errs);
             Bind(m, ctex, true, -1, false, MI_LOBE_ALWAYS);
         }
+        if (roughSrc.tex >= 0) { m->rough_tex[0] = roughSrc.tex; m->rough_flags |= MI_ROUGH_DISNEY; m->textured = 1; }
         return errs->empty() || m->n_bxdfs <= MI_MAX_BXDFS;
     }
     errs->push_back("material \"" + type + "\" is outside the PathIntegrator hot-path scope (SURVEY 2 row 18)");

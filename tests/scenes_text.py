@@ -608,6 +608,8 @@ Texture "ewa_png" "spectrum" "imagemap" "string filename" "tex_a.png" "float usc
 Texture "tri_tga" "spectrum" "imagemap" "string filename" "tex_b.tga" "bool trilinear" ["true"] "float udelta" [.25]
 Texture "pfm_clamp" "spectrum" "imagemap" "string filename" "tex_c.pfm" "string wrap" "clamp" "float uscale" [2] "float vscale" [2]
 Texture "png_black" "spectrum" "imagemap" "string filename" "tex_a.png" "string wrap" "black" "float uscale" [1.5] "float udelta" [-.2]
+Texture "dz_rough_raw" "float" "imagemap" "string filename" "tex_b.tga" "float uscale" [2] "float vscale" [2]
+Texture "dz_rough" "float" "scale" "texture tex1" "dz_rough_raw" "float tex2" [.8]
 # ground: every diffuse-side lobe (diffuse, retro, sheen) and the specular lobe take the colour from the map
 AttributeBegin
   Material "disney" "texture color" "ewa_png" "float roughness" [.4] "float sheen" [.7] "float sheentint" [.3] "float speculartint" [.6]
@@ -615,12 +617,12 @@ AttributeBegin
 AttributeEnd
 # back wall: metallic with clearcoat and anisotropy
 AttributeBegin
-  Material "disney" "texture color" "tri_tga" "float metallic" [.6] "float roughness" [.3] "float clearcoat" [.5] "float anisotropic" [.4] "float speculartint" [.2]
+  Material "disney" "texture color" "tri_tga" "float metallic" [.6] "texture roughness" "dz_rough" "float clearcoat" [.5] "float anisotropic" [.4] "float speculartint" [.2]
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4  4 0 4  4 4 4  -4 4 4] "float uv" [0 0 2 0 2 1 0 1]
 AttributeEnd
 # a thin sheet: fake subsurface, specular and diffuse transmission (strans * Sqrt(c), dt * c)
 AttributeBegin
-  Material "disney" "texture color" "pfm_clamp" "bool thin" ["true"] "float spectrans" [.5] "float flatness" [.4] "float difftrans" [.8] "float roughness" [.25] "float eta" [1.4]
+  Material "disney" "texture color" "pfm_clamp" "bool thin" ["true"] "float spectrans" [.5] "float flatness" [.4] "float difftrans" [.8] "texture roughness" "dz_rough_raw" "float eta" [1.4]
   Translate -2.2 1 0
   Rotate 35 0 1 0
   Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -.9 0  1 -.9 0  1 .9 0  -1 .9 0] "float uv" [0 0 1 0 1 1 0 1]
@@ -634,7 +636,7 @@ AttributeBegin
 AttributeEnd
 # a curved, bumpy-normal patch
 AttributeBegin
-  Material "disney" "texture color" "ewa_png" "float roughness" [.6] "float sheen" [.4] "float clearcoat" [1] "float clearcoatgloss" [.3]
+  Material "disney" "rgb color" [.7 .4 .2] "texture roughness" "dz_rough" "float sheen" [.4] "float clearcoat" [1] "float clearcoatgloss" [.3] "float spectrans" [.3]
   Translate 0 .2 -1.5
 %(patch)s
 AttributeEnd
@@ -1007,6 +1009,9 @@ def random_scene(seed, res=32, spp=8):
                 base += ' "float speculartint" [%.2f] "float sheentint" [%.2f]' % (float(rng2.uniform(0, 1)), float(rng2.uniform(0, 1)))
                 if rng2.random() < .5: base += ' "float spectrans" [%.2f]' % float(rng2.uniform(.1, .9))
                 if rng2.random() < .4: base += ' "bool thin" ["true"] "float flatness" [%.2f] "float difftrans" [%.2f]' % (float(rng2.uniform(0, 1)), float(rng2.uniform(0, 1.6)))
+            if rng2.random() < .3:   # (round 3: the roughness from a float map)
+                import re as _re
+                base = _re.sub(r'"float roughness" \[[0-9.]+\]', '"texture roughness" "gl_rough"', base) + ' "float anisotropic" [%.2f]' % float(rng2.uniform(0, .9))
             return base
         if k == 9: return 'Material "matte" "texture Kd" "img_a"%s' % bump
         if k == 10: return 'Material "plastic" "texture Kd" "img_s" "rgb Ks" %s "float roughness" [%.3f]%s' % (rgb(.05, .4), r(.02, .3), bump)

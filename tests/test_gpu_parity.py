@@ -690,7 +690,9 @@ def test_roughness_textures_against_oracle(pt, ob, tmp_path):
 def test_disney_with_a_textured_colour_against_oracle(pt, ob, tmp_path):
     """DisneyMaterial::ComputeScatteringFunctions with `color` an image texture (disney.cpp:485-587): the lobes are added
     whatever the colour is, their weights stay constants, and the sheen, specular and specular-transmission spectra are
-    formed at the hit from the colour and its luminance (Csheen, Cspec0, strans * Sqrt(c): mi_lobe_rule). Exact mode."""
+    formed at the hit from the colour and its luminance (Csheen, Cspec0, strans * Sqrt(c): mi_lobe_rule). And with `roughness` a
+    float image texture (disney.cpp:491, 538-541, 568-573): the value at the hit is the FakeSS / Retro lobes' roughness and, through
+    the anisotropy's aspect (and 0.65 eta - 0.35 on a thin surface's transmission lobe), the microfacet lobes' alphas. Exact mode."""
     st.write_texture_files(str(tmp_path))
     for lens in (False, True):
         s = pt.Scene(text=st.disney_textured_scene(lens=lens), base_dir=str(tmp_path))
@@ -700,6 +702,7 @@ def test_disney_with_a_textured_colour_against_oracle(pt, ob, tmp_path):
         assert len(disney) == 5 and all(m.textured for m in disney)
         rules = sorted({m.tex[i].rule for m in disney for i in range(m.n_bxdfs) if m.tex[i].tex_R >= 0})
         assert rules == [3, 4, 5, 6]   # MI_LOBE_ALWAYS, _DISNEY_SHEEN, _DISNEY_SPEC, _DISNEY_STRANS
+        assert sum(1 for m in disney if m.rough_flags & 4) == 3   # MI_ROUGH_DISNEY: thick + anisotropic, thin, and one without a colour map
         film, weight, integ, ofilm, oweight, oc = _parity(pt, ob, s, "disney textured colour lens=%s" % lens)
     # the maps matter: with a constant colour in their place the picture differs visibly
     flat = st.disney_textured_scene(lens=True)
