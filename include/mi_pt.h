@@ -460,7 +460,10 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  *   mode 1: NEE shadow rays -- k_trav<1>, k_resolve_shadow, k_resolve_overflow; any hit (prim = 0 / -1); d is the
  *           unnormalised vector to the light sample and tMax must be 1 - 0.0001f (Interaction::SpawnRayTo).
  *   mode 2: BSDF-sampled MIS rays -- k_trav<2>, then the quadric step of k_resolve_mis (the same device function; that
- *           kernel consumes the hit in place); closest hit, tMax must be +infinity (Interaction::SpawnRay).
+ *           kernel consumes the hit in place); closest hit, tMax must be +infinity (Interaction::SpawnRay). (A render of a
+ *           scene without instances and alpha masks asks these rays as visibility queries bounded by the sampled emitter,
+ *           k_trav<3>, and falls back to this closest-hit form for the rays that does not settle; this call always runs
+ *           the closest-hit kernel.)
  * hits: as mi_pt_trace. extra (may be NULL): n x 4 words {b2 (float), instance of the hit (int32 bits, -1 = none),
  * the count of postponed quadrics as the traversal kernel left it (int32 bits: count | 0x100 on overflow),
  * the hit primitive as the traversal kernel left it, before the quadric step (int32 bits; -2 = the ray was never answered;

@@ -364,7 +364,7 @@ DEV Interaction ShapeSample(const DScene &s, int shape, const Interaction &ref, 
 }
 
 // Shape::Pdf(ref, wi) for the light's own shape (no BVH: it intersects only that shape).
-DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &ref, const V3 &wi) {
+DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &ref, const V3 &wi, float *tTri = nullptr) {
     Ray ray = SpawnRay(ref, wi);
     if (shape < 0) {
         const mi_sphere &sp = s.spheres[~shape];
@@ -393,6 +393,7 @@ DEV float ShapePdf(const DScene &s, int shape, float area, const Interaction &re
         V3 dpdu, dpdv;
         if (!TriPartials(p0, p1, p2, uv, &dpdu, &dpdv)) return 0;
     }
+    if (tTri) *tTri = h.t;
     SurfaceInteraction il;
     TriInteraction(s, shape, h.b0, h.b1, h.b2, ray.d, &il);
     float pdf = DistanceSquared(ref.p, il.p) / (AbsDot(il.n, -wi) * area);

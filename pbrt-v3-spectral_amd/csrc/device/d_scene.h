@@ -46,6 +46,8 @@ struct DScene {
     const mi_sphere *spheres;
     const mi_material *materials;
     const mi_light *lights;
+    const int *lightPrim;        // [nLights]: the primitive whose shape an area light is (k_trav<3> leaves it out)
+    int misAny;                  // MIS rays are traced as visibility queries (k_trav, MODE 3; pt_kernels.hip)
     const float4 *lightBounds;   // [2 * nLights]: dilated world bounds of an area light's shape (see F_MIS_DARK, pt_kernels.hip)
     uint32_t nNodes, nPrims, nLights, nMaterials;
     uint32_t classMask;  // shading classes present in the scene (bit c), see pt_kernels.hip

@@ -10,8 +10,10 @@
 //              BSDF sample for MIS, BSDF sample for the continuation, Russian roulette;
 //              streams the 31 bins of beta / contributions through HBM planes
 //   shadow   : any-hit traversal of the NEE shadow rays, adds unoccluded contributions
-//   mis      : closest-hit traversal of the MIS rays, adds emission if the sampled
-//              light was hit; closes the per-vertex direct-lighting statistics
+//   mis      : the BSDF-sampled rays of the direct-lighting estimates: is the closest hit the
+//              sampled light's shape? (a visibility query up to that shape, k_trav MODE 3; the
+//              closest-hit traversal, MODE 2, for scenes with instances or alpha masks); adds the
+//              emission if so; closes the per-vertex direct-lighting statistics
 //
 // which restates, per path vertex, PathIntegrator::Li (src/integrators/path.cpp:64-188)
 // with UniformSampleOneLight / EstimateDirect (src/core/integrator.cpp:85-215) inside
@@ -151,8 +153,8 @@ DEV int LOtherPlane(int flags) { return (flags & F_L_IN_B) ? Q_L : Q_LB; }   // 
 DEV int StateWord(int flags, int bounces, int dim) { return (flags & FLAG_MASK) | ((bounces & 0xff) << BOUNCE_SHIFT) | (int)((unsigned)(dim & 0x3ff) << DIM_SHIFT); }
 DEV int StateBounces(int word) { return (word >> BOUNCE_SHIFT) & 0xff; }
 DEV int StateDim(int word) { return (int)((unsigned)word >> DIM_SHIFT); }
-// Conservative: false only if the ray o + t d, t >= 0, stays outside the box.
-DEV bool RayMayHitBox(const V3 &o, const V3 &d, const float4 &bmin, const float4 &bmax) {
+// Conservative: false only if the ray o + t d, t >= 0, stays outside the box; [*lo, *hi] contains the parameters at which it is inside.
+DEV bool RaySpanInBox(const V3 &o, const V3 &d, const float4 &bmin, const float4 &bmax, float *spanLo, float *spanHi) {
     float t0 = 0.f, t1 = kInfinity;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {bmin.x, bmin.y, bmin.z}, hi[3] = {bmax.x, bmax.y, bmax.z};
 #pragma unroll
@@ -165,7 +167,19 @@ DEV bool RayMayHitBox(const V3 &o, const V3 &d, const float4 &bmin, const float4
         if (ta > t0) t0 = ta;
         if (tb < t1) t1 = tb;
     }
+    *spanLo = t0; *spanHi = t1;
     return !(t0 > t1);
+}
+constexpr unsigned MIS_EXCL_BITS = 27, MIS_EXCL_NONE = (1u << MIS_EXCL_BITS) - 1u;
+// The two words k_trav<3> reads beside a MIS ray (R_MI1.z, .w): the end tHi of the span in which the sampled light's shape can
+// be hit, and that shape's primitive | c << 27 with tLo = tHi (1 - 2^-c) at or below the span's start (c = 0: tLo = 0).
+DEV void MisSpanWords(float lo, float hi, unsigned prim, float *tHi, float *word) {
+    const float w = 1.f - lo / hi;          // tLo = hi (1 - 2^-c) <= lo  <=>  2^-c >= w
+    int c = 126 - (int)((__float_as_uint(w) >> 23) & 0xffu);
+    if (!(w > 0.f)) c = 20;
+    c = (lo > 0.f && hi < kInfinity) ? max(0, min(c, 20)) : 0;   // (1 - 2^-c is exact in a float up to c = 24)
+    *tHi = hi;
+    *word = __uint_as_float(prim | ((unsigned)c << MIS_EXCL_BITS));
 }
 
 // Shading classes: materials with the same lobe-type list share a class (ids in order of
@@ -645,7 +659,8 @@ DEV void HitInteraction(const DScene &s, int prim, const V3 &ro, const V3 &rd, f
 
 // ------------------------------------------------------------------ persistent traversal
 // One launch traverses every ray of a class (MODE 0: path rays of the alive slots, closest
-// hit; 1: NEE shadow rays of shadowQ, any hit; 2: MIS rays of misQ, closest hit). A fixed
+// hit; 1: NEE shadow rays of shadowQ, any hit; 2: MIS rays of misQ, closest hit; 3: the same rays as visibility queries,
+// see TRAV_IS_ANY below). A fixed
 // grid of waves pulls rays from a device-wide cursor: lanes whose ray finished fetch a new
 // one as soon as fewer than REFILL_BELOW lanes of the wave are still traversing (dynamic
 // fetch), so a long ray no longer idles the other 63 lanes. Quadrics are only recorded
@@ -690,14 +705,32 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 // the pool and resumes the leaf -- with the instance ray's tMax if something was hit inside (`r.tMax = ray.tMax`). The
 // sequence of box tests, primitive tests and tMax updates per ray is the reference's recursion unrolled.
 template <int MODE, bool ALPHA, int W, bool INST = false>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 1 && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU, (MODE == 1 && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU)))
+// MODE 3: the MIS rays again, as a visibility query (scenes without instances and alpha masks: DScene::misAny). The estimator
+// reads one bit of a MIS ray -- is the closest hit the sampled light's shape (integrator.cpp:196-203) -- so k_shade hands
+// over the span [tLo, tHi] of the ray in which that shape can be hit and the shape's primitive, and this walks the tree as the
+// any-hit kernel does (no entry distances, no child ordering, five blocks per CU) with Triangle::Intersect's acceptance
+// rules: a primitive other than the light's that is accepted below tLo ends the ray (occluded whatever the visiting order);
+// one accepted inside the span only marks the ray ambiguous (the outcome depends on the order in which the reference meets
+// the two), and an ambiguous ray, or one that met a quadric, is traversed again by the reference-order routine
+// (k_resolve_overflow). Rays towards the environment light, and the rays whose answer nothing reads (F_MIS_DARK), carry
+// tLo = tHi = infinity: any hit ends them.
+#define TRAV_IS_ANY(MODE_) ((MODE_) == 1 || (MODE_) == 3)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((TRAV_IS_ANY(MODE) && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU, (TRAV_IS_ANY(MODE) && !ALPHA) ? MIPT_TRAV_WAVES_PER_EU_ANY : MIPT_TRAV_WAVES_PER_EU)))
 k_trav(DScene s, Pool pool, DevCounters *ctr) {
-    constexpr bool ANY = (MODE == 1);
+    constexpr bool ANY = TRAV_IS_ANY(MODE);
+    constexpr bool PSEM = (MODE == 1);      // Triangle::IntersectP's acceptance rules (MODE 3 asks with Intersect's)
+    constexpr bool MISANY = (MODE == 3);
+    constexpr int QM = MISANY ? 2 : MODE;   // the queue and cursor of the class
+    static_assert(!(MISANY && (ALPHA || INST)), "the visibility form of the MIS rays is built for scenes without alpha masks and instances");
+    int excl = -1;                          // MISANY: the sampled light's primitive
+    float tLo = 0;                          // MISANY: hits accepted at or beyond it are ambiguous
+    bool ambiguous = false;
     const int lane = threadIdx.x;
     const int wlane = threadIdx.x & 63;
     const unsigned nPrim = (MODE == 0) ? ctr->primCount.v : 0, nCont = (MODE == 0) ? ctr->contCount.v : 0;
     const unsigned total = (MODE == 0) ? nPrim + nCont : ((MODE == 1) ? ctr->shadowCount.v : ctr->misCount.v);
     const uint32_t *__restrict__ queue = (MODE == 0) ? pool.extQ : ((MODE == 1) ? pool.shadowQ : pool.misQ);
+    (void)excl; (void)tLo; (void)ambiguous;
     const unsigned travChunk = (total >= (1u << 23)) ? 2u * (unsigned)TRAV_CHUNK : (unsigned)TRAV_CHUNK;
     const float4 *__restrict__ primTri = s.primTri;
     unsigned nodeCount = 0, triCount = 0, rayCount = 0;
@@ -731,7 +764,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
             if (idle) {
                 if (chunkNext == chunkEnd) {  // the wave's private range is used up: reserve a chunk more
                     unsigned base = 0;
-                    if (wlane == 0) base = atomicAdd(&ctr->travNext[MODE].v, travChunk);
+                    if (wlane == 0) base = atomicAdd(&ctr->travNext[QM].v, travChunk);
                     base = __shfl(base, 0, 64);
                     chunkNext = min(base, total);
                     chunkEnd = min(base + travChunk, total);
@@ -750,7 +783,14 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                             const float4 r1 = pool.R((MODE == 0) ? R_RAY1 : ((MODE == 1) ? R_SH1 : R_MI1), slot);
                             if (MODE == 0) InitRayCtx(r, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z);
                             else InitRayCtx(r, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
-                            tMax = (MODE == 0) ? r0.w : ((MODE == 1) ? 1 - kShadowEpsilon : kInfinity);
+                            tMax = (MODE == 0) ? r0.w : ((MODE == 1) ? 1 - kShadowEpsilon : (MISANY ? r1.z : kInfinity));
+                            if (MISANY) {   // (k_shade: R_MI1 = d.y, d.z, tHi, light primitive | width code << 27; tLo = tHi (1 - 2^-code))
+                                const unsigned xw = __float_as_uint(r1.w);
+                                excl = (int)(xw & MIS_EXCL_NONE);
+                                const unsigned code = xw >> MIS_EXCL_BITS;
+                                tLo = code == 0 ? 0.f : tMax * (1.f - __uint_as_float((127u - code) << 23));
+                                ambiguous = false;
+                            }
                             StartTraversal(s, r, tMax, st, nodeCount);
                             triRay = MakeTriRay(V3(r.dx, r.dy, r.dz));
                             nPend = 0; hitPrim = -1;
@@ -763,6 +803,8 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                             else if (MODE == 2) {
                                 *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2(0xffffffffu, 0u);
                                 pool.R(R_HIT, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            } else if (MISANY) {
+                                *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2(0xffffffffu, 0u);
                             } else {  // the ray misses the world bound: nothing to traverse
                                 pool.I(I_HITPRIM, slot) = -1;
                                 pool.I(I_NPEND, slot) = 0;
@@ -839,7 +881,9 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                 wtr.kz = __shfl(triRay.kz, owner, 64);
                 wtr.Sx = __shfl(triRay.Sx, owner, 64); wtr.Sy = __shfl(triRay.Sy, owner, 64); wtr.Sz = __shfl(triRay.Sz, owner, 64);
                 const float wT = __shfl(tMax, owner, 64);
-                bool res = false;
+                const int wExcl = MISANY ? __shfl(excl, owner, 64) : -1;
+                const float wLo = MISANY ? __shfl(tLo, owner, 64) : 0.f;
+                bool res = false, resClear = false;
                 float rT = 0, rB0 = 0, rB1 = 0, rB2 = 0, rDet = 0, rTs = 0;
                 if (worker) {
                     const int prim = wOff + tk;
@@ -851,13 +895,19 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                         if constexpr (ALPHA)
                             if (pf & PRIM_FLAG_ALPHA)
                                 counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
-                        res = counts && (ANY || !(pf & PRIM_FLAG_DEGENERATE));
+                        res = counts && (PSEM || !(pf & PRIM_FLAG_DEGENERATE));
+                        if (MISANY) { res = res && prim != wExcl; resClear = res && th.t < wLo; }
                         rT = th.t; rB0 = th.b0; rB1 = th.b1; rB2 = th.b2;
                     }
                 }
                 const unsigned long long hitMask = __ballot(res);
                 const unsigned seg = grant > 0 ? (unsigned)(hitMask >> base) & ((1u << grant) - 1u) : 0u;   // bit k: my k-th pair hit
-                if (ANY) {
+                if (MISANY) {
+                    const unsigned long long clearMask = __ballot(resClear);
+                    const unsigned segClear = grant > 0 ? (unsigned)(clearMask >> base) & ((1u << grant) - 1u) : 0u;
+                    if (segClear) { hitPrim = leafOff + (__ffs(segClear) - 1); finished = true; triCount += (unsigned)__ffs(segClear); }
+                    else { if (seg) ambiguous = true; triCount += (unsigned)grant; }
+                } else if (ANY) {
                     if (seg) { hitPrim = leafOff + (__ffs(seg) - 1); finished = true; triCount += (unsigned)__ffs(seg); }
                     else triCount += (unsigned)grant;
                 } else {
@@ -922,7 +972,8 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                         else { tMax = t; hitPrim = prim; hitT = t; hitB0 = hitB1 = hitB2 = 0; hitInst = curInst; hitInCur = true; }
                     }
                 } else
-                if (pf & PRIM_FLAG_SPHERE) {
+                if (MISANY && prim == excl) {}   // the sampled light's own shape
+                else if (pf & PRIM_FLAG_SPHERE) {
                     if ((nPend & 0xff) < MAX_PEND) {
                         pool.I(I_PEND0 + (nPend & 0xff), slot) = prim;
                         if (!ANY) pool.F(P_TENC0 + (nPend & 0xff), slot) = tMax;   // (see ResolveQuadrics)
@@ -942,7 +993,13 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                             if (pf & PRIM_FLAG_ALPHA)
                                 counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
                         if (!counts) {}
-                        else if (ANY) { hitPrim = prim; finished = true; }
+                        else if (PSEM) { hitPrim = prim; finished = true; }
+                        else if (MISANY) {
+                            if (!(pf & PRIM_FLAG_DEGENERATE)) {
+                                if (th.t < tLo) { hitPrim = prim; finished = true; }
+                                else ambiguous = true;
+                            }
+                        }
                         else if (!(pf & PRIM_FLAG_DEGENERATE)) {
                             tMax = th.t;
                             hitPrim = prim; hitT = th.t; hitB0 = th.b0; hitB1 = th.b1; hitB2 = th.b2;
@@ -984,6 +1041,11 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
             if (finished && MODE == 2) {
                 *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2((unsigned)hitPrim, (unsigned)nPend);
                 pool.R(R_HIT, slot) = make_float4(hitT, hitB0, hitB1, hitB2);
+                has = false;
+                leafCnt = 0;
+            } else
+            if (finished && MISANY) {   // an occluder's primitive, -1: nothing in front of the light's span, -2: ambiguous
+                *reinterpret_cast<uint2 *>(pool.misQ + pool.n + 2 * (size_t)myEntry) = make_uint2(hitPrim >= 0 ? (unsigned)hitPrim : (ambiguous ? 0xfffffffeu : 0xffffffffu), (unsigned)nPend);
                 has = false;
                 leafCnt = 0;
             } else
@@ -1263,13 +1325,76 @@ DEV void ResolveMisSlot(const DScene &s, const Pool &pool, DevCounters *ctr, uin
     if (!added && !(flags & F_A_ADDED)) ++zero;
     pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_MIS_DARK);
 }
+// The commit of a MIS ray that k_trav<3> answered as a visibility query (DScene::misAny). word0: an occluder's primitive,
+// -1 (nothing accepted up to the end of the light's span) or -2 (something accepted inside the span). A ray that is
+// ambiguous, met a quadric on its way to an area light, or reaches a sphere whose root the reference could reject against a
+// hit beyond the span, goes to k_resolve_overflow: the closest-hit routine in the reference's order, then ResolveMisSlot.
+DEV void ResolveMisVisibility(const DScene &s, const Pool &pool, DevCounters *ctr, uint32_t slot, int word0, int npend, unsigned &zero) {
+    unsigned nodes = 0, tris = 0;
+    int flags = pool.I(I_FLAGS, slot);
+    const bool dark = (flags & F_MIS_DARK) != 0;   // (nothing reads the ray's answer)
+    bool exact = !dark && (npend & PEND_OVERFLOW) != 0, add = false;
+    if (!exact && !dark) {
+        const int misLight = s.nLights > 1 ? pool.I(I_MISLIGHT, slot) : 0;
+        const mi_light &l = s.lights[misLight];
+        if (l.type == MI_LIGHT_INFINITE) {   // Li = light.Le(ray) if nothing is hit, integrator.cpp:204
+            bool found = word0 >= 0;
+            if (!found && (npend & 0xff)) {
+                const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot);
+                Hit h;
+                found = ResolveQuadrics<true, false, false>(s, pool, slot, V3(r0.x, r0.y, r0.z), V3(r0.w, r1.x, r1.y), kInfinity, &h, false, nodes, tris, npend);
+            }
+            add = !found;
+        } else if (word0 >= 0) {}           // a primitive in front of the light's span
+        else if (word0 == -2 || (npend & 0xff)) exact = true;
+        else {                              // nothing up to the end of the span: the light's shape, if the ray meets it, is the closest hit
+            const float4 r0 = pool.R(R_MI0, slot), r1 = pool.R(R_MI1, slot);
+            const V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+            if (l.shape < 0) {
+                const mi_sphere &sp = s.spheres[~l.shape];
+                SurfaceInteraction li;
+                float t, t2;
+                if (SphereInteraction(sp, ro, rd, kInfinity, &li, &t)) {
+                    if (!SphereHitT(sp, ro, rd, r1.z, &t2)) exact = true;   // (its upper error bound lies beyond the span)
+                    else add = l.two_sided != 0 || Dot(li.n, -rd) > 0;
+                }
+            } else if (l.two_sided != 0) add = true;   // (k_shade: Shape::Pdf has intersected the triangle, else there is no ray)
+            else {
+                const int32_t *v = &s.triIndices[3 * l.shape];
+                TriHit th;
+                if (TriTest(LoadV3(s.P, v[0]), LoadV3(s.P, v[1]), LoadV3(s.P, v[2]), ro, rd, kInfinity, &th)) {
+                    SurfaceInteraction li;
+                    TriInteraction(s, l.shape, th.b0, th.b1, th.b2, rd, &li);
+                    add = Dot(li.n, -rd) > 0;
+                }
+            }
+        }
+    }
+    if (exact) { pool.ovfQ[2 * (size_t)pool.n + atomicAdd(&ctr->ovfCount[2].v, 1u)] = slot; return; }
+    bool added = false;
+    if (add) {
+        const bool lZero = (flags & F_L_ZERO) != 0;
+        for (int c = 0; c < NQ; ++c) {
+            const float4 a = pool.Q(Q_LMIS + c, slot);
+            added |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f);
+            float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!lZero) lq = pool.Q(LPlane(flags) + c, slot);
+            lq.x += a.x; lq.y += a.y; lq.z += a.z; lq.w += a.w;
+            pool.Q(LPlane(flags) + c, slot) = lq;
+        }
+        flags &= ~F_L_ZERO;
+    }
+    if (!added && !(flags & F_A_ADDED)) ++zero;
+    pool.I(I_FLAGS, slot) = flags & ~(F_NEE | F_MIS | F_A_ADDED | F_MIS_DARK);
+}
 template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_resolve_mis(DScene s, Pool pool, DevCounters *ctr) {
     const uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
     unsigned zero = 0;
     if (qi < ctr->misCount.v) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(pool.misQ + pool.n + 2 * (size_t)qi);   // k_trav<2>'s answer, in queue order
-        ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], (int)v.x, (int)v.y, zero);
+        const uint2 v = *reinterpret_cast<const uint2 *>(pool.misQ + pool.n + 2 * (size_t)qi);   // k_trav<2>'s / k_trav<3>'s answer, in queue order
+        if (!INST && s.misAny) ResolveMisVisibility(s, pool, ctr, pool.misQ[qi], (int)v.x, (int)v.y, zero);
+        else ResolveMisSlot<INST, false>(s, pool, ctr, pool.misQ[qi], (int)v.x, (int)v.y, zero);
     }
     CountAdd(&Stats(ctr).zeroRadiancePaths, zero);
 }
@@ -2255,9 +2380,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // Pdf_Li has no side effect: evaluate it before knowing whether f is black
                                 float weight = 1;
                                 bool go = true;
+                                float tShape = -1.f;   // a triangle light: where wi meets it
                                 if (!(sampledType & MI_BSDF_SPECULAR)) {
                                     const float lp = (TM_LIGHT(TM, MI_LIGHT_INFINITE) && light.type == MI_LIGHT_INFINITE) ? InfinitePdfLi(s, light, wi)
-                                                                                       : ShapePdf(s, light.shape, light.area, isect, wi);
+                                                                                       : ShapePdf(s, light.shape, light.area, isect, wi, &tShape);
                                     if (lp == 0) go = false;
                                     else { float pf = 1 * sPdf, pg = 1 * lp; weight = (pf * pf) / (pf * pf + pg * pg); }
                                 }
@@ -2270,7 +2396,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 // a ray that cannot reach the sampled area light is traced all the same (the reference
                                 // traces it), but its contribution is never read: F_MIS_DARK
                                 const Ray mr = SpawnRay(isect, wi);
-                                const bool dark = go && !isEnvLight && !RayMayHitBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1]);
+                                float spanLo = 0.f, spanHi = kInfinity;
+                                const bool dark = go && !isEnvLight && !RaySpanInBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1], &spanLo, &spanHi);
+                                float misTHi = kInfinity, misWord = __uint_as_float(MIS_EXCL_NONE | (31u << MIS_EXCL_BITS));   // (environment light, dark ray: any hit ends it)
+                                if (s.misAny && go && !dark && !isEnvLight) {
+                                    // a triangle: Shape::Pdf has intersected it (the same test the traversal runs); a sphere: its span in the dilated bounds
+                                    if (tShape > 0.f) MisSpanWords(tShape * (1.f - 1e-5f), tShape * (1.f + 1e-5f), (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
+                                    else MisSpanWords(spanLo * 0.9999f, spanHi, (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
+                                }
                                 if constexpr (ACCUM) {   // f of the sampled direction into the tile (only if something will read it)
                                     if (go) {
                                         if (ev.n > 0) AccumulateSpecular<NL, TM>(ev.lobes[0], mat->bxdf, ltp, rdTile, wrTile);
@@ -2376,7 +2509,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 if (fNonBlack && go) {
                                     if (dark) newFlags |= F_MIS_DARK;
                                     pool.R(R_MI0, slot) = make_float4(mr.o.x, mr.o.y, mr.o.z, mr.d.x);
-                                    pool.R(R_MI1, slot) = make_float4(mr.d.y, mr.d.z, 0.f, 0.f);
+                                    pool.R(R_MI1, slot) = make_float4(mr.d.y, mr.d.z, misTHi, misWord);
                                     if (s.nLights > 1) pool.I(I_MISLIGHT, slot) = lightNum;   // (one light: k_resolve_mis knows which)
                                     newFlags |= F_MIS;
                                 }
@@ -3439,6 +3572,26 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         }
         UP(lb.data(), lb.size(), s.lightBounds);
     }
+    {   // the area lights' primitives, and whether the MIS rays can be asked as visibility queries (k_trav, MODE 3): no
+        // instances and no alpha masks (the traversal kernels compiled for those keep the closest-hit form), and every
+        // area light the shape of exactly one primitive
+        std::vector<int> lp((size_t)std::max<uint32_t>(d->n_lights, 1), (int)MIS_EXCL_NONE), seen((size_t)std::max<uint32_t>(d->n_lights, 1), 0);
+        bool ok = !pt->hasInstances && !pt->hasAlphaMasks && d->n_prims < MIS_EXCL_NONE;
+        for (uint32_t i = 0; i < d->n_prims; ++i) {
+            const int al = d->prims[i].area_light;
+            if (al < 0) continue;
+            if ((uint32_t)al >= d->n_lights) { ok = false; continue; }
+            lp[al] = (int)i;
+            if (++seen[al] > 1 || d->prims[i].shape != d->lights[al].shape || d->prims[i].instance != 0) ok = false;
+        }
+        for (uint32_t i = 0; i < d->n_lights; ++i)
+            if (d->lights[i].type == MI_LIGHT_DIFFUSE_AREA && !seen[i]) ok = false;
+        UP(lp.data(), lp.size(), s.lightPrim);
+#ifdef MIPT_NO_MIS_ANY
+        ok = false;
+#endif
+        s.misAny = ok ? 1 : 0;
+    }
     UP(d->sampler.primes, d->sampler.n_dims, s.primes);
     UP(d->sampler.prime_sums, d->sampler.n_dims, s.primeSums);
     UP(d->sampler.perms, d->sampler.n_perms, s.perms);
@@ -3668,8 +3821,9 @@ static void SortQueueExperiment(mi_pt *pt, SubRenderer &sub, int mode) {
 #endif
 
 // The launches of one wavefront iteration, shared by RenderSub and the path-dump tool.
-static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid) {
-    if (mode == 1 && !pt->hasAlphaMasks && !pt->hasInstances && travGrid.x == (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU) travGrid.x = (unsigned)pt->numCUs * MIPT_TRAV_WAVES_PER_EU_ANY;   // (a full-size launch: one more block per CU)
+static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid, bool closestMis = false) {
+    if (mode == 2 && pt->scene.misAny && !closestMis) mode = 3;   // the MIS rays as visibility queries (k_trav, MODE 3)
+    if (TRAV_IS_ANY(mode) && !pt->hasAlphaMasks && !pt->hasInstances && travGrid.x == (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU) travGrid.x = (unsigned)pt->numCUs * MIPT_TRAV_WAVES_PER_EU_ANY;   // (a full-size launch: one more block per CU)
     const DScene &s = pt->scene;
     const dim3 block(BLOCK);
     hipStream_t st = sub.stream;
@@ -3686,6 +3840,7 @@ static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid
     } else {
         if (mode == 0) TRAV_LAUNCH_W(0, false);
         else if (mode == 1) TRAV_LAUNCH_W(1, false);
+        else if (mode == 3) TRAV_LAUNCH_W(3, false);
         else TRAV_LAUNCH_W(2, false);
     }
 #undef TRAV_LAUNCH_W
@@ -3869,7 +4024,7 @@ static int RenderSub(mi_pt *pt, SubRenderer &sub, const mi_render_params *rp, in
         LaunchTraversal(pt, sub, 2, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
-        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
+        if (pt->hasQuadrics || s.misAny) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());   // a launch of this iteration that was refused (bad configuration) stops the render here
@@ -4116,7 +4271,7 @@ int mi_pt_debug_path(mi_pt *pt, int32_t px, int32_t py, int64_t sample, int32_t 
         LaunchTraversal(pt, sub, 2, travGrid);
         if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_mis<true>), grid, block, 0, st, s, sub.pool, sub.ctr);
         else hipLaunchKernelGGL((k_resolve_mis<false>), grid, block, 0, st, s, sub.pool, sub.ctr);
-        if (pt->hasQuadrics) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
+        if (pt->hasQuadrics || s.misAny) { if (pt->hasInstances) hipLaunchKernelGGL((k_resolve_overflow<true>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2);
             else hipLaunchKernelGGL((k_resolve_overflow<false>), dim3(OVERFLOW_GRID), block, 0, st, s, sub.pool, sub.ctr, 2); }
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
@@ -4204,7 +4359,7 @@ int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, fl
     const dim3 chunkGrid(grid.x / SLOT_CHUNKS);
     const dim3 travGrid(std::min<unsigned>(grid.x, (unsigned)pt->numCUs * TRAV_BLOCKS_PER_CU));
     hipLaunchKernelGGL(k_trace_load, grid, block, 0, st, sub.pool, sub.ctr, dr.as<float>(), n, mode);
-    LaunchTraversal(pt, sub, mode, travGrid);
+    LaunchTraversal(pt, sub, mode, travGrid, true);   // (mode 2: the closest-hit kernel, whose records this call returns)
     hipLaunchKernelGGL(k_trace_raw, grid, block, 0, st, sub.pool, n, mode, dx.as<float>());
     const bool inst = pt->hasInstances;
 #define MIPT_BY_INST(K, G, ...) do { if (inst) hipLaunchKernelGGL((K<true>), G, block, 0, st, __VA_ARGS__); else hipLaunchKernelGGL((K<false>), G, block, 0, st, __VA_ARGS__); } while (0)

@@ -1259,3 +1259,70 @@ def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0,
         offs.append(p); p += len(c)
     with open(path, "wb") as f:
         f.write(struct.pack("<II", 20000630, 2) + header + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(chunks))
+
+
+MIS_SPAN_SCENE = """
+LookAt 0 2.5 -9  0 2 0  0 1 0
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
+Sampler "halton" "integer pixelsamples" [%(spp)d]
+Integrator "path" "integer maxdepth" [%(depth)d] "string lightsamplestrategy" "uniform"
+WorldBegin
+# (a) an emitter lying IN the ceiling: both of its triangles are coplanar with the two ceiling triangles, so a ray that
+#     reaches it meets the ceiling at the same t and the closest hit is whichever the reference tests first
+Material "matte" "rgb Kd" [.6 .6 .6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 5 -6  6 5 -6  6 5 8  -6 5 8]
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [6 6 5]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-2 5 -1  2 5 -1  2 5 3  -2 5 3]
+AttributeEnd
+# (b) a one-sided emitter on the left wall that faces the wall (its light goes into a 0.001 gap), and a two-sided one on the right
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  -6 0 8  -6 5 8  -6 5 -6]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [6 0 -6  6 5 -6  6 5 8  6 0 8]
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [9 3 3]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5.999 1 0  -5.999 1 3  -5.999 3 3  -5.999 3 0]
+AttributeEnd
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [3 3 9] "bool twosided" ["true"]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [5.5 1 0  5.5 3 0  5.5 3 3  5.5 1 3]
+AttributeEnd
+# (c) a sphere light sunk half into the back wall (geometry inside the span of its bounds), a partial one (a ray through the
+#     cut-away part misses it) with reversed orientation, and one inside a glass shell (a quadric on every ray towards it)
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 8  6 0 8  6 5 8  -6 5 8]
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [5 8 5]
+  Translate -3 2.5 8
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [8 8 3]
+  Translate 3 1.2 4
+  Rotate 40 1 0 0
+  ReverseOrientation
+  Shape "sphere" "float radius" [.7] "float phimax" [250] "float zmax" [.4]
+AttributeEnd
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [10 10 10]
+  Translate 0 1.5 5
+  Shape "sphere" "float radius" [.4]
+AttributeEnd
+AttributeBegin
+  Material "glass" "float index" [1.4]
+  Translate 0 1.5 5
+  Shape "sphere" "float radius" [.8]
+AttributeEnd
+# floor (glossy: its BSDF samples aim at the emitters), a matte block that hides part of every emitter from part of the floor
+Material "plastic" "rgb Kd" [.4 .4 .45] "rgb Ks" [.4 .4 .4] "float roughness" [.15]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 -6  6 0 -6  6 0 8  -6 0 8]
+Material "matte" "rgb Kd" [.7 .5 .3]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3  4 5 6 4 6 7  0 1 5 0 5 4  2 3 7 2 7 6  1 2 6 1 6 5  0 3 7 0 7 4]
+  "point P" [-1.5 0 1  1.5 0 1  1.5 0 2  -1.5 0 2  -1.5 2.2 1  1.5 2.2 1  1.5 2.2 2  -1.5 2.2 2]
+WorldEnd
+"""
+
+
+def mis_span_scene(res=64, spp=16, depth=5):
+    """Emitters whose BSDF-sampled (MIS) rays cannot be settled by a visibility query alone: coplanar with other geometry,
+    sunk into a wall, behind a quadric, partial, one-sided and facing away (k_trav MODE 3 / k_resolve_overflow)."""
+    return MIS_SPAN_SCENE % dict(res=res, spp=spp, depth=depth)

@@ -663,6 +663,20 @@ def test_rays_with_more_quadrics_than_the_pending_list_holds(pt, ob):
     assert ((extra[:, 2] & 0x100) != 0).sum() > 100   # (rays whose quadric list did overflow)
 
 
+def test_mis_rays_that_a_visibility_query_cannot_settle(pt, ob):
+    """On scenes without instances and alpha masks the BSDF-sampled ray of a direct-lighting estimate is traced as a
+    visibility query up to the span in which the sampled emitter can be hit (k_trav MODE 3); rays for which that does not
+    decide what integrator.cpp:196-203 reads -- something accepted inside the span (an emitter coplanar with the ceiling, a
+    sphere light sunk into a wall), a quadric on the way (a light in a glass shell) -- are traced again in the reference's
+    order. Exact-mode parity on a scene made of those cases, with one-sided emitters facing away, a two-sided one and a
+    partial sphere, under both light distributions."""
+    s = pt.Scene(text=st.mis_span_scene())
+    assert s.errors == [] and s.desc.n_lights == 9 and s.desc.n_spheres == 4
+    _parity(pt, ob, s, "MIS rays: emitters coplanar / sunk / in a shell / partial / one-sided")
+    s2 = pt.Scene(text=st.mis_span_scene(depth=3, spp=8).replace('"uniform"', '"power"'))
+    _parity(pt, ob, s2, "MIS rays, power light distribution")
+
+
 def test_roughness_textures_against_oracle(pt, ob, tmp_path):
     """Float image textures on the roughness parameters (plastic.cpp:57-62, uber.cpp:88-96, substrate.cpp:55-60,
     metal.cpp:66-73, translucent.cpp:70-72): the value at the hit, through RoughnessToAlpha unless "remaproughness" is off,
