@@ -906,7 +906,12 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                     const unsigned long long clearMask = __ballot(resClear);
                     const unsigned segClear = grant > 0 ? (unsigned)(clearMask >> base) & ((1u << grant) - 1u) : 0u;
                     if (segClear) { hitPrim = leafOff + (__ffs(segClear) - 1); finished = true; triCount += (unsigned)__ffs(segClear); }
-                    else { if (seg) ambiguous = true; triCount += (unsigned)grant; }
+                    else {
+#ifndef MIPT_EXP_IGNORE_AMBIGUOUS   // (mutation build: tests/test_gpu_parity.py::test_mis_rays_... must fail with it)
+                        if (seg) ambiguous = true;
+#endif
+                        triCount += (unsigned)grant;
+                    }
                 } else if (ANY) {
                     if (seg) { hitPrim = leafOff + (__ffs(seg) - 1); finished = true; triCount += (unsigned)__ffs(seg); }
                     else triCount += (unsigned)grant;
