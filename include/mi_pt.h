@@ -464,6 +464,11 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  *           scene without instances and alpha masks asks these rays as visibility queries bounded by the sampled emitter,
  *           k_trav<3>, and falls back to this closest-hit form for the rays that does not settle; this call always runs
  *           the closest-hit kernel.)
+ *   mode 3: the same rays as the visibility queries a render asks (k_trav<3>; only for scenes without instances and alpha
+ *           masks): tMax is the end of the span in which the sampled emitter could be hit, the span starts at
+ *           tMax (1 - 2^-8), no primitive is left out. hits[4i]: a primitive accepted in front of the span (any one: the
+ *           kernel stops at the first), -1 if nothing was accepted up to tMax, -2 if something was accepted only inside the
+ *           span (a render traces such a ray again in the reference's order); postponed quadrics are reported, not tested.
  * hits: as mi_pt_trace. extra (may be NULL): n x 4 words {b2 (float), instance of the hit (int32 bits, -1 = none),
  * the count of postponed quadrics as the traversal kernel left it (int32 bits: count | 0x100 on overflow),
  * the hit primitive as the traversal kernel left it, before the quadric step (int32 bits; -2 = the ray was never answered;

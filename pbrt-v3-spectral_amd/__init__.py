@@ -390,7 +390,8 @@ class PathIntegrator:
 
     def trace_wavefront(self, rays, mode=0):
         """The rays through the render's own kernels (mi_pt_trace_wavefront): mode 0 path rays (k_trav<0> + resolve),
-        1 shadow rays (tMax = 1 - 0.0001f), 2 MIS rays (tMax = inf). Returns (hits [n, 4] as trace(), extra [n, 4] int32 view:
+        1 shadow rays (tMax = 1 - 0.0001f), 2 MIS rays (tMax = inf), 3 MIS rays as visibility queries (tMax = the end of the
+        emitter's span; prim = an occluder, -1 or -2 = ambiguous). Returns (hits [n, 4] as trace(), extra [n, 4] int32 view:
         b2 bits, hit instance, raw I_NPEND, raw I_HITPRIM)."""
         rays = np.ascontiguousarray(rays, np.float32)
         n = rays.shape[0]

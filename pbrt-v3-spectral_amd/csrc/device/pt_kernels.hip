@@ -2405,9 +2405,22 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIPT
                                 const bool dark = go && !isEnvLight && !RaySpanInBox(mr.o, mr.d, s.lightBounds[2 * lightNum], s.lightBounds[2 * lightNum + 1], &spanLo, &spanHi);
                                 float misTHi = kInfinity, misWord = __uint_as_float(MIS_EXCL_NONE | (31u << MIS_EXCL_BITS));   // (environment light, dark ray: any hit ends it)
                                 if (s.misAny && go && !dark && !isEnvLight) {
-                                    // a triangle: Shape::Pdf has intersected it (the same test the traversal runs); a sphere: its span in the dilated bounds
-                                    if (tShape > 0.f) MisSpanWords(tShape * (1.f - 1e-5f), tShape * (1.f + 1e-5f), (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
-                                    else MisSpanWords(spanLo * 0.9999f, spanHi, (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
+                                    // a triangle: Shape::Pdf has intersected it (the same test the traversal runs); a sphere: its span in the
+                                    // dilated bounds. Either way widened by what the float arithmetic of the triangle and box tests can disagree
+                                    // by about where things are along the ray: those work on coordinates relative to the ray's origin, so their
+                                    // absolute error in t grows with the distance of the farthest vertex, a few ulps of it (a ray that starts
+                                    // 1e-3 above a 2000-unit ground plane meets it at a t that is 10 % noise, and the plane's box later than that:
+                                    // tests/test_gpu_parity.py::test_mis_visibility_kernel_verdicts_on_recorded_rays). 64 ulps of the distance to
+                                    // the far corner of the world bound: inside the span the reference's visiting order decides, outside it cannot.
+                                    const float far = maxf(absf(mr.o.x - s.wbMin[0]), absf(s.wbMax[0] - mr.o.x)) + maxf(absf(mr.o.y - s.wbMin[1]), absf(s.wbMax[1] - mr.o.y)) +
+                                                      maxf(absf(mr.o.z - s.wbMin[2]), absf(s.wbMax[2] - mr.o.z));
+#ifdef MIPT_EXP_NO_SPAN_SLACK   // (experiment build; no test scene so far tells it from the default)
+                                    const float slack = 0.f * far;
+#else
+                                    const float slack = far * 0x1p-18f;
+#endif
+                                    if (tShape > 0.f) MisSpanWords(tShape * (1.f - 1e-5f) - slack, tShape * (1.f + 1e-5f) + slack, (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
+                                    else MisSpanWords(spanLo * 0.9999f - slack, spanHi + slack, (unsigned)s.lightPrim[lightNum], &misTHi, &misWord);
                                 }
                                 if constexpr (ACCUM) {   // f of the sampled direction into the tile (only if something will read it)
                                     if (go) {
@@ -2887,13 +2900,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace_load(Pool pool, DevCounters *ct
             flags = F_ALIVE;
         } else {
             pool.R(mode == 1 ? R_SH0 : R_MI0, i) = make_float4(r[0], r[1], r[2], r[3]);
-            pool.R(mode == 1 ? R_SH1 : R_MI1, i) = make_float4(r[4], r[5], 0.f, 0.f);
+            // (mode 3, the visibility form of a MIS ray: the span ends at the given tMax and starts at tMax (1 - 2^-8); no primitive left out)
+            pool.R(mode == 1 ? R_SH1 : R_MI1, i) = make_float4(r[4], r[5], mode == 3 ? r[6] : 0.f, mode == 3 ? __uint_as_float(MIS_EXCL_NONE | (8u << MIS_EXCL_BITS)) : 0.f);
             (mode == 1 ? pool.shadowQ : pool.misQ)[i] = i;
             flags = mode == 1 ? (F_ALIVE | F_NEE | F_SHADOW | F_L_ZERO | F_CAND | F_NEE_NZ) : (F_ALIVE | F_NEE | F_MIS);
         }
         pool.I(I_HITPRIM, i) = -2;   // (every ray must be answered: k_trav overwrites this)
         if (mode == 1) pool.shadowQ[pool.n + i] = 0xfffffffeu;   // (... a shadow or MIS ray's answer lies beside its queue entry)
-        if (mode == 2) { pool.misQ[pool.n + 2 * (size_t)i] = 0xfffffffeu; pool.misQ[pool.n + 2 * (size_t)i + 1] = 0u; }
+        if (mode >= 2) { pool.misQ[pool.n + 2 * (size_t)i] = mode == 3 ? 0xfffffffdu : 0xfffffffeu; pool.misQ[pool.n + 2 * (size_t)i + 1] = 0u; }
         pool.I(I_NPEND, i) = 0;
         pool.I(I_HITINST, i) = -1;
         pool.I(I_MISLIGHT, i) = 0;
@@ -2910,7 +2924,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_raw(Pool pool, uint32_t n, int 
         extra[4 * (size_t)i + 3] = __int_as_float(v == 0xfffffffeu ? -2 : ((v >> 31) ? 0 : -1));
         return;
     }
-    if (mode == 2) {
+    if (mode >= 2) {
         extra[4 * (size_t)i + 2] = __int_as_float((int)pool.misQ[pool.n + 2 * (size_t)i + 1]);
         extra[4 * (size_t)i + 3] = __int_as_float((int)pool.misQ[pool.n + 2 * (size_t)i]);
         return;
@@ -2925,10 +2939,11 @@ template <bool INST>
 __global__ void __launch_bounds__(BLOCK) k_trace_read(DScene s, Pool pool, uint32_t n, int mode, float *hits, float *extra) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    int prim = mode == 2 ? (int)pool.misQ[pool.n + 2 * (size_t)i] : pool.I(I_HITPRIM, i), inst = -1;
+    int prim = mode >= 2 ? (int)pool.misQ[pool.n + 2 * (size_t)i] : pool.I(I_HITPRIM, i), inst = -1;
     float4 hr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode == 0) { hr = pool.R(R_HIT, i); if (INST) inst = pool.I(I_HITINST, i); }
     else if (mode == 1) prim = (pool.I(I_FLAGS, i) & F_L_ZERO) ? 0 : -1;
+    else if (mode == 3) {}   // (k_trav<3>'s verdict as it stands: an occluder, -1, -2 = ambiguous; -3 = never answered)
     else {
         const float4 r0 = pool.R(R_MI0, i), r1 = pool.R(R_MI1, i);
         const V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
@@ -2944,7 +2959,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_read(DScene s, Pool pool, uint3
         hr = make_float4(h.t, h.b0, h.b1, h.b2);
         inst = h.inst;
     }
-    const bool rec = prim >= 0 && mode != 1;
+    const bool rec = prim >= 0 && mode != 1 && mode != 3;
     float *o = hits + (size_t)i * 4;
     o[0] = __int_as_float(prim);
     o[1] = rec ? hr.x : 0.f; o[2] = rec ? hr.y : 0.f; o[3] = rec ? hr.z : 0.f;
@@ -4334,12 +4349,15 @@ int mi_pt_math_probe(int device_ordinal, int op, uint32_t n, const float *x, con
 
 int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra) {
     if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
-    if (mode < 0 || mode > 2) { g_err = "mi_pt_trace_wavefront: mode must be 0 (path rays), 1 (shadow rays) or 2 (MIS rays)"; return MI_ERR_INVALID; }
+    if (mode < 0 || mode > 3) { g_err = "mi_pt_trace_wavefront: mode must be 0 (path rays), 1 (shadow rays), 2 (MIS rays) or 3 (MIS rays as visibility queries)"; return MI_ERR_INVALID; }
+    if (mode == 3 && !pt->scene.misAny) { g_err = "mi_pt_trace_wavefront: mode 3 needs a scene without instances and alpha masks (others keep the closest-hit form of the MIS rays)"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;
     if (n > (1u << 24)) { g_err = "mi_pt_trace_wavefront: at most 16M rays per call"; return MI_ERR_INVALID; }
     // the kernels fix what the render fixes: a shadow ray ends at 1 - ShadowEpsilon (Interaction::SpawnRayTo), a BSDF-sampled
     // ray never ends (SpawnRay)
-    for (uint32_t i = 0; i < n && mode != 0; ++i) {
+    for (uint32_t i = 0; i < n && mode == 3; ++i)
+        if (!(rays[(size_t)i * 7 + 6] > 0)) { g_err = "mi_pt_trace_wavefront: mode 3 rays carry the end of the emitter's span, tMax > 0"; return MI_ERR_INVALID; }
+    for (uint32_t i = 0; i < n && (mode == 1 || mode == 2); ++i) {
         const float tMax = rays[(size_t)i * 7 + 6];
         if (mode == 1 ? tMax != 1 - kShadowEpsilon : !std::isinf(tMax) || tMax < 0) {
             g_err = mode == 1 ? "mi_pt_trace_wavefront: shadow rays (mode 1) carry tMax = 1 - 0.0001f" : "mi_pt_trace_wavefront: MIS rays (mode 2) carry tMax = +infinity";
@@ -4370,7 +4388,7 @@ int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, fl
 #define MIPT_BY_INST(K, G, ...) do { if (inst) hipLaunchKernelGGL((K<true>), G, block, 0, st, __VA_ARGS__); else hipLaunchKernelGGL((K<false>), G, block, 0, st, __VA_ARGS__); } while (0)
     if (mode == 0) MIPT_BY_INST(k_resolve_extend, chunkGrid, s, sub.pool, sub.ctr);
     else if (mode == 1) MIPT_BY_INST(k_resolve_shadow, grid, s, sub.pool, sub.ctr);
-    if (mode != 2 && pt->hasQuadrics) MIPT_BY_INST(k_resolve_overflow, dim3(OVERFLOW_GRID), s, sub.pool, sub.ctr, mode);
+    if (mode < 2 && pt->hasQuadrics) MIPT_BY_INST(k_resolve_overflow, dim3(OVERFLOW_GRID), s, sub.pool, sub.ctr, mode);
     MIPT_BY_INST(k_trace_read, grid, s, sub.pool, n, mode, dh.as<float>(), dx.as<float>());
 #undef MIPT_BY_INST
     HIPCHK(hipGetLastError());

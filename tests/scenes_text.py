@@ -1262,12 +1262,13 @@ def write_exr(path, img, compression="zip", dtype="half", data_window_origin=(0,
 
 
 MIS_SPAN_SCENE = """
-LookAt 0 2.5 -9  0 2 0  0 1 0
+LookAt %(ox)g 2.5 %(cz)g  %(ox)g 2 %(oz)g  0 1 0
 Camera "perspective" "float fov" [40]
 Film "image" "integer xresolution" [%(res)d] "integer yresolution" [%(res)d]
 Sampler "halton" "integer pixelsamples" [%(spp)d]
 Integrator "path" "integer maxdepth" [%(depth)d] "string lightsamplestrategy" "uniform"
 WorldBegin
+Translate %(ox)g 0 %(oz)g
 # (a) an emitter lying IN the ceiling: both of its triangles are coplanar with the two ceiling triangles, so a ray that
 #     reaches it meets the ceiling at the same t and the closest hit is whichever the reference tests first
 Material "matte" "rgb Kd" [.6 .6 .6]
@@ -1322,7 +1323,9 @@ WorldEnd
 """
 
 
-def mis_span_scene(res=64, spp=16, depth=5):
+def mis_span_scene(res=64, spp=16, depth=5, offset=0.0):
     """Emitters whose BSDF-sampled (MIS) rays cannot be settled by a visibility query alone: coplanar with other geometry,
-    sunk into a wall, behind a quadric, partial, one-sided and facing away (k_trav MODE 3 / k_resolve_overflow)."""
-    return MIS_SPAN_SCENE % dict(res=res, spp=spp, depth=depth)
+    sunk into a wall, behind a quadric, partial, one-sided and facing away (k_trav MODE 3 / k_resolve_overflow). `offset`
+    moves the whole scene and the camera that far from the origin along x and z (coarser floats: a coplanar emitter and
+    ceiling then differ by more in their computed hit distances)."""
+    return MIS_SPAN_SCENE % dict(res=res, spp=spp, depth=depth, ox=offset, oz=offset, cz=offset - 9)
