@@ -461,11 +461,11 @@ int mi_pt_trace(mi_pt *pt, const float *rays, uint32_t n, int any_hit, float *hi
  *           unnormalised vector to the light sample and tMax must be 1 - 0.0001f (Interaction::SpawnRayTo).
  *   mode 2: BSDF-sampled MIS rays -- k_trav<2>, then the quadric step of k_resolve_mis (the same device function; that
  *           kernel consumes the hit in place); closest hit, tMax must be +infinity (Interaction::SpawnRay). (A render of a
- *           scene without instances and alpha masks asks these rays as visibility queries bounded by the sampled emitter,
+ *           scene without instances (and without an alpha mask on an emitter's own mesh) asks these rays as visibility queries bounded by the sampled emitter,
  *           k_trav<3>, and falls back to this closest-hit form for the rays that does not settle; this call always runs
  *           the closest-hit kernel.)
- *   mode 3: the same rays as the visibility queries a render asks (k_trav<3>; only for scenes without instances and alpha
- *           masks): tMax is the end of the span in which the sampled emitter could be hit, the span starts at
+ *   mode 3: the same rays as the visibility queries a render asks (k_trav<3>; only for scenes without instances and
+ *           without an alpha mask on an emitter's own mesh): tMax is the end of the span in which the sampled emitter could be hit, the span starts at
  *           tMax (1 - 2^-8), no primitive is left out. hits[4i]: a primitive accepted in front of the span (any one: the
  *           kernel stops at the first), -1 if nothing was accepted up to tMax, -2 if something was accepted only inside the
  *           span (a render traces such a ray again in the reference's order); postponed quadrics are reported, not tested.

@@ -12,7 +12,7 @@
 //   shadow   : any-hit traversal of the NEE shadow rays, adds unoccluded contributions
 //   mis      : the BSDF-sampled rays of the direct-lighting estimates: is the closest hit the
 //              sampled light's shape? (a visibility query up to that shape, k_trav MODE 3; the
-//              closest-hit traversal, MODE 2, for scenes with instances or alpha masks); adds the
+//              closest-hit traversal, MODE 2, for scenes with instances or a masked emitter); adds the
 //              emission if so; closes the per-vertex direct-lighting statistics
 //
 // which restates, per path vertex, PathIntegrator::Li (src/integrators/path.cpp:64-188)
@@ -705,7 +705,7 @@ constexpr int TRAV_CHUNK = MIPT_TRAV_CHUNK;  // work-list entries a wave reserve
 // the pool and resumes the leaf -- with the instance ray's tMax if something was hit inside (`r.tMax = ray.tMax`). The
 // sequence of box tests, primitive tests and tMax updates per ray is the reference's recursion unrolled.
 template <int MODE, bool ALPHA, int W, bool INST = false>
-// MODE 3: the MIS rays again, as a visibility query (scenes without instances and alpha masks: DScene::misAny). The estimator
+// MODE 3: the MIS rays again, as a visibility query (scenes without instances and without an alpha mask on an emitter's own mesh: DScene::misAny). The estimator
 // reads one bit of a MIS ray -- is the closest hit the sampled light's shape (integrator.cpp:196-203) -- so k_shade hands
 // over the span [tLo, tHi] of the ray in which that shape can be hit and the shape's primitive, and this walks the tree as the
 // any-hit kernel does (no entry distances, no child ordering, five blocks per CU) with Triangle::Intersect's acceptance
@@ -721,7 +721,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
     constexpr bool PSEM = (MODE == 1);      // Triangle::IntersectP's acceptance rules (MODE 3 asks with Intersect's)
     constexpr bool MISANY = (MODE == 3);
     constexpr int QM = MISANY ? 2 : MODE;   // the queue and cursor of the class
-    static_assert(!(MISANY && (ALPHA || INST)), "the visibility form of the MIS rays is built for scenes without alpha masks and instances");
+    static_assert(!(MISANY && INST), "the visibility form of the MIS rays is not built for scenes with instances");
     int excl = -1;                          // MISANY: the sampled light's primitive
     float tLo = 0;                          // MISANY: hits accepted at or beyond it are ambiguous
     bool ambiguous = false;
@@ -894,7 +894,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                         bool counts = true;
                         if constexpr (ALPHA)
                             if (pf & PRIM_FLAG_ALPHA)
-                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
+                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, PSEM);   // (the shadow mask is IntersectP's alone, triangle.cpp:531-570)
                         res = counts && (PSEM || !(pf & PRIM_FLAG_DEGENERATE));
                         if (MISANY) { res = res && prim != wExcl; resClear = res && th.t < wLo; }
                         rT = th.t; rB0 = th.b0; rB1 = th.b1; rB2 = th.b2;
@@ -996,7 +996,7 @@ k_trav(DScene s, Pool pool, DevCounters *ctr) {
                         bool counts = true;
                         if constexpr (ALPHA)
                             if (pf & PRIM_FLAG_ALPHA)
-                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, ANY);
+                                counts = !(pf & PRIM_FLAG_DEGENERATE) && AlphaPass(s, __float_as_int(v1.w), th.b0, th.b1, th.b2, PSEM);   // (the shadow mask is IntersectP's alone, triangle.cpp:531-570)
                         if (!counts) {}
                         else if (PSEM) { hitPrim = prim; finished = true; }
                         else if (MISANY) {
@@ -3593,10 +3593,10 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
         UP(lb.data(), lb.size(), s.lightBounds);
     }
     {   // the area lights' primitives, and whether the MIS rays can be asked as visibility queries (k_trav, MODE 3): no
-        // instances and no alpha masks (the traversal kernels compiled for those keep the closest-hit form), and every
-        // area light the shape of exactly one primitive
+        // instances (the traversal kernels compiled for those keep the closest-hit form), no alpha mask on an emitter's own
+        // mesh, and every area light the shape of exactly one primitive
         std::vector<int> lp((size_t)std::max<uint32_t>(d->n_lights, 1), (int)MIS_EXCL_NONE), seen((size_t)std::max<uint32_t>(d->n_lights, 1), 0);
-        bool ok = !pt->hasInstances && !pt->hasAlphaMasks && d->n_prims < MIS_EXCL_NONE;
+        bool ok = !pt->hasInstances && d->n_prims < MIS_EXCL_NONE;
         for (uint32_t i = 0; i < d->n_prims; ++i) {
             const int al = d->prims[i].area_light;
             if (al < 0) continue;
@@ -3604,8 +3604,16 @@ int mi_pt_create(const mi_scene_desc *d, int device_ordinal, mi_pt **out) {
             lp[al] = (int)i;
             if (++seen[al] > 1 || d->prims[i].shape != d->lights[al].shape || d->prims[i].instance != 0) ok = false;
         }
-        for (uint32_t i = 0; i < d->n_lights; ++i)
-            if (d->lights[i].type == MI_LIGHT_DIFFUSE_AREA && !seen[i]) ok = false;
+        for (uint32_t i = 0; i < d->n_lights; ++i) {
+            const mi_light &l = d->lights[i];
+            if (l.type != MI_LIGHT_DIFFUSE_AREA) continue;
+            if (!seen[i]) ok = false;
+            // an emitter whose own mesh is masked: Shape::Pdf intersects it without the mask (shape.cpp:60), the traversal with it
+            if (l.shape >= 0 && (uint32_t)l.shape < d->n_tris) {
+                const mi_mesh &m = d->meshes[d->tri_mesh[l.shape]];
+                if (m.alpha_tex >= 0 || m.shadow_alpha_tex >= 0) ok = false;
+            }
+        }
         UP(lp.data(), lp.size(), s.lightPrim);
 #ifdef MIPT_NO_MIS_ANY
         ok = false;
@@ -3856,6 +3864,7 @@ static void LaunchTraversal(mi_pt *pt, SubRenderer &sub, int mode, dim3 travGrid
     } else if (pt->hasAlphaMasks) {
         if (mode == 0) TRAV_LAUNCH_W(0, true);
         else if (mode == 1) TRAV_LAUNCH_W(1, true);
+        else if (mode == 3) TRAV_LAUNCH_W(3, true);
         else TRAV_LAUNCH_W(2, true);
     } else {
         if (mode == 0) TRAV_LAUNCH_W(0, false);
@@ -4350,7 +4359,7 @@ int mi_pt_math_probe(int device_ordinal, int op, uint32_t n, const float *x, con
 int mi_pt_trace_wavefront(mi_pt *pt, const float *rays, uint32_t n, int mode, float *hits, float *extra) {
     if (!pt || !rays || !hits) { g_err = "null argument"; return MI_ERR_INVALID; }
     if (mode < 0 || mode > 3) { g_err = "mi_pt_trace_wavefront: mode must be 0 (path rays), 1 (shadow rays), 2 (MIS rays) or 3 (MIS rays as visibility queries)"; return MI_ERR_INVALID; }
-    if (mode == 3 && !pt->scene.misAny) { g_err = "mi_pt_trace_wavefront: mode 3 needs a scene without instances and alpha masks (others keep the closest-hit form of the MIS rays)"; return MI_ERR_INVALID; }
+    if (mode == 3 && !pt->scene.misAny) { g_err = "mi_pt_trace_wavefront: mode 3 needs a scene without instances and without an alpha mask on an emitter's mesh (others keep the closest-hit form of the MIS rays)"; return MI_ERR_INVALID; }
     if (n == 0) return MI_OK;
     if (n > (1u << 24)) { g_err = "mi_pt_trace_wavefront: at most 16M rays per call"; return MI_ERR_INVALID; }
     // the kernels fix what the render fixes: a shadow ray ends at 1 - ShadowEpsilon (Interaction::SpawnRayTo), a BSDF-sampled

@@ -664,7 +664,7 @@ def test_rays_with_more_quadrics_than_the_pending_list_holds(pt, ob):
 
 
 def test_mis_rays_that_a_visibility_query_cannot_settle(pt, ob):
-    """On scenes without instances and alpha masks the BSDF-sampled ray of a direct-lighting estimate is traced as a
+    """On scenes without instances (and without an alpha mask on an emitter's own mesh) the BSDF-sampled ray of a direct-lighting estimate is traced as a
     visibility query up to the span in which the sampled emitter can be hit (k_trav MODE 3); rays for which that does not
     decide what integrator.cpp:196-203 reads -- something accepted inside the span (an emitter coplanar with the ceiling, a
     sphere light sunk into a wall), a quadric on the way (a light in a glass shell) -- are traced again in the reference's
